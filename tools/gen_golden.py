@@ -1,0 +1,474 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures under tests/golden/ by importing the reference.
+
+Runs ONLY in the build container (needs /root/reference); the GPU box never runs
+it.  Must be started as ``python3 -B tools/gen_golden.py`` so that no bytecode
+is written into the (root-writable) reference tree.
+
+What is imported from the reference (read-only, executed as-is):
+  src/rl/windows_workspace/specific/customEnv.py   Revolt, RevoltSimple/Limited/Final
+  src/rl/windows_workspace/specific/errorFrame.py  ErrorFrame
+  src/rl/windows_workspace/spinup/algos/tf1/ppo/ppo.py   TrajectoryBuffer
+  src/rl/windows_workspace/spinup/algos/tf1/ppo/core.py  discount_cumsum
+  src/sl/SupervisedTau.py                          SupervisedTau.B / F / tau
+behind stub modules for gym / keras / tensorflow / mpi4py (absent here) and a
+scripted fake plant that implements the reference's own plant seam
+``val(module, feature, value=None)`` / ``step(n)`` (digitwin.py:50-114,213-219).
+
+The closed-source Cybersea plant is NOT available, so the fake plant replays
+scripted (eta, nu) values: fixtures pin everything around the integrator
+(action decode, command writes, observation, reward parts, termination, reset
+writes, new_ref timing, GAE) - never the integrator itself.
+
+Each env variant is built in a fresh interpreter because RevoltLimited/Final
+mutate a shared default list (customEnv.py:26,361,386).
+
+Only data (inputs + expected outputs) is written; no reference source text.
+"""
+import os
+import subprocess
+import sys
+import types
+
+sys.dont_write_bytecode = True
+import numpy as np
+
+REF = '/root/reference'
+WW = os.path.join(REF, 'src/rl/windows_workspace')
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+
+MODES = {
+    # name: (class name, ctor kwargs, act_dim)
+    'full': ('Revolt', dict(), 6),
+    'simple': ('RevoltSimple', dict(), 3),
+    'limited': ('RevoltLimited', dict(), 5),
+    'final_wrap': ('RevoltFinal', dict(cont_ang=False), 5),
+    'final_cont': ('RevoltFinal', dict(cont_ang=True), 7),
+}
+
+
+def install_stubs():
+    gym = types.ModuleType('gym')
+    spaces = types.ModuleType('gym.spaces')
+
+    class Env(object):
+        pass
+
+    class Box(object):
+        def __init__(self, low, high, dtype=None):
+            self.low, self.high, self.shape, self.dtype = low, high, low.shape, dtype
+
+    class Discrete(object):
+        def __init__(self, n):
+            self.n = n
+
+    gym.Env = Env
+    spaces.Box = Box
+    spaces.Discrete = Discrete
+    gym.spaces = spaces
+    sys.modules['gym'] = gym
+    sys.modules['gym.spaces'] = spaces
+    keras = types.ModuleType('keras')
+    kb = types.ModuleType('keras.backend')
+    keras.backend = kb
+    sys.modules['keras'] = keras
+    sys.modules['keras.backend'] = kb
+
+
+def install_tf_mpi_stubs():
+    class _Any(object):
+        def __getattr__(self, k):
+            return _Any()
+
+        def __call__(self, *a, **k):
+            return _Any()
+
+    tf = types.ModuleType('tensorflow')
+    tf.__getattr__ = lambda k: _Any()
+    train = types.ModuleType('tensorflow.train')
+    train.AdamOptimizer = object
+    tf.train = train
+    sys.modules['tensorflow'] = tf
+    sys.modules['tensorflow.train'] = train
+
+    mpi4py = types.ModuleType('mpi4py')
+    MPI = types.ModuleType('mpi4py.MPI')
+
+    class Comm(object):
+        def Get_rank(self):
+            return 0
+
+        def Get_size(self):
+            return 1
+
+        def Allreduce(self, x, buf, op=None):
+            buf[...] = x
+
+        def Bcast(self, x, root=0):
+            pass
+
+    MPI.COMM_WORLD = Comm()
+    MPI.SUM, MPI.MIN, MPI.MAX = 'sum', 'min', 'max'
+    mpi4py.MPI = MPI
+    sys.modules['mpi4py'] = mpi4py
+    sys.modules['mpi4py.MPI'] = MPI
+    for name in ('joblib', ):
+        pass
+
+
+class ScriptedPlant(object):
+    """Implements the reference's plant seam; records writes, replays reads."""
+
+    def __init__(self):
+        self.eta = [0.0] * 6
+        self.yaw = 0.0
+        self.nu = [0.0] * 6
+        self.log = []
+        self.next_state = None   # (eta3, nu3) applied by the next step(20)
+        self.reset_state = None  # filled from Hull.* writes, applied by step(50)
+
+    def set3(self, eta3, nu3):
+        self.eta = [float(eta3[0]), float(eta3[1]), 0.0, 0.0, 0.0, float(eta3[2])]
+        self.yaw = float(eta3[2])
+        self.nu = [float(nu3[0]), float(nu3[1]), 0.0, 0.0, 0.0, float(nu3[2])]
+
+    def val(self, module, feat, val=None, report=False):
+        if val is None:
+            return {'Yaw': self.yaw, 'Eta': self.eta, 'Nu': self.nu}[feat]
+        self.log.append((module, feat, val))
+        if module == 'Hull':
+            if self.reset_state is None:
+                self.reset_state = {}
+            self.reset_state[feat] = val
+        return None
+
+    def step(self, n):
+        self.log.append(('step', '', n))
+        if n == 50 and self.reset_state is not None:
+            rs = self.reset_state
+            if 'PosNED' in rs and 'PosAttitude' in rs and 'VelocityNu' in rs:
+                nu6 = rs['VelocityNu']
+                self.set3([rs['PosNED'][0], rs['PosNED'][1], rs['PosAttitude'][2]],
+                          [nu6[0], nu6[1], nu6[5]])
+            self.reset_state = None
+        elif self.next_state is not None:
+            self.set3(*self.next_state)
+            self.next_state = None
+
+
+def f32(x):
+    """Round to float32 and return as float64 so fp32 kernels see identical inputs."""
+    return np.asarray(x, dtype=np.float32).astype(np.float64)
+
+
+def cmds_from_log(log):
+    """Return thrust[3] (THR1..3) and azimuth[3] (THR1..3; nan = not written) + step count."""
+    thrust = [np.nan] * 3
+    azm = [np.nan] * 3
+    nstep = 0
+    for m, f, v in log:
+        if m == 'step':
+            nstep += v
+        elif f == 'ThrustOrTorqueCmdMtc':
+            thrust[int(m[3]) - 1] = v
+        elif f == 'AzmCmdMtc':
+            azm[int(m[3]) - 1] = v
+    return thrust, azm, nstep
+
+
+def gen_mode(mode):
+    install_stubs()
+    sys.path.insert(0, WW)
+    import specific.customEnv as CE
+    cls_name, kw, act_dim = MODES[mode]
+    cls = getattr(CE, cls_name)
+    rng = np.random.RandomState(1234 + sorted(MODES).index(mode))
+    out = {}
+
+    for ext in (True, False):
+        if mode == 'simple' and ext:
+            # reference indexes real_action_bounds[4] in the angular penalty
+            # (customEnv.py:319) but simple has 3 bounds -> IndexError; record that.
+            plant = ScriptedPlant()
+            env = cls(plant, extended_state=True, **kw)
+            env.reset()
+            plant.next_state = ([0.1, 0.2, 0.0], [0.0, 0.0, 0.0])
+            try:
+                env.step(np.zeros(act_dim))
+                crashed = 0
+            except IndexError:
+                crashed = 1
+            out['simple_ext_raises_indexerror'] = np.array([crashed])
+            continue
+        tag = 'ext' if ext else 'base'
+        plant = ScriptedPlant()
+        env = cls(plant, extended_state=ext, **kw)
+        M = 384
+        obs_dim = 9 if ext else 6
+        # ---- single-step cases with explicit pre-state -------------------
+        A = f32(rng.normal(0.0, 0.9, size=(M, act_dim)))
+        A[:32] = f32(rng.uniform(-3.2, 3.2, size=(32, act_dim)))    # far outside [-1,1]: clip + wrap
+        A[32:40] = 0.0
+        if mode == 'final_cont':
+            A[40:44, 3:] = 0.0                                        # atan2(0,0)
+            A[44, 3:] = [0.0, -1.0, 0.0, -1.0]                        # atan2(0,-1) = pi
+            A[45, 3:] = f32([-1e-8, -1.0, 1e-8, -1.0])                # +-pi crossing
+        pre_thrust = f32(rng.uniform(-100, 100, size=(M, 3)))
+        pre_angles = f32(rng.uniform(-np.pi, np.pi, size=(M, 3)))
+        ref = f32(rng.uniform(-5, 5, size=(M, 3)) * np.array([1, 1, 0.2]))
+        ref[:64] = 0.0
+        eta = f32(rng.uniform(-9, 9, size=(M, 3)) * np.array([1, 1, 0.12]))
+        nu = f32(rng.uniform(-1, 1, size=(M, 3)) * np.array([1.6, 0.35, 0.6]))
+        eta[64:72, 2] = f32(rng.uniform(-7, 7, size=8))              # |psi| > pi (quirk Q1)
+        eta[72:76, 2] = f32([200.0, -200.0, 181.0, -181.0])          # beyond +-180: deg-mode wrap fires
+        eta[76:96] = f32(rng.normal(0, 0.3, size=(20, 3)) * np.array([1, 1, 0.05]))  # near setpoint
+        ref[76:96] = 0.0
+        nu[76:96] *= 0.1
+        # termination boundary cases each side of every bound
+        bnds = list(env.real_ss_bounds)
+        k = 96
+        for i, b in enumerate(bnds):
+            for sgn in (1.0, -1.0):
+                for eps in (1e-3, -1e-3):
+                    eta[k] = 0.0
+                    nu[k] = 0.0
+                    ref[k] = 0.0
+                    val = sgn * b * (1.0 + eps)
+                    if i < 3:
+                        eta[k, i] = val
+                    else:
+                        nu[k, i - 3] = val
+                    k += 1
+        eta, nu = f32(eta), f32(nu)
+        new_ref = f32(rng.uniform(-5, 5, size=(M, 3)))
+        use_new_ref = (rng.uniform(size=M) < 0.25)
+
+        cmd_thrust = np.zeros((M, 3))
+        cmd_azm = np.full((M, 3), np.nan)
+        nstep = np.zeros(M, dtype=np.int64)
+        ang_after = np.zeros((M, 3))
+        prev_ang_after = np.zeros((M, 3))
+        obs = np.zeros((M, obs_dim))
+        rew = np.zeros(M)
+        parts = np.zeros((M, 4))
+        done = np.zeros(M, dtype=np.uint8)
+        ref_after = np.zeros((M, 3))
+        thrust_after = np.zeros((M, 3))
+        for i in range(M):
+            env.prev_thrust = [float(x) for x in pre_thrust[i]]
+            env.current_angles = [float(x) for x in pre_angles[i]]
+            env.prev_angles = [0.0, 0.0, 0.0]
+            env.EF.update(ref=[float(x) for x in ref[i]] if np.any(ref[i] != 0) else [0.0, 0.0, 0.0])
+            plant.log = []
+            plant.next_state = (eta[i], nu[i])
+            nr = [float(x) for x in new_ref[i]] if use_new_ref[i] else None
+            s, r, d, info = env.step(A[i].copy(), new_ref=nr)
+            t, a, n = cmds_from_log(plant.log)
+            cmd_thrust[i], cmd_azm[i], nstep[i] = t, a, n
+            ang_after[i] = env.current_angles
+            prev_ang_after[i] = env.prev_angles
+            obs[i] = s
+            rew[i] = float(np.asarray(r).reshape(-1)[0])
+            # parts are pure functions of the post-step env state; ref may already be the
+            # new one (quirk Q4) so restore the old ref for the pose-dependent part.
+            if nr is not None:
+                env.EF.update(ref=[float(x) for x in ref[i]])
+            parts[i, 0] = env.vel_reward()
+            parts[i, 1] = float(np.asarray(env.multivariate_gaussian()).reshape(-1)[0])
+            parts[i, 2] = env.thrust_penalty([0.20, 0.30, 0.30])
+            parts[i, 3] = env.action_derivative_penalty(thrust=True, pen_coeff=[0.05, 0.05, 0.05],
+                                                        angular=True, ang_coeff=[0.00, 0.01, 0.01])
+            if nr is not None:
+                env.EF.update(ref=nr)
+            done[i] = 1 if d else 0
+            ref_after[i] = env.EF.get_NED_ref()
+            thrust_after[i] = env.prev_thrust
+        assert np.allclose(parts.sum(1), rew, rtol=0, atol=1e-12)
+        p = 'step_%s_' % tag
+        out.update({p + 'action': A, p + 'pre_thrust': pre_thrust, p + 'pre_angles': pre_angles,
+                    p + 'ref': ref, p + 'eta': eta, p + 'nu': nu, p + 'new_ref': new_ref,
+                    p + 'use_new_ref': use_new_ref.astype(np.uint8),
+                    p + 'cmd_thrust': cmd_thrust, p + 'cmd_azm': cmd_azm, p + 'nstep': nstep,
+                    p + 'angles_after': ang_after, p + 'prev_angles_after': prev_ang_after,
+                    p + 'obs': obs, p + 'reward': rew, p + 'reward_parts': parts, p + 'done': done,
+                    p + 'ref_after': ref_after, p + 'thrust_after': thrust_after})
+
+        # ---- sequences: reset + T steps with scripted plant, new_ref mid-way ----
+        S, T = 6, 10
+        seq_action = f32(rng.normal(0, 0.7, size=(S, T, act_dim)))
+        seq_init = f32(rng.uniform(-4, 4, size=(S, 6)) * np.array([1, 1, 0.1, 0.2, 0.05, 0.05]))
+        seq_eta = f32(rng.uniform(-6, 6, size=(S, T, 3)) * np.array([1, 1, 0.1]))
+        seq_nu = f32(rng.uniform(-1, 1, size=(S, T, 3)) * np.array([1.0, 0.25, 0.4]))
+        seq_newref = f32(rng.uniform(-5, 5, size=(S, 3)) * np.array([1, 1, 0.1]))
+        seq_obs0 = np.zeros((S, obs_dim))
+        seq_obs = np.zeros((S, T, obs_dim))
+        seq_rew = np.zeros((S, T))
+        seq_done = np.zeros((S, T), dtype=np.uint8)
+        seq_reset_nlog = np.zeros(S, dtype=np.int64)
+        reset_writes = []
+        for s_i in range(S):
+            env.EF.update(ref=[0.0, 0.0, 0.0])
+            plant.log = []
+            init = {'Hull.PosNED': [float(seq_init[s_i, 0]), float(seq_init[s_i, 1])],
+                    'Hull.PosAttitude': [0, 0, float(seq_init[s_i, 2])],
+                    'Hull.VelocityNu': [float(seq_init[s_i, 3]), float(seq_init[s_i, 4]), 0, 0, 0,
+                                        float(seq_init[s_i, 5])]}
+            seq_obs0[s_i] = env.reset(**init)
+            seq_reset_nlog[s_i] = len(plant.log)
+            if s_i == 0:
+                reset_writes = ['%s.%s=%s' % (m, f, np.round(np.asarray(v, dtype=float), 12).tolist())
+                                for m, f, v in plant.log]
+            for t in range(T):
+                plant.next_state = (seq_eta[s_i, t], seq_nu[s_i, t])
+                nr = [float(x) for x in seq_newref[s_i]] if t == T // 2 else None
+                o, r, d, _ = env.step(seq_action[s_i, t].copy(), new_ref=nr)
+                seq_obs[s_i, t] = o
+                seq_rew[s_i, t] = float(np.asarray(r).reshape(-1)[0])
+                seq_done[s_i, t] = 1 if d else 0
+        p = 'seq_%s_' % tag
+        out.update({p + 'action': seq_action, p + 'init': seq_init, p + 'eta': seq_eta, p + 'nu': seq_nu,
+                    p + 'new_ref': seq_newref, p + 'new_ref_step': np.array([T // 2]),
+                    p + 'obs0': seq_obs0, p + 'obs': seq_obs, p + 'reward': seq_rew, p + 'done': seq_done,
+                    p + 'reset_writes': np.array(reset_writes)})
+
+    # ---- constants the host shim must mirror --------------------------------
+    plant = ScriptedPlant()
+    env = cls(plant, extended_state=True, **kw)
+    out['real_ss_bounds'] = np.array(env.real_ss_bounds, dtype=np.float64)
+    out['real_action_bounds'] = np.array(env.real_action_bounds, dtype=np.float64)
+    out['default_actions'] = np.array([env.default_actions[i] for i in range(6)], dtype=np.float64)
+    out['valid_action_indices'] = np.array(env.valid_action_indices)
+    out['meta'] = np.array([env.dt, env.n_steps, env.max_ep_len, env.num_actions, env.num_states])
+    out['name'] = np.array([env.name])
+    env_t = cls(plant, testing=True, realtime=True, **kw)
+    out['meta_testing_realtime'] = np.array([env_t.dt, env_t.n_steps, env_t.max_ep_len])
+    env_400 = cls(plant, max_ep_len=800, **kw)
+    out['max_ep_len_800'] = np.array([env_400.max_ep_len])
+
+    # ---- reset samplers (deterministic parts + ranges) -----------------------
+    from specific.misc import simtools as ST
+    import io
+    import contextlib
+    fixed = []
+    for n in range(6):
+        with contextlib.redirect_stdout(io.StringIO()):
+            fixed.append(ST.get_fixed_pose_on_radius(n))
+    out['fixed_pose_on_radius'] = np.array(fixed)
+    np.random.seed(7)
+    tr = np.array([list(ST.get_pose_on_state_space(env.real_ss_bounds[0:3], fraction=0.8)) +
+                   list(ST.get_vel_on_state_space(env.real_ss_bounds[3:], fraction=0.3 * 0.8))
+                   for _ in range(4000)])
+    out['train_reset_absmax'] = np.abs(tr).max(0)
+    out['train_reset_mean'] = tr.mean(0)
+    out['train_reset_std'] = tr.std(0)
+    rr = np.array([ST.get_random_pose_on_radius() for _ in range(2000)])
+    out['radius_reset_r'] = np.array([np.hypot(rr[:, 0], rr[:, 1]).min(), np.hypot(rr[:, 0], rr[:, 1]).max()])
+    out['radius_reset_yaw_absmax'] = np.array([np.abs(rr[:, 2]).max()])
+
+    np.savez_compressed(os.path.join(OUT, 'env_%s.npz' % mode), **out)
+    print('wrote env_%s.npz (%d arrays)' % (mode, len(out)))
+
+
+def gen_errorframe():
+    install_stubs()
+    sys.path.insert(0, WW)
+    from specific.errorFrame import ErrorFrame
+    rng = np.random.RandomState(99)
+    M = 256
+    pos = f32(rng.uniform(-10, 10, size=(M, 3)) * np.array([1, 1, 0.7]))
+    ref = f32(rng.uniform(-10, 10, size=(M, 3)) * np.array([1, 1, 0.7]))
+    pos[:4, 2] = f32([3.0, -3.0, 185.0, -190.0])
+    ref[:4, 2] = f32([-3.0, 3.0, 0.0, 1.0])
+    pos, ref = f32(pos), f32(ref)
+    err = np.array([ErrorFrame(pos=[float(x) for x in pos[i]], ref=[float(x) for x in ref[i]]).get_pose()
+                    for i in range(M)])
+    smoke = np.array(ErrorFrame(pos=[1, 2, 0.5], ref=[0.5, -1, 0.1]).get_pose())
+    np.savez_compressed(os.path.join(OUT, 'errorframe.npz'), pos=pos, ref=ref, err=err, smoke=smoke)
+    print('wrote errorframe.npz')
+
+
+def gen_gae():
+    install_stubs()
+    install_tf_mpi_stubs()
+    sys.path.insert(0, WW)
+    from spinup.algos.tf1.ppo.ppo import TrajectoryBuffer
+    import spinup.algos.tf1.ppo.core as core
+    from spinup.utils.mpi_tools import mpi_statistics_scalar
+    rng = np.random.RandomState(5)
+    out = {}
+    out['dc_x'] = np.array([1.0, 2.0, 3.0])
+    out['dc_y'] = core.discount_cumsum(np.array([1.0, 2.0, 3.0]), 0.5)
+    size, obs_dim, act_dim = 24, 9, 7
+    buf = TrajectoryBuffer(obs_dim, act_dim, size, gamma=0.99, lam=0.97)
+    obs = rng.normal(size=(size, obs_dim)).astype(np.float32)
+    act = rng.normal(size=(size, act_dim)).astype(np.float32)
+    rew = rng.normal(1.0, 1.0, size=size).astype(np.float32)
+    val = rng.normal(0.5, 1.0, size=size).astype(np.float32)
+    logp = rng.normal(-3, 1.0, size=size).astype(np.float32)
+    # three paths: len 7 ending terminal (last_val 0), len 9 cut by time limit (bootstrap), len 8 epoch cut
+    path_ends = [7, 16, 24]
+    last_vals = [0.0, 0.731, -0.25]
+    k = 0
+    for t in range(size):
+        buf.store(obs[t], act[t], rew[t], val[t], logp[t])
+        if t + 1 == path_ends[k]:
+            buf.finish_path(last_vals[k])
+            k += 1
+    adv_raw = buf.adv_buf.copy()
+    ret = buf.ret_buf.copy()
+    o, a, adv, r, lp = buf.get()
+    mean, std = mpi_statistics_scalar(adv_raw)
+    out.update(dict(gae_obs=obs, gae_act=act, gae_rew=rew, gae_val=val, gae_logp=logp,
+                    gae_path_ends=np.array(path_ends), gae_last_vals=np.array(last_vals),
+                    gae_adv_raw=adv_raw, gae_ret=ret, gae_adv_norm=adv, gae_mean_std=np.array([mean, std]),
+                    gae_gamma_lam=np.array([0.99, 0.97])))
+    np.savez_compressed(os.path.join(OUT, 'gae.npz'), **out)
+    print('wrote gae.npz')
+
+
+def gen_forcemap():
+    sys.path.insert(0, os.path.join(REF, 'src/sl'))
+    from SupervisedTau import SupervisedTau
+    st = SupervisedTau()
+    rng = np.random.RandomState(3)
+    M = 256
+    a = f32(rng.uniform(-np.pi, np.pi, size=(M, 3)))
+    u = f32(rng.uniform(-100, 100, size=(M, 3)))
+    a[0] = f32([0.3, -0.4, np.pi / 2])
+    u[0] = [50, -25, 100]
+    a[1:9, 2] = f32(np.pi / 2)
+    a, u = f32(a), f32(u)
+    tau = np.zeros((M, 3))
+    F = np.zeros((M, 3))
+    B = np.zeros((M, 3, 3))
+    for i in range(M):
+        ai = a[i].reshape(3, 1)
+        ui = u[i].reshape(3, 1)
+        tau[i] = np.asarray(st.tau(ai, ui), dtype=np.float64).reshape(3)
+        F[i] = np.asarray(st.F(ui), dtype=np.float64).reshape(3)
+        B[i] = np.asarray(st.B(ai), dtype=np.float64).reshape(3, 3)
+    np.savez_compressed(os.path.join(OUT, 'forcemap.npz'), alpha=a, u=u, tau=tau, F=F, B=B,
+                        lx=np.array(st.lx, dtype=np.float64), ly=np.array(st.ly, dtype=np.float64),
+                        K_fwd=np.array([0.0027, 0.0027, 0.001518]), K_rev=np.array([0.0027, 0.0027, 0.0006172]))
+    print('wrote forcemap.npz')
+
+
+def main():
+    if len(sys.argv) > 1:
+        what = sys.argv[1]
+        if what in MODES:
+            gen_mode(what)
+        else:
+            {'errorframe': gen_errorframe, 'gae': gen_gae, 'forcemap': gen_forcemap}[what]()
+        return
+    assert os.path.isdir(REF), 'reference tree not present: fixtures can only be regenerated in the build container'
+    os.makedirs(OUT, exist_ok=True)
+    for what in list(MODES) + ['errorframe', 'gae', 'forcemap']:
+        subprocess.check_call([sys.executable, '-B', os.path.abspath(__file__), what])
+    # the reference tree must stay pristine
+    for root, dirs, files in os.walk(REF):
+        assert '__pycache__' not in dirs, 'bytecode leaked into reference tree: ' + root
+
+
+if __name__ == '__main__':
+    main()

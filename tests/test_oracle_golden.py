@@ -1,0 +1,238 @@
+"""Pins the CPU oracle (oracle/) against golden vectors produced by the imported reference
+(tools/gen_golden.py).  CPU only.  float64 build: libm-noise agreement; float32 build: 1e-5."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import tolerances as TOL
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+MODES = ['full', 'simple', 'limited', 'final_wrap', 'final_cont']
+
+
+def load(name):
+    return np.load(os.path.join(G, name + '.npz'))
+
+
+def cases():
+    for m in MODES:
+        for tag in ('ext', 'base'):
+            if m == 'simple' and tag == 'ext':
+                continue
+            for dt in (np.float64, np.float32):
+                yield m, tag, dt
+
+
+def close(a, b, floor, dt, what):
+    if dt == np.float64:
+        assert np.allclose(a, b, rtol=0, atol=TOL.ATOL_F64), '%s max err %g' % (what, np.abs(np.asarray(a) - b).max())
+    else:
+        TOL.assert_close(a, b, floor, what=what)
+
+
+@pytest.mark.parametrize('mode,tag,dt', list(cases()))
+def test_single_step_cases(mode, tag, dt):
+    """customEnv.py:92-133 with the plant replaced by scripted (eta, nu): commands written,
+    azimuth bookkeeping, observation, reward parts, reward, termination, new_ref timing."""
+    d = load('env_' + mode)
+    p = 'step_%s_' % tag
+    variant, cont = O.MODES[mode]
+    ext = 1 if tag == 'ext' else 0
+    orc = O.Oracle(O.make_config(variant=variant, extended_state=ext, cont_ang=cont), dt)
+    A = d[p + 'action']
+    M = A.shape[0]
+    assert A.shape[1] == orc.act_dim
+    state, ctr = orc.new_state(M)
+    state[O.S['REF_N']:O.S['REF_N'] + 3] = d[p + 'ref'].T
+    state[O.S['PT_BOW']:O.S['PT_BOW'] + 3] = d[p + 'pre_thrust'].T
+    state[O.S['A_BOW']:O.S['A_BOW'] + 3] = d[p + 'pre_angles'].T
+    use = d[p + 'use_new_ref'].astype(bool)
+    new_ref = np.where(use[:, None], d[p + 'new_ref'], d[p + 'ref']).T
+    override = np.concatenate([d[p + 'eta'].T, d[p + 'nu'].T], 0)
+    obs, rew, done, parts = orc.step(state, ctr, A, new_ref=new_ref, plant_override=override, want_parts=True)
+    od = 9 if ext else 6
+    assert set(d[p + 'nstep'].tolist()) == {20}
+    # commands written to the plant == thrust / azimuth state after the step
+    close(state[O.S['PT_BOW']:O.S['PT_BOW'] + 3].T, d[p + 'cmd_thrust'], TOL.THRUST_FLOOR, dt, 'cmd_thrust')
+    close(state[O.S['PT_BOW']:O.S['PT_BOW'] + 3].T, d[p + 'thrust_after'], TOL.THRUST_FLOOR, dt, 'thrust_after')
+    azm = d[p + 'cmd_azm']
+    ang = state[O.S['A_BOW']:O.S['A_BOW'] + 3].T
+    written = ~np.isnan(azm)
+    expect_written = {'full': [1, 1, 1], 'simple': [0, 0, 0]}.get(mode, [0, 1, 1])
+    assert (written == np.array(expect_written, bool)[None, :]).all()
+    close(ang[written], azm[written], TOL.ANGLE_FLOOR, dt, 'cmd_azm')
+    close(ang, d[p + 'angles_after'], TOL.ANGLE_FLOOR, dt, 'angles_after')
+    assert np.array_equal(d[p + 'prev_angles_after'], d[p + 'pre_angles'])
+    close(obs, d[p + 'obs'], TOL.OBS_FLOOR[:od], dt, 'obs')
+    close(parts, d[p + 'reward_parts'], TOL.PARTS_FLOOR, dt, 'reward parts')
+    close(rew, d[p + 'reward'], TOL.REWARD_FLOOR, dt, 'reward')
+    assert np.array_equal(done & 1, d[p + 'done']), 'done'
+    assert d[p + 'done'].min() == 0 and d[p + 'done'].max() == 1
+    close(state[O.S['REF_N']:O.S['REF_N'] + 3].T, d[p + 'ref_after'], 1.0, dt, 'ref_after')
+    assert (ctr[0] == 1).all()
+
+
+@pytest.mark.parametrize('mode,tag,dt', list(cases()))
+def test_sequences(mode, tag, dt):
+    """reset(**init) then 10 steps: previous-thrust lag (Q2), new_ref one step late (Q4), reset obs."""
+    d = load('env_' + mode)
+    p = 'seq_%s_' % tag
+    variant, cont = O.MODES[mode]
+    ext = 1 if tag == 'ext' else 0
+    orc = O.Oracle(O.make_config(variant=variant, extended_state=ext, cont_ang=cont), dt)
+    A = d[p + 'action']
+    S_, T = A.shape[:2]
+    od = 9 if ext else 6
+    state, ctr = orc.new_state(S_)
+    obs0 = orc.reset(state, ctr, init=d[p + 'init'].T, ref=np.zeros((3, S_)))
+    close(obs0, d[p + 'obs0'], TOL.OBS_FLOOR[:od], dt, 'reset obs')
+    t_ref = int(d[p + 'new_ref_step'][0])
+    for t in range(T):
+        override = np.concatenate([d[p + 'eta'][:, t].T, d[p + 'nu'][:, t].T], 0)
+        nr = d[p + 'new_ref'].T if t == t_ref else None
+        obs, rew, done = orc.step(state, ctr, A[:, t], new_ref=nr, plant_override=override)
+        close(obs, d[p + 'obs'][:, t], TOL.OBS_FLOOR[:od], dt, 'obs t=%d' % t)
+        close(rew, d[p + 'reward'][:, t], TOL.REWARD_FLOOR, dt, 'reward t=%d' % t)
+        assert np.array_equal(done & 1, d[p + 'done'][:, t])
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_reset_writes_and_constants(mode):
+    """customEnv.py:135-194: what reset writes to the plant, and the per-variant constants."""
+    d = load('env_' + mode)
+    tag = 'base' if mode == 'simple' else 'ext'
+    w = [str(x) for x in d['seq_%s_reset_writes' % tag]]
+    names = [x.split('=')[0] for x in w]
+    assert names[:10] == ['Hull.PosNED', 'Hull.PosAttitude', 'Hull.VelocityNu', 'Hull.StateResetOn',
+                          'THR1.LinActuator', 'step.', 'Hull.StateResetOn', 'THR1.MtcOn', 'THR2.MtcOn', 'THR3.MtcOn']
+    assert w[5] == 'step.=50.0'
+    variant, cont = O.MODES[mode]
+    orc = O.Oracle(O.make_config(variant=variant, extended_state=0 if mode == 'simple' else 1, cont_ang=cont))
+    # defaults written after the held 50 sub-steps == oracle's post-reset thrust / azimuth state
+    defaults = {x.split('=')[0]: float(x.split('=')[1]) for x in w[10:]}
+    state, ctr = orc.new_state(1)
+    state[:] = 7.0
+    orc.reset(state, ctr, init=np.zeros((6, 1)))
+    for i in range(3):
+        assert defaults['THR%d.ThrustOrTorqueCmdMtc' % (i + 1)] == 0.0 == state[O.S['PT_BOW'] + i, 0]
+        assert abs(defaults['THR%d.AzmCmdMtc' % (i + 1)] - state[O.S['A_BOW'] + i, 0]) < 1e-12
+        assert abs(d['default_actions'][3 + i] - state[O.S['A_BOW'] + i, 0]) < 1e-12
+    assert int(d['meta'][3]) == orc.act_dim
+    assert list(d['meta'][:3]) == [0.2, 20, 400]
+    if mode == 'simple':
+        assert d['simple_ext_raises_indexerror'][0] == 1
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_reset_sampler_distribution(mode):
+    """customEnv.py:143-145 + simtools.py:109-123: training reset ranges (distributional parity only:
+    the reference draws from numpy's wall-clock-seeded global RNG, quirk Q8)."""
+    d = load('env_' + mode)
+    variant, cont = O.MODES[mode]
+    orc = O.Oracle(O.make_config(variant=variant, cont_ang=cont, seed=11))
+    X = np.array([np.concatenate(orc.sample_reset(g, 0)) for g in range(4000)])
+    lim = 0.8 * d['real_ss_bounds'] * np.array([1, 1, 1, 0.3, 0.3, 0.3])
+    assert (np.abs(X) <= lim + 1e-12).all()
+    assert (np.abs(X).max(0) > 0.98 * lim).all()
+    assert (d['train_reset_absmax'] <= lim).all()
+    # uniform on [-l, l]: mean 0, std l/sqrt(3)
+    assert (np.abs(X.mean(0)) < 0.05 * lim).all()
+    assert np.allclose(X.std(0), lim / np.sqrt(3), rtol=0.04)
+    assert np.allclose(d['train_reset_std'], lim / np.sqrt(3), rtol=0.04)
+    # a different episode index or env id gives a different draw; same inputs repeat exactly
+    a = np.concatenate(orc.sample_reset(5, 0))
+    assert np.array_equal(a, np.concatenate(orc.sample_reset(5, 0)))
+    assert not np.array_equal(a, np.concatenate(orc.sample_reset(5, 1)))
+    assert not np.array_equal(a, np.concatenate(orc.sample_reset(6, 0)))
+    # float build draws the same 24-bit uniforms
+    o32 = O.Oracle(O.make_config(variant=variant, cont_ang=cont, seed=11), np.float32)
+    b = np.concatenate(o32.sample_reset(5, 0))
+    assert np.allclose(a, b, rtol=2e-7, atol=0)
+
+
+@pytest.mark.parametrize('dt', [np.float64, np.float32])
+def test_errorframe(dt):
+    """errorFrame.py:25-37 incl. the degree-mode wrap on radians (quirk Q1)."""
+    d = load('errorframe')
+    orc = O.Oracle(O.make_config(extended_state=0), dt)
+    got = np.array([orc.obs(d['pos'][i], np.zeros(3), d['ref'][i], np.zeros(3))[:3] for i in range(len(d['pos']))])
+    close(got, d['err'], np.array([1.0, 1.0, 0.1]), dt, 'error frame')
+    sm = orc.obs([1, 2, 0.5], np.zeros(3), [0.5, -1, 0.1], np.zeros(3))[:3]
+    close(sm, [1.8770678967577954, 2.3930349163690168, 0.4000000000000057], 1.0, dt, 'SURVEY appendix C smoke value')
+    close(sm, d['smoke'], 1.0, dt, 'smoke')
+    # quirk Q1: yaw error is NOT wrapped to (-pi, pi] in reference mode ...
+    q1 = orc.obs([0, 0, 3.0], np.zeros(3), [0, 0, -3.0], np.zeros(3))[2]
+    assert abs(q1 - 6.0) < 1e-6
+    # ... and is in radians mode (the ROS deployment's behaviour)
+    orad = O.Oracle(O.make_config(extended_state=0, wrap_mode=O.WRAP_RADIANS), dt)
+    q1r = orad.obs([0, 0, 3.0], np.zeros(3), [0, 0, -3.0], np.zeros(3))[2]
+    assert abs(q1r - (6.0 - 2 * np.pi)) < 1e-5
+
+
+@pytest.mark.parametrize('dt', [np.float64, np.float32])
+def test_force_map(dt):
+    """SupervisedTau.py:42-83 (2016 thrust constants, asymmetric bow), reference order port,star,bow."""
+    d = load('forcemap')
+    orc = O.Oracle(O.make_config(), dt)
+    v = orc.vessel.copy()
+    # reference order (port, star, bow) -> env order (bow, port, star)
+    perm = [2, 0, 1]
+    v[12:15] = d['K_fwd'][perm]
+    v[15:18] = d['K_rev'][perm]
+    v[18:21] = d['lx'][perm]
+    v[21:24] = d['ly'][perm]
+    got = np.array([orc.thrust_map(d['u'][i][perm], d['alpha'][i][perm], vessel=v) for i in range(len(d['u']))])
+    close(got, d['tau'], TOL.TAU_FLOOR, dt, 'tau')
+    close(got[0], [4.89423087, 17.83190485, 14.62468833], TOL.TAU_FLOOR, np.float32, 'SURVEY appendix C value')
+    # the default vessel carries the simulator's current constants (qp_allocator.py:51-55,69-70)
+    dv = orc.vessel
+    assert np.allclose(dv[12:18], [0.0009, 0.00205, 0.00205] * 2)
+    assert np.allclose(dv[18:24], [1.08, -1.12, -1.12, 0.0, -0.15, 0.15])
+    fmax = orc.thrust_map([100, 100, 100], [0, 0, 0])
+    assert abs(fmax[0] - (9.0 + 20.5 + 20.5)) < 1e-4
+
+
+@pytest.mark.parametrize('dt', [np.float64, np.float32])
+def test_gae(dt):
+    """ppo.py:65-105, core.py:48-63, mpi_tools.py:71-92."""
+    d = load('gae')
+    orc = O.Oracle(O.make_config(), dt)
+    y = orc.discount_cumsum(d['dc_x'], 0.5)
+    assert np.allclose(y, d['dc_y']) and np.allclose(y, [2.75, 3.5, 3.0])
+    T = len(d['gae_rew'])
+    end = np.zeros((T, 1), np.uint8)
+    boot = np.zeros((T, 1))
+    for e, lv in zip(d['gae_path_ends'], d['gae_last_vals']):
+        end[e - 1, 0] = 1
+        boot[e - 1, 0] = lv
+    g, l = d['gae_gamma_lam']
+    adv, ret = orc.gae(d['gae_rew'][:, None], d['gae_val'][:, None], end=end, boot=boot, gamma=g, lam=l)
+    # the reference stores into float32 buffers (ppo.py:42-46)
+    tol = dict(rtol=2e-6, atol=2e-6) if dt == np.float64 else dict(rtol=1e-5, atol=1e-5)
+    assert np.allclose(adv[:, 0], d['gae_adv_raw'], **tol)
+    assert np.allclose(ret[:, 0], d['gae_ret'], **tol)
+    norm, ms = orc.normalize_adv(d['gae_adv_raw'].astype(dt))
+    assert np.allclose(ms, d['gae_mean_std'], rtol=1e-5)
+    assert np.allclose(norm, d['gae_adv_norm'], rtol=1e-4, atol=1e-5)
+    # without boot: inner ends bootstrap 0, last row uses last_val
+    end2 = np.zeros((T, 1), np.uint8)
+    end2[6, 0] = 1
+    adv2, ret2 = orc.gae(d['gae_rew'][:, None], d['gae_val'][:, None], end=end2, last_val=np.array([0.5]), gamma=g, lam=l)
+    ref_ret = np.zeros(T)
+    acc = 0.5
+    for t in range(T - 1, -1, -1):
+        if t == 6:
+            acc = 0.0
+        acc = d['gae_rew'][t] + g * acc
+        ref_ret[t] = acc
+    assert np.allclose(ret2[:, 0], ref_ret, rtol=1e-5, atol=1e-5)
+
+
+def test_philox_known_answers():
+    """Random123 known-answer vectors for philox4x32-10."""
+    assert O.philox([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert O.philox([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert O.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]

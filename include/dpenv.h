@@ -1,0 +1,189 @@
+/*
+ * dpenv.h - C ABI of libdpenv.so: the MI355X-native batched ReVolt dynamic-positioning
+ * environment (env.step hot path of simensov/ml4ca as one HIP kernel for gfx950).
+ *
+ * This is the drop-in boundary.  The reference is pure Python with no FFI of its own; the
+ * interface this library replaces is (paths relative to the reference root,
+ * WW = src/rl/windows_workspace):
+ *   - upper boundary, what the PPO loop calls: Revolt.reset / Revolt.step
+ *       WW/specific/customEnv.py:135-194, :92-133  (consumed at WW/spinup/algos/tf1/ppo/ppo.py:286-322)
+ *   - lower boundary, the plant plug-in seam it swallows: DigiTwin.val / DigiTwin.step
+ *       WW/specific/digitwin.py:50-114, :213-219   (py4j RPC into the Cybersea simulator)
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - Plain C: opaque handle, raw pointers and sizes, int status codes.  No torch types.
+ *   - Every bulk-data pointer is a DEVICE pointer owned by the caller (e.g. tensor.data_ptr());
+ *     config structs and vessel parameter vectors are HOST memory.  A NULL optional pointer
+ *     means "not requested".
+ *   - The library owns the per-env state block in HBM behind the handle.  No allocation,
+ *     no host synchronisation inside reset/step: calls are ordered on the hipStream_t passed in
+ *     and are graph-capturable.
+ *   - One handle per (process, GPU).  A handle is not thread-safe; different handles are independent.
+ *   - Thruster order everywhere: 0 = bow (THR1), 1 = stern port (THR2), 2 = stern starboard (THR3)
+ *     (customEnv.py:48-50).  The ROS/QP code uses port, star, bow (qp_allocator.py:69-70).
+ *   - Return value: DPENV_OK or a negative DPENV_E*; dpenv_last_error() gives the message.
+ *     There is NO CPU fallback: without a usable gfx950 device dpenv_create fails with DPENV_ENODEV.
+ */
+#ifndef DPENV_H
+#define DPENV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPENV_ABI_VERSION 1
+
+typedef struct dpenv_s* dpenv_handle;
+typedef void* dpenv_stream; /* hipStream_t; NULL = the null stream */
+
+enum {
+    DPENV_OK = 0,
+    DPENV_EINVAL = -1,  /* bad argument / unsupported combination */
+    DPENV_ENODEV = -2,  /* no usable HIP device */
+    DPENV_ENOMEM = -3,  /* device allocation failed */
+    DPENV_EHIP = -4,    /* HIP runtime error (launch, copy) */
+};
+
+/* env variants, customEnv.py:11 (Revolt, name 'full'), :327 RevoltSimple, :351 RevoltLimited, :373 RevoltFinal */
+enum { DPENV_FULL = 0, DPENV_SIMPLE = 1, DPENV_LIMITED = 2, DPENV_FINAL = 3 };
+/* memory layout of action / observation batches */
+enum { DPENV_AOS = 0 /* [n_envs][dim] row-major (torch-native) */, DPENV_SOA = 1 /* [dim][n_envs] */ };
+/* yaw wrap in the error frame: REFERENCE replicates errorFrame.py:29,31 calling wrap_angle with its
+ * default deg=True on radians (mathematics.py:14); RADIANS wraps to [-pi,pi) like the ROS node. */
+enum { DPENV_WRAP_REFERENCE = 0, DPENV_WRAP_RADIANS = 1 };
+enum { DPENV_F32 = 0, DPENV_BF16 = 1 };
+/* bits of the per-env done byte */
+enum { DPENV_DONE_TERMINAL = 1 /* is_terminal, customEnv.py:207-213 */,
+       DPENV_DONE_TIMELIMIT = 2 /* traj_len == max_ep_len, ppo.py:304 */,
+       DPENV_DONE_FAULT = 4 /* non-finite state */ };
+
+/* canonical state exchange format for get/set_state: float state[DPENV_NSTATE][n_envs] */
+enum {
+    DPENV_S_N = 0, DPENV_S_E, DPENV_S_PSI, DPENV_S_U, DPENV_S_V, DPENV_S_R,
+    DPENV_S_REF_N, DPENV_S_REF_E, DPENV_S_REF_PSI,
+    DPENV_S_PT_BOW, DPENV_S_PT_PORT, DPENV_S_PT_STAR, /* previous thrust command, percent (customEnv.py:126) */
+    DPENV_S_A_BOW, DPENV_S_A_PORT, DPENV_S_A_STAR,    /* azimuth command in force, rad (customEnv.py:122) */
+    DPENV_NSTATE
+};
+/* int32 counters[2][n_envs]: [0] steps taken in the running episode, [1] episodes sampled so far */
+
+/* vessel parameter vector: float[DPENV_NPARAM] per vessel class.  Hull terms are BUILD-OWNED (the
+ * reference's plant is the closed Cybersea simulator); thruster terms come from the reference
+ * (K: qp_allocator.py:51-55 / SupervisedTau.py:69-71, lever arms: qp_allocator.py:69-70). */
+enum {
+    DPENV_P_M11 = 0, DPENV_P_M22, DPENV_P_M23, DPENV_P_M33, /* rigid-body + added mass, symmetric */
+    DPENV_P_XU, DPENV_P_XUU, DPENV_P_YV, DPENV_P_YVV, DPENV_P_YR, DPENV_P_NV, DPENV_P_NR, DPENV_P_NRR, /* damping >= 0 */
+    DPENV_P_KF_BOW, DPENV_P_KF_PORT, DPENV_P_KF_STAR, /* F = K n|n|, n >= 0 */
+    DPENV_P_KR_BOW, DPENV_P_KR_PORT, DPENV_P_KR_STAR, /* n < 0 */
+    DPENV_P_LX_BOW, DPENV_P_LX_PORT, DPENV_P_LX_STAR,
+    DPENV_P_LY_BOW, DPENV_P_LY_PORT, DPENV_P_LY_STAR,
+    DPENV_NPARAM = 32
+};
+#define DPENV_MAX_CLASSES 64
+
+typedef struct dpenv_config {
+    uint32_t struct_size;    /* sizeof(dpenv_config), ABI check */
+    int32_t n_envs;
+    int32_t device;          /* HIP device ordinal, -1 = current */
+    int32_t variant;         /* DPENV_FULL .. DPENV_FINAL */
+    int32_t extended_state;  /* obs dim 9 (1) or 6 (0), customEnv.py:44,201-205 */
+    int32_t cont_ang;        /* FINAL only: 7 actions with sin/cos azimuth heads, customEnv.py:227-235 */
+    int32_t n_substeps;      /* plant sub-steps per env step, 20 (customEnv.py:79-80) */
+    float substep_dt;        /* 0.01 s (customEnv.py:81) */
+    int32_t wrap_mode;       /* DPENV_WRAP_* */
+    int32_t terminate;       /* 1: evaluate is_terminal bounds; 0: never terminal */
+    int32_t max_ep_len;      /* time limit in env steps (train.py:70-73 -> 400); 0 = none */
+    int32_t auto_reset;      /* re-sample finished envs inside step (ppo.py:305-322 batched) */
+    int32_t action_layout;   /* DPENV_AOS / DPENV_SOA */
+    int32_t obs_layout;
+    int32_t obs_dtype;       /* DPENV_F32 / DPENV_BF16 */
+    int32_t current_enabled; /* per-env constant irrotational current, see dpenv_set_current */
+    uint64_t seed;           /* Philox key of the reset sampler */
+    int64_t env_id_base;     /* global id of local env 0: results do not depend on the rank count */
+    float reset_fraction;    /* 0.8 (customEnv.py:135; curriculum hook ppo.py:286,319) */
+    int32_t hold_plant;      /* 1: hull state is held while the step runs, like Hull.StateResetOn=1
+                                (customEnv.py:164-167); lets parity tests replay the reference's scripted-plant
+                                fixtures through the kernel.  0 in production. */
+    int32_t reserved[6];
+} dpenv_config;
+
+/* Optional outputs / inputs of one step beyond the Gym tuple.  All device pointers, any may be NULL. */
+typedef struct dpenv_step_io {
+    uint32_t struct_size;
+    const float* action;     /* [n][act_dim] or [act_dim][n] per action_layout */
+    const float* new_ref;    /* [3][n]: applied AFTER obs/reward/done of this step (customEnv.py:131) */
+    void* obs;               /* [n][obs_dim] or [obs_dim][n], f32 or bf16 */
+    float* reward;           /* [n] */
+    uint8_t* done;           /* [n], DPENV_DONE_* bits */
+    float* reward_parts;     /* [4][n]: vel, pose gaussian, thrust penalty, derivative penalty */
+    void* final_obs;         /* same layout as obs: terminal observation of envs that auto-reset */
+} dpenv_step_io;
+
+/* Fill *cfg with the shipped training configuration (RevoltFinal, extended state, continuous
+ * angles, 20 x 0.01 s, T = 400, train.py:47-54).  n_envs is left 0. */
+int dpenv_default_config(dpenv_config* cfg);
+/* Default ReVolt parameter vector. */
+int dpenv_default_vessel(float params[DPENV_NPARAM]);
+/* Derived sizes for a config. */
+int dpenv_act_dim(const dpenv_config* cfg);
+int dpenv_obs_dim(const dpenv_config* cfg);
+
+/* Create an environment batch.  vessel_params: host float[n_classes][DPENV_NPARAM], NULL = one
+ * default class.  With n_classes > 1 call dpenv_set_vessel_class to assign envs to classes. */
+int dpenv_create(const dpenv_config* cfg, const float* vessel_params, int32_t n_classes, dpenv_handle* out);
+int dpenv_destroy(dpenv_handle h);
+/* Message of the last failure on this handle (h == NULL: last failure of dpenv_create in this thread). */
+const char* dpenv_last_error(dpenv_handle h);
+
+/* Change the pose/velocity fraction of the training reset sampler (curriculum hook, ppo.py:286,319-322). */
+int dpenv_set_reset_fraction(dpenv_handle h, float fraction);
+/* class_id: device int32[n_envs], values in [0, n_classes).  Copied. */
+int dpenv_set_vessel_class(dpenv_handle h, const int32_t* class_id, dpenv_stream s);
+/* vc, beta: device float[n_envs] current speed [m/s] and NED direction [rad].  Copied. */
+int dpenv_set_current(dpenv_handle h, const float* vc, const float* beta, dpenv_stream s);
+
+/* Revolt.reset (customEnv.py:135-194) for the envs selected by mask (device uint8[n], NULL = all).
+ * init: device float[6][n] = N, E, psi, u, v, r (the **init override, customEnv.py:141,152), NULL =
+ * training sample (simtools.py:109-123).  ref: device float[3][n] new setpoints, NULL = keep.
+ * obs_out (optional) receives the observation of EVERY env. */
+int dpenv_reset(dpenv_handle h, const uint8_t* mask, const float* init, const float* ref, void* obs_out,
+                dpenv_stream s);
+
+/* Revolt.step (customEnv.py:92-133) for all envs. */
+int dpenv_step(dpenv_handle h, const float* action, const float* new_ref, void* obs_out, float* rew_out,
+               uint8_t* done_out, dpenv_stream s);
+int dpenv_step_ex(dpenv_handle h, const dpenv_step_io* io, dpenv_stream s);
+
+/* Parity/test access to the library-owned state in the canonical format above. */
+int dpenv_get_state(dpenv_handle h, float* state_out, int32_t* counters_out, dpenv_stream s);
+int dpenv_set_state(dpenv_handle h, const float* state_in, const int32_t* counters_in, dpenv_stream s);
+
+/* Stateless thruster force map tau = B(alpha) F(n) (SupervisedTau.py:42-83) for n items:
+ * n_pct, alpha, tau_out are device float[3][n] (bow, port, star / Fx, Fy, Mz); params host float[DPENV_NPARAM]. */
+int dpenv_thrust_map(const float* params, const float* n_pct, const float* alpha, float* tau_out, int32_t n,
+                     dpenv_stream s);
+
+/* GAE-lambda over a [T][n] rollout (TrajectoryBuffer.finish_path, ppo.py:65-91, batched): a path ends
+ * after step t of env i where end[t][i] != 0 and always after T-1.  Bootstrap value at a path end:
+ * boot[t][i] if boot != NULL, else 0 at inner ends and last_val[i] (NULL = 0) at the final row. */
+int dpenv_gae(const float* rew, const float* val, const uint8_t* end, const float* boot, const float* last_val,
+              int32_t T, int32_t n, float gamma, float lam, float* adv_out, float* ret_out, dpenv_stream s);
+/* Advantage normalisation (TrajectoryBuffer.get, ppo.py:99-103 + mpi_tools.py:71-92) as three stream-ordered
+ * device passes so that a multi-rank caller can all-reduce the partial sums in between
+ * (mpi_statistics_scalar does exactly two all-reduces): sum -> [mean = sum/count] -> sum of squared
+ * deviations -> [std = sqrt(sumsq/count)] -> adv = (adv - mean) / (std + 1e-8).
+ * sum_out, sumsq_out, mean, std are device float scalars. */
+int dpenv_adv_sum(const float* adv, int64_t count, float* sum_out, dpenv_stream s);
+int dpenv_adv_sumsq(const float* adv, int64_t count, const float* mean, float* sumsq_out, dpenv_stream s);
+int dpenv_adv_apply(float* adv, int64_t count, const float* mean, const float* std, dpenv_stream s);
+
+int dpenv_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPENV_H */

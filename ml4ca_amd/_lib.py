@@ -1,0 +1,113 @@
+"""ctypes binding of libdpenv.so (C ABI in include/dpenv.h).
+
+There is deliberately no fallback: if the HIP library is missing or no MI355X is usable the
+import / constructor raises.  Nothing here touches oracle/.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libdpenv.so')
+
+OK, EINVAL, ENODEV, ENOMEM, EHIP = 0, -1, -2, -3, -4
+FULL, SIMPLE, LIMITED, FINAL = 0, 1, 2, 3
+AOS, SOA = 0, 1
+WRAP_REFERENCE, WRAP_RADIANS = 0, 1
+F32, BF16 = 0, 1
+DONE_TERMINAL, DONE_TIMELIMIT, DONE_FAULT = 1, 2, 4
+NSTATE, NPARAM, MAX_CLASSES = 15, 32, 64
+ABI_VERSION = 1
+
+# canonical state rows (dpenv.h DPENV_S_*)
+S = dict(N=0, E=1, PSI=2, U=3, V=4, R=5, REF_N=6, REF_E=7, REF_PSI=8,
+         PT_BOW=9, PT_PORT=10, PT_STAR=11, A_BOW=12, A_PORT=13, A_STAR=14)
+# vessel parameter slots (dpenv.h DPENV_P_*)
+P = dict(M11=0, M22=1, M23=2, M33=3, XU=4, XUU=5, YV=6, YVV=7, YR=8, NV=9, NR=10, NRR=11,
+         KF_BOW=12, KF_PORT=13, KF_STAR=14, KR_BOW=15, KR_PORT=16, KR_STAR=17,
+         LX_BOW=18, LX_PORT=19, LX_STAR=20, LY_BOW=21, LY_PORT=22, LY_STAR=23)
+
+
+class Config(C.Structure):
+    _fields_ = [('struct_size', C.c_uint32), ('n_envs', C.c_int32), ('device', C.c_int32), ('variant', C.c_int32),
+                ('extended_state', C.c_int32), ('cont_ang', C.c_int32), ('n_substeps', C.c_int32),
+                ('substep_dt', C.c_float), ('wrap_mode', C.c_int32), ('terminate', C.c_int32),
+                ('max_ep_len', C.c_int32), ('auto_reset', C.c_int32), ('action_layout', C.c_int32),
+                ('obs_layout', C.c_int32), ('obs_dtype', C.c_int32), ('current_enabled', C.c_int32),
+                ('seed', C.c_uint64), ('env_id_base', C.c_int64), ('reset_fraction', C.c_float),
+                ('hold_plant', C.c_int32), ('reserved', C.c_int32 * 6)]
+
+
+class StepIO(C.Structure):
+    _fields_ = [('struct_size', C.c_uint32), ('action', C.c_void_p), ('new_ref', C.c_void_p), ('obs', C.c_void_p),
+                ('reward', C.c_void_p), ('done', C.c_void_p), ('reward_parts', C.c_void_p), ('final_obs', C.c_void_p)]
+
+
+# every symbol include/dpenv.h declares: name -> (restype, argtypes)
+_VP, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+SYMBOLS = {
+    'dpenv_abi_version': (C.c_int, []),
+    'dpenv_default_config': (C.c_int, [C.POINTER(Config)]),
+    'dpenv_default_vessel': (C.c_int, [C.POINTER(C.c_float)]),
+    'dpenv_act_dim': (C.c_int, [C.POINTER(Config)]),
+    'dpenv_obs_dim': (C.c_int, [C.POINTER(Config)]),
+    'dpenv_create': (C.c_int, [C.POINTER(Config), C.POINTER(C.c_float), _I32, C.POINTER(_VP)]),
+    'dpenv_destroy': (C.c_int, [_VP]),
+    'dpenv_last_error': (C.c_char_p, [_VP]),
+    'dpenv_set_reset_fraction': (C.c_int, [_VP, _F]),
+    'dpenv_set_vessel_class': (C.c_int, [_VP, _VP, _VP]),
+    'dpenv_set_current': (C.c_int, [_VP, _VP, _VP, _VP]),
+    'dpenv_reset': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
+    'dpenv_step': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    'dpenv_step_ex': (C.c_int, [_VP, C.POINTER(StepIO), _VP]),
+    'dpenv_get_state': (C.c_int, [_VP, _VP, _VP, _VP]),
+    'dpenv_set_state': (C.c_int, [_VP, _VP, _VP, _VP]),
+    'dpenv_thrust_map': (C.c_int, [C.POINTER(C.c_float), _VP, _VP, _VP, _I32, _VP]),
+    'dpenv_gae': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _F, _F, _VP, _VP, _VP]),
+    'dpenv_adv_sum': (C.c_int, [_VP, _I64, _VP, _VP]),
+    'dpenv_adv_sumsq': (C.c_int, [_VP, _I64, _VP, _VP, _VP]),
+    'dpenv_adv_apply': (C.c_int, [_VP, _I64, _VP, _VP, _VP]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libdpenv.so; raise (never fall back) if it is missing or has the wrong ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError('libdpenv.so not built: run `python -c "import __graft_entry__ as g; g.build()"` '
+                          'or `make -C ml4ca_amd/csrc` (hipcc, gfx950). There is no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library drift
+        fn.restype = res
+        fn.argtypes = args
+    if lib.dpenv_abi_version() != ABI_VERSION:
+        raise ImportError('libdpenv.so ABI %d != binding ABI %d' % (lib.dpenv_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+class DpenvError(RuntimeError):
+    pass
+
+
+def check(code, handle=None):
+    if code != OK:
+        msg = load().dpenv_last_error(handle)
+        raise DpenvError('libdpenv error %d: %s' % (code, msg.decode() if msg else '?'))
+
+
+def default_config():
+    cfg = Config()
+    check(load().dpenv_default_config(C.byref(cfg)))
+    return cfg
+
+
+def default_vessel():
+    import numpy as np
+    p = (C.c_float * NPARAM)()
+    check(load().dpenv_default_vessel(p))
+    return np.array(p[:], dtype=np.float32)

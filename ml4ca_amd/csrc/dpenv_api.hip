@@ -1,0 +1,419 @@
+// dpenv_api.hip - host side of libdpenv.so: the C ABI declared in include/dpenv.h.
+// Owns the per-env state block in HBM, validates arguments, fills the kernel argument block and
+// launches on the caller's stream.  No CPU compute path exists here by design: if HIP or the
+// device is unavailable every entry point fails loudly.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/dpenv.h"
+#include "dpenv_dev.h"
+
+using namespace dpenv;
+
+struct dpenv_s {
+    dpenv_config cfg;
+    StepArgs args;          // persistent part of the kernel argument block
+    int mode;
+    int n_classes;
+    float* blob;            // one allocation: S0 | S1 | S2 | RF | episode | vc | beta | class_id | class_tab
+    size_t blob_bytes;
+    float* cur_vc;
+    float* cur_beta;
+    int32_t* class_id;
+    bool classes_assigned;
+    bool current_set;
+    int device;
+    std::string err;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(dpenv_handle h, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    else g_create_err = buf;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                               \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(h, DPENV_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" int dpenv_abi_version(void) { return DPENV_ABI_VERSION; }
+
+extern "C" int dpenv_default_config(dpenv_config* c)
+{
+    if (!c) return DPENV_EINVAL;
+    std::memset(c, 0, sizeof *c);
+    c->struct_size = (uint32_t)sizeof *c;
+    c->n_envs = 0;
+    c->device = -1;
+    c->variant = DPENV_FINAL;      // train.py:47 'final'
+    c->extended_state = 1;         // train.py:52
+    c->cont_ang = 1;               // train.py:54
+    c->n_substeps = 20;            // customEnv.py:79-80
+    c->substep_dt = 0.01f;         // customEnv.py:81
+    c->wrap_mode = DPENV_WRAP_REFERENCE;
+    c->terminate = 1;
+    c->max_ep_len = 400;           // customEnv.py:83 with max_ep_len=800, n_steps=20
+    c->auto_reset = 0;
+    c->action_layout = DPENV_AOS;
+    c->obs_layout = DPENV_AOS;
+    c->obs_dtype = DPENV_F32;
+    c->current_enabled = 0;
+    c->seed = 0;
+    c->env_id_base = 0;
+    c->reset_fraction = 0.8f;      // customEnv.py:135
+    return DPENV_OK;
+}
+
+// BUILD-OWNED hull + the reference's thruster constants
+// (qp_allocator.py:51-55 K "as currently set in the simulator", :69-70 lever arms; env order bow,port,star).
+extern "C" int dpenv_default_vessel(float* p)
+{
+    if (!p) return DPENV_EINVAL;
+    for (int i = 0; i < DPENV_NPARAM; ++i) p[i] = 0.0f;
+    p[DPENV_P_M11] = 263.93f; p[DPENV_P_M22] = 306.44f; p[DPENV_P_M23] = 7.0f; p[DPENV_P_M33] = 322.56f;
+    p[DPENV_P_XU] = 6.0f;  p[DPENV_P_XUU] = 5.75f;
+    p[DPENV_P_YV] = 30.0f; p[DPENV_P_YVV] = 58.8f;
+    p[DPENV_P_YR] = 2.0f;  p[DPENV_P_NV] = 2.0f;
+    p[DPENV_P_NR] = 50.0f; p[DPENV_P_NRR] = 71.1f;
+    p[DPENV_P_KF_BOW] = 0.0009f; p[DPENV_P_KF_PORT] = 0.00205f; p[DPENV_P_KF_STAR] = 0.00205f;
+    p[DPENV_P_KR_BOW] = 0.0009f; p[DPENV_P_KR_PORT] = 0.00205f; p[DPENV_P_KR_STAR] = 0.00205f;
+    p[DPENV_P_LX_BOW] = 1.08f; p[DPENV_P_LX_PORT] = -1.12f; p[DPENV_P_LX_STAR] = -1.12f;
+    p[DPENV_P_LY_BOW] = 0.0f;  p[DPENV_P_LY_PORT] = -0.15f; p[DPENV_P_LY_STAR] = 0.15f;
+    return DPENV_OK;
+}
+
+static int mode_of(const dpenv_config* c)
+{
+    switch (c->variant) {
+    case DPENV_FULL: return MODE_FULL;
+    case DPENV_SIMPLE: return MODE_SIMPLE;
+    case DPENV_LIMITED: return MODE_LIMITED;
+    case DPENV_FINAL: return c->cont_ang ? MODE_FINAL_CONT : MODE_FINAL_WRAP;
+    }
+    return -1;
+}
+
+extern "C" int dpenv_act_dim(const dpenv_config* c)
+{
+    if (!c) return DPENV_EINVAL;
+    switch (mode_of(c)) {
+    case MODE_FULL: return 6;          // customEnv.py:24
+    case MODE_SIMPLE: return 3;        // :332
+    case MODE_LIMITED: return 5;       // :356
+    case MODE_FINAL_WRAP: return 5;    // :379
+    case MODE_FINAL_CONT: return 7;
+    }
+    return DPENV_EINVAL;
+}
+
+extern "C" int dpenv_obs_dim(const dpenv_config* c)
+{
+    if (!c) return DPENV_EINVAL;
+    return c->extended_state ? 9 : 6;   // customEnv.py:44
+}
+
+static int derive_vessel(const float* p, VesselDev* d, std::string* why)
+{
+    const double m11 = p[DPENV_P_M11], m22 = p[DPENV_P_M22], m23 = p[DPENV_P_M23], m33 = p[DPENV_P_M33];
+    const double det = m22 * m33 - m23 * m23;
+    if (!(m11 > 0.0) || !(det > 0.0) || !(m22 > 0.0)) {
+        *why = "mass matrix is not positive definite";
+        return DPENV_EINVAL;
+    }
+    for (int i = 0; i < DPENV_NPARAM; ++i)
+        if (!std::isfinite(p[i])) { *why = "vessel parameter is not finite"; return DPENV_EINVAL; }
+    d->p[VD_M11] = (float)m11; d->p[VD_M22] = (float)m22; d->p[VD_M23] = (float)m23;
+    // same float operations as the fp32 oracle so that both sides integrate with identical constants
+    const float fm11 = (float)m11, fm22 = (float)m22, fm23 = (float)m23, fm33 = (float)m33;
+    const float fdet = fm22 * fm33 - fm23 * fm23;
+    d->p[VD_INV11] = 1.0f / fm11;
+    d->p[VD_I22] = fm33 / fdet; d->p[VD_I23] = -fm23 / fdet; d->p[VD_I33] = fm22 / fdet;
+    d->p[VD_XU] = p[DPENV_P_XU]; d->p[VD_XUU] = p[DPENV_P_XUU]; d->p[VD_YV] = p[DPENV_P_YV];
+    d->p[VD_YVV] = p[DPENV_P_YVV]; d->p[VD_YR] = p[DPENV_P_YR]; d->p[VD_NV] = p[DPENV_P_NV];
+    d->p[VD_NR] = p[DPENV_P_NR]; d->p[VD_NRR] = p[DPENV_P_NRR];
+    for (int i = 0; i < 3; ++i) {
+        d->p[VD_KF + i] = p[DPENV_P_KF_BOW + i]; d->p[VD_KR + i] = p[DPENV_P_KR_BOW + i];
+        d->p[VD_LX + i] = p[DPENV_P_LX_BOW + i]; d->p[VD_LY + i] = p[DPENV_P_LY_BOW + i];
+    }
+    return DPENV_OK;
+}
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+extern "C" int dpenv_create(const dpenv_config* cfg, const float* vessel_params, int32_t n_classes, dpenv_handle* out)
+{
+    if (!cfg || !out) return fail(nullptr, DPENV_EINVAL, "dpenv_create: NULL argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(dpenv_config))
+        return fail(nullptr, DPENV_EINVAL, "dpenv_config.struct_size %u != %zu (ABI mismatch)", cfg->struct_size,
+                    sizeof(dpenv_config));
+    if (cfg->n_envs <= 0) return fail(nullptr, DPENV_EINVAL, "n_envs must be positive");
+    const int mode = mode_of(cfg);
+    if (mode < 0) return fail(nullptr, DPENV_EINVAL, "unknown variant %d", cfg->variant);
+    if (cfg->cont_ang && cfg->variant != DPENV_FINAL)
+        return fail(nullptr, DPENV_EINVAL, "cont_ang is only defined for the final variant (customEnv.py:228)");
+    if (cfg->variant == DPENV_SIMPLE && cfg->extended_state)
+        return fail(nullptr, DPENV_EINVAL,
+                    "simple + extended_state is not runnable in the reference either (IndexError at customEnv.py:319)");
+    if (cfg->n_substeps <= 0 || !(cfg->substep_dt > 0.0f)) return fail(nullptr, DPENV_EINVAL, "bad sub-step settings");
+    if (cfg->action_layout < 0 || cfg->action_layout > 1 || cfg->obs_layout < 0 || cfg->obs_layout > 1)
+        return fail(nullptr, DPENV_EINVAL, "bad layout");
+    if (cfg->obs_dtype != DPENV_F32 && cfg->obs_dtype != DPENV_BF16) return fail(nullptr, DPENV_EINVAL, "bad obs_dtype");
+    if (cfg->max_ep_len < 0) return fail(nullptr, DPENV_EINVAL, "max_ep_len < 0");
+    if (vessel_params == nullptr) n_classes = 1;
+    if (n_classes < 1 || n_classes > MAX_CLASSES)
+        return fail(nullptr, DPENV_EINVAL, "n_classes must be in [1, %d]", MAX_CLASSES);
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, DPENV_ENODEV, "no HIP device available (%s); libdpenv has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    int dev = cfg->device;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) return fail(nullptr, DPENV_ENODEV, "hipGetDevice failed");
+    } else if (dev >= ndev) {
+        return fail(nullptr, DPENV_ENODEV, "device %d out of range (%d devices)", dev, ndev);
+    }
+    if (hipSetDevice(dev) != hipSuccess) return fail(nullptr, DPENV_ENODEV, "hipSetDevice(%d) failed", dev);
+
+    dpenv_s* h = new (std::nothrow) dpenv_s();
+    if (!h) return fail(nullptr, DPENV_ENOMEM, "host allocation failed");
+    h->cfg = *cfg;
+    h->mode = mode;
+    h->n_classes = n_classes;
+    h->device = dev;
+    h->classes_assigned = false;
+    h->current_set = false;
+
+    VesselDev tab[MAX_CLASSES];
+    float defp[DPENV_NPARAM];
+    dpenv_default_vessel(defp);
+    for (int c = 0; c < n_classes; ++c) {
+        std::string why;
+        const float* p = vessel_params ? vessel_params + (size_t)c * DPENV_NPARAM : defp;
+        if (derive_vessel(p, &tab[c], &why) != DPENV_OK) {
+            delete h;
+            return fail(nullptr, DPENV_EINVAL, "vessel class %d: %s", c, why.c_str());
+        }
+    }
+
+    const size_t n = (size_t)cfg->n_envs;
+    const size_t npad = align_up(n, 256);
+    size_t off = 0;
+    const size_t o_s0 = off; off += npad * 16;
+    const size_t o_s1 = off; off += npad * 16;
+    const size_t o_s2 = off; off += npad * 16;
+    const size_t o_rf = off; off += npad * 16;
+    const size_t o_ep = off; off += npad * 4;
+    const size_t o_vc = off; off += npad * 4;
+    const size_t o_be = off; off += npad * 4;
+    const size_t o_ci = off; off += npad * 4;
+    const size_t o_ct = off; off += align_up(sizeof(VesselDev) * MAX_CLASSES, 256);
+    h->blob_bytes = off;
+    void* blob = nullptr;
+    e = hipMalloc(&blob, off);
+    if (e != hipSuccess) {
+        delete h;
+        return fail(nullptr, DPENV_ENOMEM, "hipMalloc(%zu) failed: %s", off, hipGetErrorString(e));
+    }
+    h->blob = (float*)blob;
+    char* b = (char*)blob;
+    e = hipMemset(blob, 0, off);
+    if (e == hipSuccess) e = hipMemcpy(b + o_ct, tab, sizeof(VesselDev) * n_classes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(blob);
+        delete h;
+        return fail(nullptr, DPENV_EHIP, "state initialisation failed: %s", hipGetErrorString(e));
+    }
+
+    StepArgs& a = h->args;
+    std::memset(&a, 0, sizeof a);
+    a.S0 = (float4*)(b + o_s0); a.S1 = (float4*)(b + o_s1); a.S2 = (float4*)(b + o_s2); a.RF = (float4*)(b + o_rf);
+    a.episode = (int32_t*)(b + o_ep);
+    h->cur_vc = (float*)(b + o_vc); h->cur_beta = (float*)(b + o_be);
+    h->class_id = (int32_t*)(b + o_ci);
+    a.class_tab = (const float*)(b + o_ct);
+    a.n_classes = n_classes;
+    a.v0 = tab[0];
+    a.n = cfg->n_envs;
+    a.n_substeps = cfg->n_substeps;
+    a.h = cfg->substep_dt;
+    a.inv_dt = 1.0f / (cfg->substep_dt * (float)cfg->n_substeps);
+    a.max_ep_len = cfg->max_ep_len;
+    a.terminate = cfg->terminate;
+    a.auto_reset = cfg->auto_reset;
+    a.wrap_mode = cfg->wrap_mode;
+    a.action_layout = cfg->action_layout;
+    a.obs_layout = cfg->obs_layout;
+    a.obs_bf16 = (cfg->obs_dtype == DPENV_BF16);
+    a.hold_plant = cfg->hold_plant;
+    a.seed_lo = (uint32_t)(cfg->seed & 0xffffffffu);
+    a.seed_hi = (uint32_t)(cfg->seed >> 32);
+    a.env_id_base = cfg->env_id_base;
+    a.reset_fraction = cfg->reset_fraction;
+    *out = h;
+    return DPENV_OK;
+}
+
+extern "C" int dpenv_destroy(dpenv_handle h)
+{
+    if (!h) return DPENV_EINVAL;
+    if (h->blob) (void)hipFree(h->blob);
+    delete h;
+    return DPENV_OK;
+}
+
+extern "C" const char* dpenv_last_error(dpenv_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int dpenv_set_reset_fraction(dpenv_handle h, float fraction)
+{
+    if (!h) return DPENV_EINVAL;
+    if (!(fraction >= 0.0f) || !std::isfinite(fraction)) return fail(h, DPENV_EINVAL, "bad reset fraction");
+    h->cfg.reset_fraction = fraction;
+    h->args.reset_fraction = fraction;
+    return DPENV_OK;
+}
+
+extern "C" int dpenv_set_vessel_class(dpenv_handle h, const int32_t* class_id, dpenv_stream s)
+{
+    if (!h || !class_id) return fail(h, DPENV_EINVAL, "dpenv_set_vessel_class: NULL argument");
+    HIP_TRY(h, hipMemcpyAsync(h->class_id, class_id, sizeof(int32_t) * (size_t)h->cfg.n_envs, hipMemcpyDeviceToDevice,
+                              (hipStream_t)s));
+    h->classes_assigned = true;
+    return DPENV_OK;
+}
+
+extern "C" int dpenv_set_current(dpenv_handle h, const float* vc, const float* beta, dpenv_stream s)
+{
+    if (!h || !vc || !beta) return fail(h, DPENV_EINVAL, "dpenv_set_current: NULL argument");
+    if (!h->cfg.current_enabled) return fail(h, DPENV_EINVAL, "config.current_enabled is 0");
+    const size_t bytes = sizeof(float) * (size_t)h->cfg.n_envs;
+    HIP_TRY(h, hipMemcpyAsync(h->cur_vc, vc, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
+    HIP_TRY(h, hipMemcpyAsync(h->cur_beta, beta, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
+    h->current_set = true;
+    return DPENV_OK;
+}
+
+static void bind_optional(dpenv_handle h, StepArgs& a)
+{
+    // current_enabled without dpenv_set_current = zero current (the block is zero-initialised)
+    a.cur_vc = h->cfg.current_enabled ? h->cur_vc : nullptr;
+    a.cur_beta = h->cfg.current_enabled ? h->cur_beta : nullptr;
+    a.class_id = h->class_id;
+}
+
+extern "C" int dpenv_reset(dpenv_handle h, const uint8_t* mask, const float* init, const float* ref, void* obs_out,
+                           dpenv_stream s)
+{
+    if (!h) return DPENV_EINVAL;
+    StepArgs a = h->args;
+    bind_optional(h, a);
+    a.obs = obs_out;
+    HIP_TRY(h, dpenv_dev_launch_reset(&a, h->mode, h->cfg.extended_state, mask, init, ref, (hipStream_t)s));
+    return DPENV_OK;
+}
+
+extern "C" int dpenv_step_ex(dpenv_handle h, const dpenv_step_io* io, dpenv_stream s)
+{
+    if (!h) return DPENV_EINVAL;
+    if (!io || io->struct_size != sizeof(dpenv_step_io)) return fail(h, DPENV_EINVAL, "dpenv_step_io ABI mismatch");
+    if (!io->action || !io->obs || !io->reward || !io->done)
+        return fail(h, DPENV_EINVAL, "action, obs, reward and done buffers are required");
+    if (h->n_classes > 1 && !h->classes_assigned)
+        return fail(h, DPENV_EINVAL, "n_classes > 1 but dpenv_set_vessel_class was never called");
+    StepArgs a = h->args;
+    bind_optional(h, a);
+    a.action = io->action;
+    a.new_ref = io->new_ref;
+    a.obs = io->obs;
+    a.rew = io->reward;
+    a.done = io->done;
+    a.parts = io->reward_parts;
+    a.final_obs = io->final_obs;
+    HIP_TRY(h, dpenv_dev_launch_step(&a, h->mode, h->cfg.extended_state, h->n_classes > 1, (hipStream_t)s));
+    return DPENV_OK;
+}
+
+extern "C" int dpenv_step(dpenv_handle h, const float* action, const float* new_ref, void* obs_out, float* rew_out,
+                          uint8_t* done_out, dpenv_stream s)
+{
+    dpenv_step_io io;
+    std::memset(&io, 0, sizeof io);
+    io.struct_size = (uint32_t)sizeof io;
+    io.action = action; io.new_ref = new_ref; io.obs = obs_out; io.reward = rew_out; io.done = done_out;
+    return dpenv_step_ex(h, &io, s);
+}
+
+extern "C" int dpenv_get_state(dpenv_handle h, float* state_out, int32_t* counters_out, dpenv_stream s)
+{
+    if (!h) return DPENV_EINVAL;
+    HIP_TRY(h, dpenv_dev_launch_get_state(&h->args, state_out, counters_out, (hipStream_t)s));
+    return DPENV_OK;
+}
+
+extern "C" int dpenv_set_state(dpenv_handle h, const float* state_in, const int32_t* counters_in, dpenv_stream s)
+{
+    if (!h) return DPENV_EINVAL;
+    HIP_TRY(h, dpenv_dev_launch_set_state(&h->args, state_in, counters_in, (hipStream_t)s));
+    return DPENV_OK;
+}
+
+extern "C" int dpenv_thrust_map(const float* params, const float* n_pct, const float* alpha, float* tau_out, int32_t n,
+                                dpenv_stream s)
+{
+    if (!n_pct || !alpha || !tau_out || n <= 0) return fail(nullptr, DPENV_EINVAL, "dpenv_thrust_map: bad argument");
+    float defp[DPENV_NPARAM];
+    if (!params) { dpenv_default_vessel(defp); params = defp; }
+    VesselDev vd;
+    std::string why;
+    if (derive_vessel(params, &vd, &why) != DPENV_OK) return fail(nullptr, DPENV_EINVAL, "%s", why.c_str());
+    HIP_TRY(nullptr, dpenv_dev_launch_thrust_map(&vd, n_pct, alpha, tau_out, n, (hipStream_t)s));
+    return DPENV_OK;
+}
+
+extern "C" int dpenv_gae(const float* rew, const float* val, const uint8_t* end, const float* boot, const float* last_val,
+                         int32_t T, int32_t n, float gamma, float lam, float* adv_out, float* ret_out, dpenv_stream s)
+{
+    if (!rew || !val || !adv_out || !ret_out || T <= 0 || n <= 0)
+        return fail(nullptr, DPENV_EINVAL, "dpenv_gae: bad argument");
+    HIP_TRY(nullptr, dpenv_dev_launch_gae(rew, val, end, boot, last_val, T, n, gamma, lam, adv_out, ret_out, (hipStream_t)s));
+    return DPENV_OK;
+}
+
+extern "C" int dpenv_adv_sum(const float* adv, int64_t count, float* sum_out, dpenv_stream s)
+{
+    if (!adv || !sum_out || count <= 0) return fail(nullptr, DPENV_EINVAL, "dpenv_adv_sum: bad argument");
+    HIP_TRY(nullptr, dpenv_dev_launch_sum(adv, count, nullptr, sum_out, (hipStream_t)s));
+    return DPENV_OK;
+}
+
+extern "C" int dpenv_adv_sumsq(const float* adv, int64_t count, const float* mean, float* sumsq_out, dpenv_stream s)
+{
+    if (!adv || !mean || !sumsq_out || count <= 0) return fail(nullptr, DPENV_EINVAL, "dpenv_adv_sumsq: bad argument");
+    HIP_TRY(nullptr, dpenv_dev_launch_sum(adv, count, mean, sumsq_out, (hipStream_t)s));
+    return DPENV_OK;
+}
+
+extern "C" int dpenv_adv_apply(float* adv, int64_t count, const float* mean, const float* std, dpenv_stream s)
+{
+    if (!adv || !mean || !std || count <= 0) return fail(nullptr, DPENV_EINVAL, "dpenv_adv_apply: bad argument");
+    HIP_TRY(nullptr, dpenv_dev_launch_adv_apply(adv, count, mean, std, (hipStream_t)s));
+    return DPENV_OK;
+}

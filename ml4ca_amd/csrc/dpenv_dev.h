@@ -1,0 +1,92 @@
+// dpenv_dev.h - internal contract between the host API (dpenv_api.hip) and the kernels
+// (dpenv_kernels.hip) of libdpenv.so.  Not part of the public ABI (that is include/dpenv.h).
+#ifndef DPENV_DEV_H
+#define DPENV_DEV_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#ifndef DPENV_BLOCK
+#define DPENV_BLOCK 256   // threads per workgroup = 4 wave64; one lane per environment
+#endif
+
+namespace dpenv {
+
+constexpr int BLOCK = DPENV_BLOCK;
+constexpr int MAX_CLASSES = 64;
+
+// kernel specialisations: variant x azimuth-head style (customEnv.py:11,327,351,373 + cont_ang :90)
+enum { MODE_FULL = 0, MODE_SIMPLE = 1, MODE_LIMITED = 2, MODE_FINAL_WRAP = 3, MODE_FINAL_CONT = 4 };
+enum { LAYOUT_AOS = 0, LAYOUT_SOA = 1 };
+enum { WRAP_REFERENCE = 0, WRAP_RADIANS = 1 };
+enum { DONE_TERMINAL = 1u, DONE_TIMELIMIT = 2u, DONE_FAULT = 4u };
+
+// derived per-class parameter block (host precomputes the mass-matrix inverse)
+enum {
+    VD_M11 = 0, VD_M22, VD_M23, VD_INV11, VD_I22, VD_I23, VD_I33,
+    VD_XU, VD_XUU, VD_YV, VD_YVV, VD_YR, VD_NV, VD_NR, VD_NRR,
+    VD_KF, VD_KR = VD_KF + 3, VD_LX = VD_KR + 3, VD_LY = VD_LX + 3,
+    VD_COUNT = VD_LY + 3
+};
+
+struct VesselDev {
+    float p[VD_COUNT];
+};
+
+struct StepArgs {
+    // library-owned state streams (see dpenv_kernels.hip header)
+    float4* S0;
+    float4* S1;
+    float4* S2;
+    float4* RF;
+    int32_t* episode;
+    // per-call I/O (caller-owned device memory)
+    const float* action;
+    const float* new_ref;
+    void* obs;
+    float* rew;
+    uint8_t* done;
+    float* parts;
+    void* final_obs;
+    // optional per-env inputs owned by the library
+    const float* cur_vc;
+    const float* cur_beta;
+    const int32_t* class_id;
+    const float* class_tab;   // [n_classes][VD_COUNT]
+    int32_t n_classes;
+    VesselDev v0;             // class 0 by value -> SGPRs on the single-class path
+    int32_t n;
+    int32_t n_substeps;
+    float h;
+    float inv_dt;             // 1 / (n_substeps * h)
+    int32_t max_ep_len;
+    int32_t terminate;
+    int32_t auto_reset;
+    int32_t wrap_mode;
+    int32_t action_layout;
+    int32_t obs_layout;
+    int32_t obs_bf16;
+    int32_t hold_plant;
+    uint32_t seed_lo, seed_hi;
+    int64_t env_id_base;
+    float reset_fraction;
+};
+
+}  // namespace dpenv
+
+extern "C" {
+hipError_t dpenv_dev_launch_step(const dpenv::StepArgs* a, int mode, int ext, int per_class, hipStream_t s);
+hipError_t dpenv_dev_launch_reset(const dpenv::StepArgs* a, int mode, int ext, const uint8_t* mask, const float* init,
+                                  const float* ref, hipStream_t s);
+hipError_t dpenv_dev_launch_get_state(const dpenv::StepArgs* a, float* st, int32_t* ctr, hipStream_t s);
+hipError_t dpenv_dev_launch_set_state(const dpenv::StepArgs* a, const float* st, const int32_t* ctr, hipStream_t s);
+hipError_t dpenv_dev_launch_thrust_map(const dpenv::VesselDev* vd, const float* n_pct, const float* alpha, float* tau,
+                                       int n, hipStream_t s);
+hipError_t dpenv_dev_launch_gae(const float* rew, const float* val, const uint8_t* end, const float* boot,
+                                const float* last_val, int T, int n, float gamma, float lam, float* adv, float* ret,
+                                hipStream_t s);
+hipError_t dpenv_dev_launch_sum(const float* x, int64_t count, const float* mean, float* out, hipStream_t s);
+hipError_t dpenv_dev_launch_adv_apply(float* x, int64_t count, const float* mean, const float* std, hipStream_t s);
+}
+
+#endif

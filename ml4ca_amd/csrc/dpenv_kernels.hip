@@ -1,0 +1,705 @@
+// dpenv_kernels.hip - gfx950 (CDNA4 / MI355X) kernels of libdpenv.so.
+//
+// Hot path: Revolt.step (reference src/rl/windows_workspace/specific/customEnv.py:92-133, "ENV")
+// for a batch of independent environments, ONE WAVEFRONT LANE PER ENVIRONMENT:
+//   action decode + clip        ENV:104-110,215-244
+//   command map                 ENV:117-122
+//   thruster force map          src/sl/SupervisedTau.py:42-83, qp_allocator.py:51-55,69-70
+//   plant, 20 x 10 ms           BUILD-OWNED (ENV:124 calls the closed Cybersea simulator)
+//   pose-error observation      errorFrame.py:25-37, mathematics.py:7-17, ENV:196-205
+//   reward                      ENV:253-325
+//   termination                 ENV:207-213
+//   new_ref                     ENV:131
+//   auto-reset                  ENV:135-194 + simtools.py:109-123 (batched form of ppo.py:305-322)
+//
+// Memory plan (HBM): library-owned state as four float4 streams so that every wave-level access
+// is one 1 KiB coalesced dwordx4 transaction (16 B per lane):
+//   S0[i] = (N, E, psi, u)            read + written every step
+//   S1[i] = (v, r, a_port, a_star)    read + written every step
+//   S2[i] = (pt_bow, pt_port, pt_star, step_count bits)   read + written every step
+//   RF[i] = (ref_N, ref_E, ref_psi, a_bow)   read every step, written only on new_ref / reset / FULL
+// => 64 B read + 48 B written of state per env-step; with a 7-float action, 9-float observation,
+// reward and done byte: 92 B read + 89 B written (SURVEY 8d accounts 88 + 89 = 177 B).
+// Caller-facing action/observation batches are [n][dim] (torch-native); they are transposed
+// through LDS (odd row strides 7 / 9 / 5 / 3 -> conflict-free ds_read/ds_write) so that global
+// traffic stays fully coalesced.  Per-vessel-class parameter blocks (mass, damping, thruster
+// geometry) are staged in LDS as [param][class] when more than one class exists; with a single
+// class they arrive as kernel arguments (SGPRs).  No MFMA: this is batched 3x3 physics.
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+
+#include "dpenv_dev.h"
+
+namespace dpenv {
+
+constexpr float kPi = 3.14159265358979323846f;
+
+// ---- Philox4x32-10 (Salmon et al. SC'11): counter-based RNG of the reset sampler -------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ float u01_sym(uint32_t w)
+{
+    // 24-bit uniform mapped to [-1, 1): every step is exact in fp32
+    return 2.0f * (float)(w >> 8) * (1.0f / 16777216.0f) - 1.0f;
+}
+
+template <int MODE> struct ModeTraits;
+template <> struct ModeTraits<MODE_FULL> { static constexpr int A = 6; };
+template <> struct ModeTraits<MODE_SIMPLE> { static constexpr int A = 3; };
+template <> struct ModeTraits<MODE_LIMITED> { static constexpr int A = 5; };
+template <> struct ModeTraits<MODE_FINAL_WRAP> { static constexpr int A = 5; };
+template <> struct ModeTraits<MODE_FINAL_CONT> { static constexpr int A = 7; };
+
+// state-space bounds, ENV:26,337,361,386 (intended per-variant values)
+template <int MODE> __device__ __forceinline__ void ss_bounds(float b[6])
+{
+    b[0] = 8.0f; b[1] = 8.0f; b[2] = kPi * 0.5f; b[3] = 1.4f; b[4] = 0.30f; b[5] = 0.52f;
+    if (MODE == MODE_SIMPLE) { b[3] = 1.75f; b[5] = 0.51f; }
+    if (MODE == MODE_LIMITED || MODE == MODE_FINAL_WRAP || MODE == MODE_FINAL_CONT) b[2] = 45.0f * kPi / 180.0f;
+}
+
+// default azimuth commands, ENV:58,341-346,366-371,394-399
+template <int MODE> __device__ __forceinline__ void default_angles(float& a_bow, float& a_port, float& a_star)
+{
+    a_bow = 0.0f; a_port = 0.0f; a_star = 0.0f;
+    if (MODE == MODE_SIMPLE) { a_bow = kPi * 0.5f; a_port = -3.0f * kPi * 0.25f; a_star = 3.0f * kPi * 0.25f; }
+    if (MODE == MODE_LIMITED || MODE == MODE_FINAL_WRAP || MODE == MODE_FINAL_CONT) a_bow = kPi * 0.5f;
+}
+
+// mathematics.py:14-17 wrap_angle in the cancellation-free form x - 2ref*floor((x+ref)/(2ref));
+// deg=true is what errorFrame.py:29,31 actually calls (quirk Q1: degrees constant on radians).
+__device__ __forceinline__ float wrap_angle(float x, bool deg)
+{
+    const float ref = deg ? 180.0f : kPi;
+    const float k = floorf((x + ref) / (2.0f * ref));
+    return x - k * (2.0f * ref);
+}
+
+__device__ __forceinline__ float clipf(float v, float b) { return fminf(fmaxf(v, -b), b); }
+
+struct Vessel {
+    float m11, m22, m23, inv11, i22, i23, i33;
+    float Xu, Xuu, Yv, Yvv, Yr, Nv, Nr, Nrr;
+    float Kf[3], Kr[3], lx[3], ly[3];
+};
+
+__device__ __forceinline__ Vessel vessel_from_args(const VesselDev& d)
+{
+    Vessel v;
+    v.m11 = d.p[VD_M11]; v.m22 = d.p[VD_M22]; v.m23 = d.p[VD_M23];
+    v.inv11 = d.p[VD_INV11]; v.i22 = d.p[VD_I22]; v.i23 = d.p[VD_I23]; v.i33 = d.p[VD_I33];
+    v.Xu = d.p[VD_XU]; v.Xuu = d.p[VD_XUU]; v.Yv = d.p[VD_YV]; v.Yvv = d.p[VD_YVV];
+    v.Yr = d.p[VD_YR]; v.Nv = d.p[VD_NV]; v.Nr = d.p[VD_NR]; v.Nrr = d.p[VD_NRR];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        v.Kf[i] = d.p[VD_KF + i]; v.Kr[i] = d.p[VD_KR + i]; v.lx[i] = d.p[VD_LX + i]; v.ly[i] = d.p[VD_LY + i];
+    }
+    return v;
+}
+
+// LDS image of the class table is [param][class]: for a fixed parameter, lanes of different
+// classes hit different banks (n_classes <= 32 distinct banks) and lanes of one class broadcast.
+__device__ __forceinline__ Vessel vessel_from_lds(const float* tab, int ncls, int cls)
+{
+    Vessel v;
+    v.m11 = tab[VD_M11 * ncls + cls]; v.m22 = tab[VD_M22 * ncls + cls]; v.m23 = tab[VD_M23 * ncls + cls];
+    v.inv11 = tab[VD_INV11 * ncls + cls]; v.i22 = tab[VD_I22 * ncls + cls]; v.i23 = tab[VD_I23 * ncls + cls];
+    v.i33 = tab[VD_I33 * ncls + cls];
+    v.Xu = tab[VD_XU * ncls + cls]; v.Xuu = tab[VD_XUU * ncls + cls]; v.Yv = tab[VD_YV * ncls + cls];
+    v.Yvv = tab[VD_YVV * ncls + cls]; v.Yr = tab[VD_YR * ncls + cls]; v.Nv = tab[VD_NV * ncls + cls];
+    v.Nr = tab[VD_NR * ncls + cls]; v.Nrr = tab[VD_NRR * ncls + cls];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        v.Kf[i] = tab[(VD_KF + i) * ncls + cls]; v.Kr[i] = tab[(VD_KR + i) * ncls + cls];
+        v.lx[i] = tab[(VD_LX + i) * ncls + cls]; v.ly[i] = tab[(VD_LY + i) * ncls + cls];
+    }
+    return v;
+}
+
+// SupervisedTau.py:42-83: tau = B(alpha) F, F_i = K_i n_i |n_i|
+__device__ __forceinline__ void thrust_map(const Vessel& ve, const float n[3], const float al[3], float& tx, float& ty,
+                                           float& tn)
+{
+    tx = 0.0f; ty = 0.0f; tn = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float K = (n[i] >= 0.0f) ? ve.Kf[i] : ve.Kr[i];
+        const float F = K * fabsf(n[i]) * n[i];
+        float sa, ca;
+        sincosf(al[i], &sa, &ca);
+        tx += ca * F;
+        ty += sa * F;
+        tn += (ve.lx[i] * sa - ve.ly[i] * ca) * F;
+    }
+}
+
+// observation, errorFrame.py:25-32 + ENV:196-205
+__device__ __forceinline__ void make_obs(float N, float E, float psi, float u, float v, float r, float refN, float refE,
+                                         float refPsi, const float pt[3], bool deg, float o[9])
+{
+    const float eN = N - refN, eE = E - refE;
+    const float rot = wrap_angle(psi, deg);
+    float sr, cr;
+    sincosf(rot, &sr, &cr);
+    o[0] = cr * eN + sr * eE;
+    o[1] = cr * eE - sr * eN;
+    o[2] = wrap_angle(psi - refPsi, deg);
+    o[3] = u; o[4] = v; o[5] = r;
+    o[6] = pt[0] * 0.01f; o[7] = pt[1] * 0.01f; o[8] = pt[2] * 0.01f;
+}
+
+// training reset sampler, ENV:143-145 + simtools.py:109-123, Philox keyed (seed; global env id, episode)
+template <int MODE>
+__device__ __forceinline__ void sample_reset(const StepArgs& a, int64_t gid, uint32_t episode, float eta[3], float nu[3])
+{
+    float b[6];
+    ss_bounds<MODE>(b);
+    const float fr = a.reset_fraction, fv = 0.30f * a.reset_fraction;
+    uint32_t w0[4], w1[4];
+    const uint32_t g0 = (uint32_t)((uint64_t)gid & 0xffffffffu), g1 = (uint32_t)((uint64_t)gid >> 32);
+    philox4x32_10(g0, g1, episode, 0u, a.seed_lo, a.seed_hi, w0);
+    philox4x32_10(g0, g1, episode, 1u, a.seed_lo, a.seed_hi, w1);
+    eta[0] = (b[0] * fr) * u01_sym(w0[0]);
+    eta[1] = (b[1] * fr) * u01_sym(w0[1]);
+    eta[2] = (b[2] * fr) * u01_sym(w0[2]);
+    nu[0] = (b[3] * fv) * u01_sym(w0[3]);
+    nu[1] = (b[4] * fv) * u01_sym(w1[0]);
+    nu[2] = (b[5] * fv) * u01_sym(w1[1]);
+}
+
+__device__ __forceinline__ uint16_t f2bf(float x)
+{
+    // plain cast: v_cvt_pk_bf16_f32 (RNE, NaN stays NaN)
+    return __builtin_bit_cast(uint16_t, __float2bfloat16(x));
+}
+
+// Write one observation row per lane.  AOS: through LDS so that the global stores are coalesced
+// (row stride OD is odd for OD = 9 -> conflict-free; OD = 6 costs a 2-way conflict).
+template <int OD>
+__device__ __forceinline__ void store_obs(const StepArgs& a, void* dst, const float o[9], int i, bool live, float* lds)
+{
+    const int tid = threadIdx.x;
+    const int n = a.n;
+    if (a.obs_layout == LAYOUT_SOA) {
+        if (live) {
+            if (a.obs_bf16) {
+                uint16_t* p = (uint16_t*)dst;
+#pragma unroll
+                for (int k = 0; k < OD; ++k) p[(int64_t)k * n + i] = f2bf(o[k]);
+            } else {
+                float* p = (float*)dst;
+#pragma unroll
+                for (int k = 0; k < OD; ++k) p[(int64_t)k * n + i] = o[k];
+            }
+        }
+        return;
+    }
+    __syncthreads();   // previous users of the LDS staging area are done
+#pragma unroll
+    for (int k = 0; k < OD; ++k) lds[tid * OD + k] = o[k];
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * (BLOCK * OD);
+    const int64_t total = (int64_t)n * OD;
+    if (a.obs_bf16) {
+        uint16_t* p = (uint16_t*)dst;
+#pragma unroll
+        for (int j = 0; j < OD; ++j) {
+            const int64_t idx = base + j * BLOCK + tid;
+            if (idx < total) p[idx] = f2bf(lds[j * BLOCK + tid]);
+        }
+    } else {
+        float* p = (float*)dst;
+#pragma unroll
+        for (int j = 0; j < OD; ++j) {
+            const int64_t idx = base + j * BLOCK + tid;
+            if (idx < total) p[idx] = lds[j * BLOCK + tid];
+        }
+    }
+}
+
+// =============================================================================================
+//  env.step
+// =============================================================================================
+template <int MODE, bool EXT, bool PER_CLASS>
+__global__ __launch_bounds__(BLOCK) void step_kernel(const StepArgs a)
+{
+    constexpr int A = ModeTraits<MODE>::A;
+    constexpr int OD = EXT ? 9 : 6;
+    __shared__ float lds_io[BLOCK * 9];
+    __shared__ float lds_cls[PER_CLASS ? VD_COUNT * MAX_CLASSES : 1];
+
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * BLOCK + tid;
+    const int n = a.n;
+    const bool live = i < n;
+    const int il = live ? i : n - 1;   // dead lanes shadow the last env and never store
+
+    // ---- issue all global loads up front ------------------------------------------------------
+    float act[A];
+    if (a.action_layout == LAYOUT_AOS) {
+        const int64_t base = (int64_t)blockIdx.x * (BLOCK * A);
+        const int64_t total = (int64_t)n * A;
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+            const int64_t idx = base + j * BLOCK + tid;
+            lds_io[j * BLOCK + tid] = (idx < total) ? a.action[idx] : 0.0f;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < A; ++k) act[k] = a.action[(int64_t)k * n + il];
+    }
+    const float4 s0 = a.S0[il];
+    const float4 s1 = a.S1[il];
+    const float4 s2 = a.S2[il];
+    const float4 rf = a.RF[il];
+    float nrN = 0.0f, nrE = 0.0f, nrP = 0.0f;
+    if (a.new_ref) { nrN = a.new_ref[il]; nrE = a.new_ref[(int64_t)n + il]; nrP = a.new_ref[2 * (int64_t)n + il]; }
+    float vc = 0.0f, beta = 0.0f;
+    if (a.cur_vc) { vc = a.cur_vc[il]; beta = a.cur_beta[il]; }
+    int cls = 0;
+    if (PER_CLASS) {
+        cls = a.class_id[il];
+        for (int k = tid; k < VD_COUNT * a.n_classes; k += BLOCK) {
+            const int c = k / VD_COUNT, p = k - c * VD_COUNT;   // global table is [class][param]
+            lds_cls[p * a.n_classes + c] = a.class_tab[k];
+        }
+    }
+    if (a.action_layout == LAYOUT_AOS || PER_CLASS) __syncthreads();
+    if (a.action_layout == LAYOUT_AOS) {
+#pragma unroll
+        for (int k = 0; k < A; ++k) act[k] = lds_io[tid * A + k];
+    }
+    const Vessel ve = PER_CLASS ? vessel_from_lds(lds_cls, a.n_classes, cls) : vessel_from_args(a.v0);
+
+    float N = s0.x, E = s0.y, psi = s0.z, u = s0.w;
+    float v = s1.x, r = s1.y;
+    float refN = rf.x, refE = rf.y, refPsi = rf.z;
+    const float pt_old[3] = {s2.x, s2.y, s2.z};
+    int steps = __float_as_int(s2.w);
+    const float ang_prev[3] = {rf.w, s1.z, s1.w};   // ENV:102 (bow, port, star)
+    float ang[3] = {rf.w, s1.z, s1.w};
+
+    // ---- action decode, ENV:104-110 + scale_and_clip ENV:215-225 + command map ENV:117-122 ------
+    float thr[3];
+    thr[0] = clipf(act[0] * 100.0f, 100.0f);
+    thr[1] = clipf(act[1] * 100.0f, 100.0f);
+    thr[2] = clipf(act[2] * 100.0f, 100.0f);
+    if (MODE == MODE_FULL) {
+        ang[0] = clipf(act[3] * kPi, kPi); ang[1] = clipf(act[4] * kPi, kPi); ang[2] = clipf(act[5] * kPi, kPi);
+    } else if (MODE == MODE_LIMITED) {
+        ang[1] = clipf(act[3] * (kPi * 0.5f), kPi * 0.5f); ang[2] = clipf(act[4] * (kPi * 0.5f), kPi * 0.5f);
+    } else if (MODE == MODE_FINAL_WRAP) {
+        // ENV:237-244: wrap_angle(a*pi, deg=False)/pi, evaluated in units of pi (exact in fp32)
+        const float w3 = act[3] - 2.0f * floorf((act[3] + 1.0f) * 0.5f);
+        const float w4 = act[4] - 2.0f * floorf((act[4] + 1.0f) * 0.5f);
+        ang[1] = clipf(w3 * kPi, kPi); ang[2] = clipf(w4 * kPi, kPi);
+    } else if (MODE == MODE_FINAL_CONT) {
+        // ENV:227-235: atan2(sin_head, cos_head)/pi, then *pi and clip
+        ang[1] = clipf(atan2f(act[3], act[4]), kPi); ang[2] = clipf(atan2f(act[5], act[6]), kPi);
+    }
+
+    // ---- plant: BUILD-OWNED 3-DOF model, n_substeps semi-implicit Euler steps ------------------
+    float tx, ty, tn;
+    thrust_map(ve, thr, ang, tx, ty, tn);
+    float sn, cs;
+    sincosf(psi, &sn, &cs);
+    float vcN = 0.0f, vcE = 0.0f;
+    if (a.cur_vc) {
+        float sb, cb;
+        sincosf(beta, &sb, &cb);
+        vcN = vc * cb; vcE = vc * sb;
+        u -= cs * vcN + sn * vcE;      // relative velocity nu_r = nu - R(psi)^T v_c
+        v -= cs * vcE - sn * vcN;
+    }
+    const float h = a.h;
+    const int nsub = a.hold_plant ? 0 : a.n_substeps;
+    for (int k = 0; k < nsub; ++k) {
+        const float c13 = -(ve.m22 * v + ve.m23 * r);
+        const float c23 = ve.m11 * u;
+        const float fx = tx - c13 * r - (ve.Xu + ve.Xuu * fabsf(u)) * u;
+        const float fy = ty - c23 * r - ((ve.Yv + ve.Yvv * fabsf(v)) * v + ve.Yr * r);
+        const float fn = tn + (c13 * u + c23 * v) - (ve.Nv * v + (ve.Nr + ve.Nrr * fabsf(r)) * r);
+        u += h * (fx * ve.inv11);
+        v += h * (ve.i22 * fy + ve.i23 * fn);
+        r += h * (ve.i23 * fy + ve.i33 * fn);
+        N += h * (cs * u - sn * v + vcN);
+        E += h * (sn * u + cs * v + vcE);
+        const float d = h * r;
+        const float d2 = d * d;
+        const float sd = d * (1.0f - d2 * (1.0f / 6.0f) * (1.0f - d2 * (1.0f / 20.0f)));
+        const float cd = 1.0f - d2 * 0.5f * (1.0f - d2 * (1.0f / 12.0f));
+        psi += d;
+        const float c2 = cs * cd - sn * sd;
+        const float s2n = sn * cd + cs * sd;
+        cs = c2; sn = s2n;
+    }
+    if (a.cur_vc) {
+        float se, ce;
+        sincosf(psi, &se, &ce);
+        u += ce * vcN + se * vcE;
+        v += ce * vcE - se * vcN;
+    }
+
+    // ---- observation (previous thrust: quirk Q2), reward, termination --------------------------
+    const bool deg = (a.wrap_mode == WRAP_REFERENCE);
+    float o[9];
+    make_obs(N, E, psi, u, v, r, refN, refE, refPsi, pt_old, deg, o);
+
+    float p_vel, p_pos, p_thr, p_der = 0.0f;
+    {
+        p_vel = -sqrtf(o[3] * o[3] * 0.5f + o[4] * o[4] * 0.5f + o[5] * o[5]);            // ENV:267-273
+        const float rr2 = o[0] * o[0] + o[1] * o[1];
+        const float yaw = o[2] * (180.0f / kPi);                                           // ENV:281
+        const float multivar = 2.0f * expf(-0.5f * (rr2 + yaw * yaw * (1.0f / 25.0f)));    // ENV:283, covar ENV:86-88
+        const float special = sqrtf(rr2 + (yaw * 0.25f) * (yaw * 0.25f));                  // ENV:287
+        p_pos = multivar + fmaxf(-1.0f, 1.0f - 0.1f * special) + 0.5f;                     // ENV:288-290
+        p_thr = -(fabsf(thr[0]) * 0.20f + fabsf(thr[1]) * 0.30f + fabsf(thr[2]) * 0.30f) * 0.01f;   // ENV:292-302
+        if (EXT) {
+            const float inv_dt = a.inv_dt;
+            float pen = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pen -= fabsf((thr[k] - pt_old[k]) * inv_dt * 0.01f) * 0.05f;   // ENV:310-313
+            const float inv_bnd = (MODE == MODE_LIMITED) ? (2.0f / kPi) : (1.0f / kPi);   // ENV:319
+            float angpen = -(fabsf((ang[1] - ang_prev[1]) * inv_dt * inv_bnd) * 0.01f +
+                             fabsf((ang[2] - ang_prev[2]) * inv_dt * inv_bnd) * 0.01f);   // ENV:315-320 (bow coeff 0)
+            p_der = pen + fmaxf(-1.0f, angpen);                                           // ENV:322-323
+        }
+    }
+    const float reward = p_vel + p_pos + p_thr + p_der;   // ENV:263
+
+    uint32_t d = 0;
+    if (a.terminate) {
+        float b[6];
+        ss_bounds<MODE>(b);
+        bool t = false;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) t = t || (fabsf(o[k]) > b[k]);   // ENV:207-213, strict >
+        d = t ? DONE_TERMINAL : 0u;
+    }
+    {
+        const float chk = N + E + psi + u + v + r;     // any NaN/Inf poisons the sum
+        if (!(fabsf(chk) <= 3.0e38f)) d |= DONE_TERMINAL | DONE_FAULT;
+    }
+    if (a.new_ref) { refN = nrN; refE = nrE; refPsi = nrP; }   // ENV:131: visible from the next step (Q4)
+    steps += 1;
+    if (a.max_ep_len > 0 && steps >= a.max_ep_len) d |= DONE_TIMELIMIT;   // ppo.py:304
+
+    float pt_new[3] = {thr[0], thr[1], thr[2]};   // ENV:126
+    bool rf_dirty = (a.new_ref != nullptr) || (MODE == MODE_FULL);
+    float o_out[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o_out[k] = o[k];
+
+    // ---- auto-reset (divergent, rare): ENV:135-194 with the training sampler --------------------
+    if (a.auto_reset && d != 0u && live) {
+        if (a.final_obs) {
+            // scattered 36-byte rows, only from lanes that finished an episode
+            if (a.obs_layout == LAYOUT_SOA) {
+                for (int k = 0; k < OD; ++k) {
+                    if (a.obs_bf16) ((uint16_t*)a.final_obs)[(int64_t)k * n + i] = f2bf(o[k]);
+                    else ((float*)a.final_obs)[(int64_t)k * n + i] = o[k];
+                }
+            } else {
+                for (int k = 0; k < OD; ++k) {
+                    if (a.obs_bf16) ((uint16_t*)a.final_obs)[(int64_t)i * OD + k] = f2bf(o[k]);
+                    else ((float*)a.final_obs)[(int64_t)i * OD + k] = o[k];
+                }
+            }
+        }
+        const uint32_t ep = (uint32_t)a.episode[i];
+        a.episode[i] = (int)(ep + 1u);
+        float eta[3], nu[3];
+        sample_reset<MODE>(a, a.env_id_base + i, ep, eta, nu);
+        N = eta[0]; E = eta[1]; psi = eta[2]; u = nu[0]; v = nu[1]; r = nu[2];
+        pt_new[0] = pt_new[1] = pt_new[2] = 0.0f;                    // ENV:190
+        default_angles<MODE>(ang[0], ang[1], ang[2]);                // ENV:173-177,192
+        steps = 0;
+        rf_dirty = true;
+        make_obs(N, E, psi, u, v, r, refN, refE, refPsi, pt_new, deg, o_out);
+    }
+
+    // ---- stores ---------------------------------------------------------------------------------
+    if (live) {
+        a.S0[i] = make_float4(N, E, psi, u);
+        a.S1[i] = make_float4(v, r, ang[1], ang[2]);
+        a.S2[i] = make_float4(pt_new[0], pt_new[1], pt_new[2], __int_as_float(steps));
+        if (rf_dirty) a.RF[i] = make_float4(refN, refE, refPsi, ang[0]);
+        a.rew[i] = reward;
+        a.done[i] = (uint8_t)d;
+        if (a.parts) {
+            a.parts[i] = p_vel; a.parts[(int64_t)n + i] = p_pos;
+            a.parts[2 * (int64_t)n + i] = p_thr; a.parts[3 * (int64_t)n + i] = p_der;
+        }
+    }
+    store_obs<OD>(a, a.obs, o_out, i, live, lds_io);
+}
+
+// =============================================================================================
+//  env.reset  (ENV:135-194)
+// =============================================================================================
+template <int MODE, bool EXT>
+__global__ __launch_bounds__(BLOCK) void reset_kernel(const StepArgs a, const uint8_t* mask, const float* init,
+                                                      const float* ref)
+{
+    constexpr int OD = EXT ? 9 : 6;
+    __shared__ float lds_io[BLOCK * 9];
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * BLOCK + tid;
+    const int n = a.n;
+    const bool live = i < n;
+    const int il = live ? i : n - 1;
+
+    float4 s0 = a.S0[il], s1 = a.S1[il], s2 = a.S2[il], rf = a.RF[il];
+    const bool sel = live && (mask == nullptr || mask[il] != 0);
+    if (sel) {
+        float eta[3], nu[3];
+        if (init) {
+            // explicit **init (ENV:141,152,159-161); the 50 held sub-steps (ENV:164-167) keep it in place
+            for (int k = 0; k < 3; ++k) { eta[k] = init[(int64_t)k * n + i]; nu[k] = init[(int64_t)(3 + k) * n + i]; }
+        } else {
+            const uint32_t ep = (uint32_t)a.episode[i];
+            a.episode[i] = (int)(ep + 1u);
+            sample_reset<MODE>(a, a.env_id_base + i, ep, eta, nu);
+        }
+        float ab, ap, as;
+        default_angles<MODE>(ab, ap, as);
+        s0 = make_float4(eta[0], eta[1], eta[2], nu[0]);
+        s1 = make_float4(nu[1], nu[2], ap, as);
+        s2 = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(0));
+        rf.w = ab;
+        if (ref) { rf.x = ref[i]; rf.y = ref[(int64_t)n + i]; rf.z = ref[2 * (int64_t)n + i]; }
+        a.S0[i] = s0; a.S1[i] = s1; a.S2[i] = s2; a.RF[i] = rf;
+    }
+    if (a.obs) {
+        const float pt[3] = {s2.x, s2.y, s2.z};
+        float o[9];
+        make_obs(s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, rf.x, rf.y, rf.z, pt, a.wrap_mode == WRAP_REFERENCE, o);
+        store_obs<OD>(a, a.obs, o, i, live, lds_io);
+    }
+}
+
+// ---- canonical state <-> packed float4 streams (parity tests, checkpointing) ---------------------
+__global__ __launch_bounds__(BLOCK) void get_state_kernel(const StepArgs a, float* st, int32_t* ctr)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t n = a.n;
+    if (i >= a.n) return;
+    const float4 s0 = a.S0[i], s1 = a.S1[i], s2 = a.S2[i], rf = a.RF[i];
+    if (st) {
+        st[0 * n + i] = s0.x; st[1 * n + i] = s0.y; st[2 * n + i] = s0.z;
+        st[3 * n + i] = s0.w; st[4 * n + i] = s1.x; st[5 * n + i] = s1.y;
+        st[6 * n + i] = rf.x; st[7 * n + i] = rf.y; st[8 * n + i] = rf.z;
+        st[9 * n + i] = s2.x; st[10 * n + i] = s2.y; st[11 * n + i] = s2.z;
+        st[12 * n + i] = rf.w; st[13 * n + i] = s1.z; st[14 * n + i] = s1.w;
+    }
+    if (ctr) { ctr[i] = __float_as_int(s2.w); ctr[n + i] = a.episode[i]; }
+}
+
+__global__ __launch_bounds__(BLOCK) void set_state_kernel(const StepArgs a, const float* st, const int32_t* ctr)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t n = a.n;
+    if (i >= a.n) return;
+    float4 s2 = a.S2[i];
+    if (st) {
+        a.S0[i] = make_float4(st[0 * n + i], st[1 * n + i], st[2 * n + i], st[3 * n + i]);
+        a.S1[i] = make_float4(st[4 * n + i], st[5 * n + i], st[13 * n + i], st[14 * n + i]);
+        a.RF[i] = make_float4(st[6 * n + i], st[7 * n + i], st[8 * n + i], st[12 * n + i]);
+        s2.x = st[9 * n + i]; s2.y = st[10 * n + i]; s2.z = st[11 * n + i];
+    }
+    if (ctr) { s2.w = __int_as_float(ctr[i]); a.episode[i] = ctr[n + i]; }
+    a.S2[i] = s2;
+}
+
+// ---- stateless force map (SupervisedTau.py:42-83) -------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void thrust_map_kernel(const VesselDev vd, const float* n_pct, const float* alpha,
+                                                           float* tau, int n)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const Vessel ve = vessel_from_args(vd);
+    const float nn[3] = {n_pct[i], n_pct[(int64_t)n + i], n_pct[2 * (int64_t)n + i]};
+    const float al[3] = {alpha[i], alpha[(int64_t)n + i], alpha[2 * (int64_t)n + i]};
+    float tx, ty, tn;
+    thrust_map(ve, nn, al, tx, ty, tn);
+    tau[i] = tx; tau[(int64_t)n + i] = ty; tau[2 * (int64_t)n + i] = tn;
+}
+
+// ---- GAE-lambda reverse scan, one lane per env column (ppo.py:65-91, core.py:48-63) ---------------
+__global__ __launch_bounds__(BLOCK) void gae_kernel(const float* rew, const float* val, const uint8_t* end,
+                                                    const float* boot, const float* last_val, int T, int n, float gamma,
+                                                    float lam, float* adv, float* ret)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float acc = 0.0f, g = 0.0f, vnext = 0.0f;
+    const float gl = gamma * lam;
+    for (int t = T - 1; t >= 0; --t) {
+        const int64_t k = (int64_t)t * n + i;
+        const bool is_end = (t == T - 1) || (end != nullptr && end[k] != 0);
+        if (is_end) {
+            const float lv = boot ? boot[k] : ((t == T - 1 && last_val) ? last_val[i] : 0.0f);
+            acc = 0.0f; g = lv; vnext = lv;
+        }
+        const float rk = rew[k], vk = val[k];
+        const float delta = rk + gamma * vnext - vk;
+        acc = delta + gl * acc;
+        g = rk + gamma * g;
+        adv[k] = acc; ret[k] = g;
+        vnext = vk;
+    }
+}
+
+// ---- advantage statistics (ppo.py:99-103, mpi_tools.py:71-92) --------------------------------------
+__device__ __forceinline__ float block_sum(float x, float* red)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) red[wave] = x;
+    __syncthreads();
+    float s = 0.0f;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < BLOCK / 64; ++w) s += red[w];
+    return s;
+}
+
+__global__ __launch_bounds__(BLOCK) void sum_kernel(const float* x, int64_t count, const float* mean, float* out)
+{
+    __shared__ float red[BLOCK / 64];
+    const float m = mean ? mean[0] : 0.0f;
+    float s = 0.0f;
+    for (int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x; k < count; k += (int64_t)gridDim.x * BLOCK) {
+        const float d = x[k] - m;
+        s += mean ? d * d : d;
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+__global__ __launch_bounds__(BLOCK) void adv_apply_kernel(float* x, int64_t count, const float* mean, const float* std)
+{
+    const float m = mean[0], inv = 1.0f / (std[0] + 1e-8f);
+    for (int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x; k < count; k += (int64_t)gridDim.x * BLOCK)
+        x[k] = (x[k] - m) * inv;
+}
+
+}  // namespace dpenv
+
+// =============================================================================================
+//  launchers (called from dpenv_api.cpp through dpenv_dev.h)
+// =============================================================================================
+using namespace dpenv;
+
+template <int MODE>
+static hipError_t launch_step_mode(const StepArgs& a, bool ext, bool per_class, hipStream_t s)
+{
+    const dim3 grid((a.n + BLOCK - 1) / BLOCK), block(BLOCK);
+    if (ext) {
+        if (per_class) hipLaunchKernelGGL((step_kernel<MODE, true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((step_kernel<MODE, true, false>), grid, block, 0, s, a);
+    } else {
+        if (per_class) hipLaunchKernelGGL((step_kernel<MODE, false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((step_kernel<MODE, false, false>), grid, block, 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+extern "C" hipError_t dpenv_dev_launch_step(const StepArgs* a, int mode, int ext, int per_class, hipStream_t s)
+{
+    switch (mode) {
+    case MODE_FULL: return launch_step_mode<MODE_FULL>(*a, ext, per_class, s);
+    case MODE_SIMPLE: return launch_step_mode<MODE_SIMPLE>(*a, ext, per_class, s);
+    case MODE_LIMITED: return launch_step_mode<MODE_LIMITED>(*a, ext, per_class, s);
+    case MODE_FINAL_WRAP: return launch_step_mode<MODE_FINAL_WRAP>(*a, ext, per_class, s);
+    case MODE_FINAL_CONT: return launch_step_mode<MODE_FINAL_CONT>(*a, ext, per_class, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+template <int MODE>
+static hipError_t launch_reset_mode(const StepArgs& a, bool ext, const uint8_t* mask, const float* init, const float* ref,
+                                    hipStream_t s)
+{
+    const dim3 grid((a.n + BLOCK - 1) / BLOCK), block(BLOCK);
+    if (ext) hipLaunchKernelGGL((reset_kernel<MODE, true>), grid, block, 0, s, a, mask, init, ref);
+    else hipLaunchKernelGGL((reset_kernel<MODE, false>), grid, block, 0, s, a, mask, init, ref);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t dpenv_dev_launch_reset(const StepArgs* a, int mode, int ext, const uint8_t* mask, const float* init,
+                                             const float* ref, hipStream_t s)
+{
+    switch (mode) {
+    case MODE_FULL: return launch_reset_mode<MODE_FULL>(*a, ext, mask, init, ref, s);
+    case MODE_SIMPLE: return launch_reset_mode<MODE_SIMPLE>(*a, ext, mask, init, ref, s);
+    case MODE_LIMITED: return launch_reset_mode<MODE_LIMITED>(*a, ext, mask, init, ref, s);
+    case MODE_FINAL_WRAP: return launch_reset_mode<MODE_FINAL_WRAP>(*a, ext, mask, init, ref, s);
+    case MODE_FINAL_CONT: return launch_reset_mode<MODE_FINAL_CONT>(*a, ext, mask, init, ref, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+extern "C" hipError_t dpenv_dev_launch_get_state(const StepArgs* a, float* st, int32_t* ctr, hipStream_t s)
+{
+    hipLaunchKernelGGL(get_state_kernel, dim3((a->n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, *a, st, ctr);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t dpenv_dev_launch_set_state(const StepArgs* a, const float* st, const int32_t* ctr, hipStream_t s)
+{
+    hipLaunchKernelGGL(set_state_kernel, dim3((a->n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, *a, st, ctr);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t dpenv_dev_launch_thrust_map(const VesselDev* vd, const float* n_pct, const float* alpha, float* tau,
+                                                  int n, hipStream_t s)
+{
+    hipLaunchKernelGGL(thrust_map_kernel, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, *vd, n_pct, alpha, tau, n);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t dpenv_dev_launch_gae(const float* rew, const float* val, const uint8_t* end, const float* boot,
+                                           const float* last_val, int T, int n, float gamma, float lam, float* adv,
+                                           float* ret, hipStream_t s)
+{
+    hipLaunchKernelGGL(gae_kernel, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, rew, val, end, boot, last_val, T, n,
+                       gamma, lam, adv, ret);
+    return hipGetLastError();
+}
+
+static int reduce_grid(int64_t count)
+{
+    int64_t g = (count + BLOCK - 1) / BLOCK;
+    if (g > 2048) g = 2048;   // 256 CUs x 8 blocks: grid-stride the rest
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" hipError_t dpenv_dev_launch_sum(const float* x, int64_t count, const float* mean, float* out, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sum_kernel, dim3(reduce_grid(count)), dim3(BLOCK), 0, s, x, count, mean, out);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t dpenv_dev_launch_adv_apply(float* x, int64_t count, const float* mean, const float* std,
+                                                 hipStream_t s)
+{
+    hipLaunchKernelGGL(adv_apply_kernel, dim3(reduce_grid(count)), dim3(BLOCK), 0, s, x, count, mean, std);
+    return hipGetLastError();
+}

@@ -1,0 +1,120 @@
+"""CPU-side checks of the product boundary: libdpenv.so loads, exports every symbol that
+include/dpenv.h declares, its structs have the layout the binding assumes, argument validation
+works, and - with no GPU - it fails loudly instead of falling back to anything."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    txt = open(os.path.join(ROOT, 'include', 'dpenv.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(dpenv_[a-z_0-9]+)\s*\(', txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from ml4ca_amd import _lib
+    lib = _lib.load()
+    declared = _header_functions()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), 'libdpenv.so does not export %s' % name
+    assert sorted(_lib.SYMBOLS) == declared, 'binding table and header drifted apart'
+    assert lib.dpenv_abi_version() == _lib.ABI_VERSION
+
+
+def test_struct_layout_matches_header(tmp_path):
+    from ml4ca_amd import _lib
+    src = tmp_path / 'sz.c'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "dpenv.h"\n'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(dpenv_config), sizeof(dpenv_step_io),'
+                   ' offsetof(dpenv_config, seed), offsetof(dpenv_config, reset_fraction),'
+                   ' offsetof(dpenv_config, hold_plant), offsetof(dpenv_step_io, final_obs));return 0;}\n')
+    exe = tmp_path / 'sz'
+    subprocess.check_call(['gcc', '-std=c99', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    want = [C.sizeof(_lib.Config), C.sizeof(_lib.StepIO), _lib.Config.seed.offset, _lib.Config.reset_fraction.offset,
+            _lib.Config.hold_plant.offset, _lib.StepIO.final_obs.offset]
+    assert got == want
+
+
+def test_defaults_match_reference_training_configuration():
+    """train.py:47-54 (final, ext, cont_ang), customEnv.py:79-83 (20 x 0.01 s, T = 400)."""
+    from ml4ca_amd import _lib
+    lib = _lib.load()
+    c = _lib.default_config()
+    assert (c.variant, c.extended_state, c.cont_ang, c.n_substeps, c.max_ep_len) == (_lib.FINAL, 1, 1, 20, 400)
+    assert abs(c.substep_dt - 0.01) < 1e-9 and abs(c.reset_fraction - 0.8) < 1e-7
+    assert lib.dpenv_act_dim(C.byref(c)) == 7 and lib.dpenv_obs_dim(C.byref(c)) == 9
+    for variant, cont, ad in [(_lib.FULL, 0, 6), (_lib.SIMPLE, 0, 3), (_lib.LIMITED, 0, 5), (_lib.FINAL, 0, 5)]:
+        c.variant, c.cont_ang = variant, cont
+        assert lib.dpenv_act_dim(C.byref(c)) == ad
+    v = _lib.default_vessel()
+    # thruster constants from the reference: qp_allocator.py:51-55,69-70 in env order bow, port, star
+    assert np.allclose(v[12:18], [0.0009, 0.00205, 0.00205] * 2)
+    assert np.allclose(v[18:24], [1.08, -1.12, -1.12, 0.0, -0.15, 0.15])
+    # and they are the constants the oracle integrates with
+    from oracle import oracle as O
+    assert np.array_equal(v, O.Oracle(O.make_config(), np.float32).vessel)
+
+
+def test_create_validates_and_fails_loudly_without_gpu():
+    import torch
+    from ml4ca_amd import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    c = _lib.default_config()
+    c.n_envs = 0
+    assert lib.dpenv_create(C.byref(c), None, 1, C.byref(h)) == _lib.EINVAL
+    assert b'n_envs' in lib.dpenv_last_error(None)
+    c.n_envs = 16
+    c.variant, c.cont_ang = _lib.SIMPLE, 0
+    assert lib.dpenv_create(C.byref(c), None, 1, C.byref(h)) == _lib.EINVAL      # simple + extended
+    assert b'customEnv.py:319' in lib.dpenv_last_error(None)
+    c = _lib.default_config()
+    c.n_envs = 16
+    c.struct_size = 8
+    assert lib.dpenv_create(C.byref(c), None, 1, C.byref(h)) == _lib.EINVAL
+    if not torch.cuda.is_available():
+        c = _lib.default_config()
+        c.n_envs = 16
+        assert lib.dpenv_create(C.byref(c), None, 1, C.byref(h)) == _lib.ENODEV
+        assert b'no CPU fallback' in lib.dpenv_last_error(None)
+        import ml4ca_amd
+        with pytest.raises(RuntimeError):
+            ml4ca_amd.BatchedRevoltEnv(4)
+        with pytest.raises(RuntimeError):
+            ml4ca_amd.RevoltFinal(None, extended_state=True, cont_ang=True)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: no file of the product package may reference it."""
+    pkg = os.path.join(ROOT, 'ml4ca_amd')
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp', 'Makefile')):
+                txt = open(os.path.join(root, f), errors='ignore').read()
+                assert 'dpenv_oracle' not in txt and 'from oracle' not in txt and 'import oracle' not in txt, f
+    code = 'import sys; import ml4ca_amd; assert not any(m == "oracle" or m.startswith("oracle.") for m in sys.modules)'
+    subprocess.check_call([sys.executable, '-c', code], cwd=ROOT)
+
+
+def test_variant_constants_match_reference_fixtures():
+    import ml4ca_amd
+    G = os.path.join(ROOT, 'tests', 'golden')
+    for mode, (variant, cont) in {'full': ('full', False), 'simple': ('simple', False), 'limited': ('limited', False),
+                                  'final_wrap': ('final', False), 'final_cont': ('final', True)}.items():
+        d = np.load(os.path.join(G, 'env_%s.npz' % mode))
+        k = ml4ca_amd.variant_constants(variant, cont)
+        assert np.allclose(k['real_ss_bounds'], d['real_ss_bounds'], rtol=0, atol=1e-15)
+        assert np.allclose(k['real_action_bounds'], d['real_action_bounds'], rtol=0, atol=1e-15)
+        assert np.allclose([k['default_actions'][i] for i in range(6)], d['default_actions'], rtol=0, atol=1e-15)
+        assert list(k['valid_action_indices']) == list(d['valid_action_indices'])
+        assert k['num_actions'] == int(d['meta'][3])

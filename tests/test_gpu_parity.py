@@ -1,0 +1,571 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against
+  (a) the committed golden vectors of the imported reference (scripted-plant fixtures), and
+  (b) the fp32 CPU oracle on identical seeded (state, action) pairs,
+plus size-independent properties at BASELINE.json's full sizes.
+
+Tolerance: north star = 1e-5 relative fp32; see tests/tolerances.py for the per-quantity floors.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import helpers as H
+from tests import tolerances as TOL
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+ALL_MODES = ['full', 'simple', 'limited', 'final_wrap', 'final_cont']
+
+
+def torch_():
+    import torch
+    assert torch.cuda.is_available(), 'gpu tests need an MI355X'
+    return torch
+
+
+def mode_tag_cases():
+    for m in ALL_MODES:
+        for ext in (True, False):
+            if m == 'simple' and ext:
+                continue
+            yield m, ext
+
+
+def step_both(env, orc, st, ctr, act, new_ref=None, current=None, want_final=False):
+    """One step on GPU and oracle from the same state; returns dicts of numpy outputs."""
+    torch = torch_()
+    n = st.shape[1]
+    env.set_state(H.to_dev(st), H.to_dev(ctr))
+    parts = torch.zeros((4, n), device=env.device)
+    fobs = torch.zeros(env.obs_shape, dtype=env.obs_torch_dtype, device=env.device) if want_final else None
+    a_dev = H.to_dev(act if env.layout == 'aos' else act.T.copy())
+    nr = None if new_ref is None else H.to_dev(new_ref)
+    obs, rew, done, _ = env.step(a_dev, new_ref=nr, reward_parts=parts, final_obs=fobs)
+    st2, ctr2 = env.get_state()
+    torch.cuda.synchronize()
+    g = dict(obs=obs.float().cpu().numpy(), rew=rew.cpu().numpy(), done=done.cpu().numpy(),
+             parts=parts.cpu().numpy().T, st=st2.cpu().numpy(), ctr=ctr2.cpu().numpy())
+    if env.layout == 'soa':
+        g['obs'] = g['obs'].T
+    if want_final:
+        g['fobs'] = fobs.float().cpu().numpy()
+    ost, octr = st.astype(orc.dtype).copy(), ctr.copy()
+    r = orc.step(ost, octr, act, new_ref=new_ref, current=current, want_parts=True, want_final_obs=want_final)
+    o = dict(obs=r[0], rew=r[1], done=r[2], parts=r[3], st=ost, ctr=octr)
+    if want_final:
+        o['fobs'] = r[4]
+    return g, o
+
+
+def compare(g, o, od, bounds):
+    TOL.assert_close(g['obs'], o['obs'], TOL.OBS_FLOOR[:od], what='obs')
+    TOL.assert_close(g['parts'], o['parts'], TOL.PARTS_FLOOR, what='reward parts')
+    TOL.assert_close(g['rew'], o['rew'], TOL.REWARD_FLOOR, what='reward')
+    TOL.assert_close(g['st'][0:3].T, o['st'][0:3].T, TOL.ETA_FLOOR, what='eta')
+    TOL.assert_close(g['st'][3:6].T, o['st'][3:6].T, TOL.NU_FLOOR, what='nu')
+    TOL.assert_close(g['st'][6:9].T, o['st'][6:9].T, TOL.ETA_FLOOR, what='ref')
+    TOL.assert_close(g['st'][9:12].T, o['st'][9:12].T, TOL.THRUST_FLOOR, what='thrust cmd')
+    TOL.assert_close(g['st'][12:15].T, o['st'][12:15].T, TOL.ANGLE_FLOOR, what='azimuth cmd')
+    assert np.array_equal(g['ctr'], o['ctr']), 'counters'
+    assert done_agrees(g['done'], o['done'], o['obs'], bounds).all(), 'done bits'
+
+
+def done_agrees(gdone, odone, oobs, bounds):
+    """done bits must be equal, except where an observation sits within fp32 rounding of a termination
+    bound (strict > on a value 1 ulp either side may legitimately flip).  Returns the mask of envs that agree."""
+    same = gdone == odone
+    if not same.all():
+        b = np.asarray(bounds, np.float64)
+        margin = np.abs(np.abs(oobs[:, :6].astype(np.float64)) - b[None, :]) / b[None, :]
+        borderline = margin.min(1) < 2e-6
+        bad = ~same & ~borderline
+        assert not bad.any(), 'done bits differ away from any bound at envs %s' % np.nonzero(bad)[0][:8]
+    return same
+
+
+# --------------------------------------------------------------------------------------------
+# (a) the reference's golden vectors straight through the HIP kernel
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('mode,ext', list(mode_tag_cases()))
+def test_reference_golden_single_steps_through_kernel(mode, ext):
+    """customEnv.py:92-133 fixtures (scripted plant): the kernel runs with hold_plant=1 from the
+    fixture's post-plant (eta, nu) and must reproduce the reference's commands, observation,
+    reward parts, reward, termination and new_ref bookkeeping."""
+    torch = torch_()
+    d = np.load(os.path.join(G, 'env_%s.npz' % mode))
+    p = 'step_%s_' % ('ext' if ext else 'base')
+    A = d[p + 'action'].astype(np.float32)
+    M = A.shape[0]
+    env, _ = H.make_pair(mode, M, ext=ext, hold_plant=True, time_limit=False)
+    st = np.zeros((O.NSTATE, M), np.float32)
+    st[0:3] = d[p + 'eta'].T
+    st[3:6] = d[p + 'nu'].T
+    st[6:9] = d[p + 'ref'].T
+    st[9:12] = d[p + 'pre_thrust'].T
+    st[12:15] = d[p + 'pre_angles'].T
+    use = d[p + 'use_new_ref'].astype(bool)
+    new_ref = np.where(use[:, None], d[p + 'new_ref'], d[p + 'ref']).T.astype(np.float32)
+    env.set_state(H.to_dev(st), H.to_dev(np.zeros((2, M), np.int32)))
+    parts = torch.zeros((4, M), device=env.device)
+    obs, rew, done, _ = env.step(H.to_dev(A), new_ref=H.to_dev(new_ref), reward_parts=parts)
+    st2, ctr2 = env.get_state()
+    torch.cuda.synchronize()
+    st2 = st2.cpu().numpy()
+    od = 9 if ext else 6
+    TOL.assert_close(obs.cpu().numpy(), d[p + 'obs'], TOL.OBS_FLOOR[:od], what='obs vs reference')
+    TOL.assert_close(parts.cpu().numpy().T, d[p + 'reward_parts'], TOL.PARTS_FLOOR, what='reward parts vs reference')
+    TOL.assert_close(rew.cpu().numpy(), d[p + 'reward'], TOL.REWARD_FLOOR, what='reward vs reference')
+    assert np.array_equal(done.cpu().numpy() & 1, d[p + 'done']), 'done vs reference'
+    TOL.assert_close(st2[9:12].T, d[p + 'cmd_thrust'], TOL.THRUST_FLOOR, what='thrust commands vs reference')
+    TOL.assert_close(st2[12:15].T, d[p + 'angles_after'], TOL.ANGLE_FLOOR, what='azimuth commands vs reference')
+    TOL.assert_close(st2[6:9].T, d[p + 'ref_after'], 1.0, what='ref after vs reference')
+    # held plant: pose and velocity untouched, bit for bit
+    assert np.array_equal(st2[0:6], st[0:6])
+    assert (ctr2.cpu().numpy()[0] == 1).all()
+
+
+@pytest.mark.parametrize('mode,ext', list(mode_tag_cases()))
+def test_reference_golden_sequences_through_kernel(mode, ext):
+    """reset(**init) + 10 steps of the reference with a scripted plant: previous-thrust lag (Q2),
+    new_ref one step late (Q4), reset observation."""
+    torch = torch_()
+    d = np.load(os.path.join(G, 'env_%s.npz' % mode))
+    p = 'seq_%s_' % ('ext' if ext else 'base')
+    A = d[p + 'action'].astype(np.float32)
+    S_, T = A.shape[:2]
+    od = 9 if ext else 6
+    env, _ = H.make_pair(mode, S_, ext=ext, hold_plant=True, time_limit=False)
+    obs0 = env.reset(init=H.to_dev(d[p + 'init'].T.astype(np.float32)), new_ref=H.to_dev(np.zeros((3, S_), np.float32)))
+    TOL.assert_close(obs0.cpu().numpy(), d[p + 'obs0'], TOL.OBS_FLOOR[:od], what='reset obs vs reference')
+    t_ref = int(d[p + 'new_ref_step'][0])
+    for t in range(T):
+        st, _ = env.get_state()
+        st[0:3] = H.to_dev(d[p + 'eta'][:, t].T.astype(np.float32))      # the scripted plant's output
+        st[3:6] = H.to_dev(d[p + 'nu'][:, t].T.astype(np.float32))
+        env.set_state(st, None)
+        nr = H.to_dev(d[p + 'new_ref'].T.astype(np.float32)) if t == t_ref else None
+        obs, rew, done, _ = env.step(H.to_dev(A[:, t]), new_ref=nr)
+        TOL.assert_close(obs.cpu().numpy(), d[p + 'obs'][:, t], TOL.OBS_FLOOR[:od], what='obs t=%d' % t)
+        TOL.assert_close(rew.cpu().numpy(), d[p + 'reward'][:, t], TOL.REWARD_FLOOR, what='reward t=%d' % t)
+        assert np.array_equal(done.cpu().numpy() & 1, d[p + 'done'][:, t])
+
+
+def test_force_map_vs_reference_fixture():
+    """SupervisedTau.py:42-83 golden (2016 constants, asymmetric bow thruster)."""
+    import ml4ca_amd
+    torch_()
+    d = np.load(os.path.join(G, 'forcemap.npz'))
+    perm = [2, 0, 1]   # reference order port, star, bow -> env order bow, port, star
+    v = ml4ca_amd.default_vessel()
+    v[12:15] = d['K_fwd'][perm]
+    v[15:18] = d['K_rev'][perm]
+    v[18:21] = d['lx'][perm]
+    v[21:24] = d['ly'][perm]
+    tau = ml4ca_amd.thrust_map(H.to_dev(d['u'][:, perm].T.astype(np.float32)),
+                               H.to_dev(d['alpha'][:, perm].T.astype(np.float32)), params=v)
+    TOL.assert_close(tau.cpu().numpy().T, d['tau'], TOL.TAU_FLOOR, what='tau vs reference')
+
+
+# --------------------------------------------------------------------------------------------
+# (b) full step (with the build-owned plant) against the fp32 oracle
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('mode,ext', list(mode_tag_cases()))
+@pytest.mark.parametrize('layout', ['aos', 'soa'])
+def test_step_matches_oracle(mode, ext, layout):
+    n = 4096 + 37          # ragged tail: last workgroup partly empty
+    rng = np.random.RandomState(17)
+    env, orc = H.make_pair(mode, n, ext=ext, layout=layout)
+    st = H.random_state(rng, n)
+    ctr = np.zeros((2, n), np.int32)
+    ctr[0] = rng.randint(0, 390, size=n)
+    act = H.random_actions(rng, n, orc.act_dim)
+    new_ref = rng.uniform(-4, 4, size=(3, n)).astype(np.float32)
+    g, o = step_both(env, orc, st, ctr, act, new_ref=new_ref)
+    compare(g, o, orc.obs_dim, env.real_ss_bounds)
+    assert 0.02 < (g['done'] & 1).mean() < 0.98     # both outcomes exercised
+
+
+@pytest.mark.parametrize('n', [1, 63, 64, 65, 255, 256, 257, 1000])
+def test_ragged_sizes(n):
+    rng = np.random.RandomState(n)
+    env, orc = H.make_pair('final_cont', n)
+    st = H.random_state(rng, n, spread=0.5)
+    g, o = step_both(env, orc, st, np.zeros((2, n), np.int32), H.random_actions(rng, n, 7))
+    compare(g, o, 9, env.real_ss_bounds)
+
+
+def test_time_limit_and_fault_bits():
+    n = 512
+    rng = np.random.RandomState(3)
+    env, orc = H.make_pair('final_cont', n)
+    st = H.random_state(rng, n, spread=0.2)
+    ctr = np.zeros((2, n), np.int32)
+    ctr[0, :100] = env.max_ep_len - 1          # these hit the time limit on this step (ppo.py:304)
+    st[0, 200] = np.nan                        # poisoned env
+    st[3, 201] = np.inf
+    g, o = step_both(env, orc, st, ctr, H.random_actions(rng, n, 7))
+    assert (g['done'][:100] & 2).all() and not (g['done'][100:] & 2).any()
+    assert g['done'][200] & 4 and g['done'][201] & 4 and (g['done'][[200, 201]] & 1).all()
+    assert np.array_equal(g['done'], o['done'])
+    ok = np.ones(n, bool)
+    ok[[200, 201]] = False
+    TOL.assert_close(g['obs'][ok], o['obs'][ok], TOL.OBS_FLOOR, what='obs')
+
+
+def test_wrap_mode_radians_and_terminate_off():
+    n = 1024
+    rng = np.random.RandomState(5)
+    env, orc = H.make_pair('final_cont', n, wrap_mode='radians', terminate=False)
+    st = H.random_state(rng, n)
+    st[2] = rng.uniform(-7, 7, size=n)          # |psi| > pi
+    st[8] = rng.uniform(-3, 3, size=n)
+    g, o = step_both(env, orc, st, np.zeros((2, n), np.int32), H.random_actions(rng, n, 7))
+    # near the +-pi seam the wrapped yaw error may legitimately differ by 2 pi between precisions
+    d = np.abs(g['obs'][:, 2] - o['obs'][:, 2])
+    seam = d > 6.0
+    assert seam.mean() < 0.01
+    TOL.assert_close(g['obs'][~seam], o['obs'][~seam], TOL.OBS_FLOOR, what='obs (radians wrap)')
+    assert (np.abs(g['obs'][:, 2]) <= np.pi + 1e-5).all()
+    assert not g['done'].any()
+
+
+def test_constant_current_matches_oracle():
+    """Config 5's disturbance: V_c = 0.2 m/s, beta_c = 135 deg (results/all_plots/current_box_test/plot_pos.py:78)."""
+    n = 2048
+    rng = np.random.RandomState(8)
+    env, orc = H.make_pair('final_cont', n, current=True)
+    vc = (0.2 + 0.05 * rng.normal(size=n)).astype(np.float32)
+    beta = (np.deg2rad(135) + 0.2 * rng.normal(size=n)).astype(np.float32)
+    env.set_current(H.to_dev(vc), H.to_dev(beta))
+    st = H.random_state(rng, n, spread=0.5)
+    g, o = step_both(env, orc, st, np.zeros((2, n), np.int32), H.random_actions(rng, n, 7),
+                     current=np.stack([vc, beta]))
+    compare(g, o, 9, env.real_ss_bounds)
+    # free drift: zero thrust from rest ends up moving with the current
+    env2, _ = H.make_pair('final_cont', 4, current=True, terminate=False, time_limit=False)
+    import torch
+    env2.set_current(torch.full((4,), 0.2, device=env2.device), torch.full((4,), float(np.deg2rad(135)), device=env2.device))
+    env2.reset(init=torch.zeros((6, 4), device=env2.device))
+    a = torch.zeros((4, 7), device=env2.device)
+    a[:, 4] = 1.0
+    a[:, 6] = 1.0
+    for _ in range(600):
+        env2.step(a)
+    s, _ = env2.get_state()
+    s = s.cpu().numpy()[:, 0]
+    vN = np.cos(s[2]) * s[3] - np.sin(s[2]) * s[4]
+    vE = np.sin(s[2]) * s[3] + np.cos(s[2]) * s[4]
+    assert abs(np.hypot(vN, vE) - 0.2) < 0.02 and abs(np.arctan2(vE, vN) - np.deg2rad(135)) < 0.15
+
+
+def test_vessel_classes_staged_in_lds():
+    """Per-class 3x3 mass / damping / thruster blocks (LDS table path) against per-class oracle runs."""
+    import ml4ca_amd
+    n, ncls = 3000, 5
+    rng = np.random.RandomState(21)
+    base = ml4ca_amd.default_vessel()
+    tab = np.stack([base * (1.0 + 0.15 * rng.uniform(-1, 1, size=base.shape)).astype(np.float32) for _ in range(ncls)])
+    tab[:, 24:] = 0
+    env, _ = H.make_pair('final_cont', n, vessel_params=tab)
+    cls = rng.randint(0, ncls, size=n).astype(np.int32)
+    env.set_vessel_class(H.to_dev(cls))
+    st = H.random_state(rng, n, spread=0.5)
+    ctr = np.zeros((2, n), np.int32)
+    act = H.random_actions(rng, n, 7)
+    torch = torch_()
+    env.set_state(H.to_dev(st), H.to_dev(ctr))
+    obs, rew, done, _ = env.step(H.to_dev(act))
+    st2, _ = env.get_state()
+    torch.cuda.synchronize()
+    obs, rew, st2 = obs.cpu().numpy(), rew.cpu().numpy(), st2.cpu().numpy()
+    for c in range(ncls):
+        idx = np.nonzero(cls == c)[0]
+        orc = O.Oracle(O.make_config(max_ep_len=400), np.float32, vessel=tab[c])
+        ost, octr = np.ascontiguousarray(st[:, idx]), np.ascontiguousarray(ctr[:, idx])
+        oo, orw, _ = orc.step(ost, octr, act[idx])
+        TOL.assert_close(obs[idx], oo, TOL.OBS_FLOOR, what='obs class %d' % c)
+        TOL.assert_close(rew[idx], orw, TOL.REWARD_FLOOR, what='reward class %d' % c)
+        TOL.assert_close(st2[0:3, idx].T, ost[0:3].T, TOL.ETA_FLOOR, what='eta class %d' % c)
+    # classes really differ
+    o0 = O.Oracle(O.make_config(max_ep_len=400), np.float32, vessel=tab[0])
+    ost = st.copy()
+    oo, _, _ = o0.step(ost, ctr.copy(), act)
+    assert np.abs(oo[cls != 0] - obs[cls != 0]).max() > 1e-3
+
+
+def test_bf16_observations():
+    n = 1024 + 3
+    rng = np.random.RandomState(4)
+    torch = torch_()
+    e32, _ = H.make_pair('final_cont', n)
+    e16, _ = H.make_pair('final_cont', n, obs_dtype='bfloat16')
+    st = H.random_state(rng, n)
+    act = H.to_dev(H.random_actions(rng, n, 7))
+    for e in (e32, e16):
+        e.set_state(H.to_dev(st), H.to_dev(np.zeros((2, n), np.int32)))
+    o32, r32, d32, _ = e32.step(act)
+    o16, r16, d16, _ = e16.step(act)
+    assert o16.dtype == torch.bfloat16
+    assert torch.equal(o32.to(torch.bfloat16), o16)          # round-to-nearest-even of the fp32 observation
+    assert torch.equal(r32, r16) and torch.equal(d32, d16)
+
+
+# --------------------------------------------------------------------------------------------
+# reset
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('mode', ALL_MODES)
+def test_reset_sampler_bit_exact_and_masked(mode):
+    n = 5000
+    torch = torch_()
+    ext = mode != 'simple'
+    env, orc = H.make_pair(mode, n, ext=ext, seed=0xDEADBEEFCAFE, env_id_base=123456789012)
+    obs = env.reset()
+    st, ctr = env.get_state()
+    ost, octr = orc.new_state(n)
+    oobs = orc.reset(ost, octr)
+    st, ctr = st.cpu().numpy(), ctr.cpu().numpy()
+    assert np.array_equal(st, ost), 'Philox reset sample must be bit-exact'
+    assert np.array_equal(ctr, octr) and (ctr[1] == 1).all()
+    TOL.assert_close(obs.cpu().numpy(), oobs, TOL.OBS_FLOOR[:orc.obs_dim], what='reset obs')
+    lim = 0.8 * np.array(env.real_ss_bounds) * np.array([1, 1, 1, 0.3, 0.3, 0.3])
+    assert (np.abs(st[0:6]) <= lim[:, None] * (1 + 1e-6)).all()
+    # masked reset with explicit init and new setpoints touches only the selected envs
+    rng = np.random.RandomState(2)
+    mask = (rng.uniform(size=n) < 0.3).astype(np.uint8)
+    init = rng.uniform(-1, 1, size=(6, n)).astype(np.float32)
+    ref = rng.uniform(-2, 2, size=(3, n)).astype(np.float32)
+    obs2 = env.reset(mask=H.to_dev(mask), init=H.to_dev(init), new_ref=H.to_dev(ref))
+    oobs2 = orc.reset(ost, octr, mask=mask, init=init, ref=ref)
+    st2, ctr2 = env.get_state()
+    assert np.array_equal(st2.cpu().numpy(), ost) and np.array_equal(ctr2.cpu().numpy(), octr)
+    TOL.assert_close(obs2.cpu().numpy(), oobs2, TOL.OBS_FLOOR[:orc.obs_dim], what='masked reset obs')
+    # second sampled reset draws a fresh episode
+    env.reset()
+    orc.reset(ost, octr)
+    st3, ctr3 = env.get_state()
+    assert np.array_equal(st3.cpu().numpy(), ost) and (ctr3.cpu().numpy()[1] == 2).all()
+    assert not np.array_equal(st3.cpu().numpy()[0:6], st[0:6])
+    # curriculum hook: fraction (ppo.py:286,319)
+    env.reset(fraction=0.25)
+    st4, _ = env.get_state()
+    assert (np.abs(st4.cpu().numpy()[0:6]) <= (lim / 0.8 * 0.25)[:, None] * (1 + 1e-6)).all()
+
+
+def _pre_reset_obs(obs, final_obs, done):
+    """observation the termination test saw: final_obs for envs that auto-reset, obs otherwise"""
+    out = obs.copy()
+    fin = done != 0
+    out[fin] = final_obs[fin]
+    return out
+
+
+def test_rollout_with_auto_reset_tracks_oracle():
+    """60 steps, auto-reset on: episode boundaries, Philox re-draws and final_obs agree with the oracle."""
+    n, T = 2048, 60
+    torch = torch_()
+    rng = np.random.RandomState(9)
+    env, orc = H.make_pair('final_cont', n, auto_reset=True, max_ep_len=40, seed=77)   # T_max = 20 steps
+    assert env.max_ep_len == 20
+    env.reset()
+    ost, octr = orc.new_state(n)
+    orc.reset(ost, octr)
+    fobs = torch.zeros(env.obs_shape, device=env.device)
+    n_done = 0
+    for t in range(T):
+        act = H.random_actions(rng, n, 7, scale=1.0)
+        # re-synchronise the oracle to the GPU state each step: parity is per (s, a) pair (north star)
+        st, ctr = env.get_state()
+        ost, octr = st.cpu().numpy().copy(), ctr.cpu().numpy().copy()
+        obs, rew, done, _ = env.step(H.to_dev(act), final_obs=fobs)
+        oobs, orew, odone, ofobs = orc.step(ost, octr, act, want_final_obs=True)
+        done = done.cpu().numpy()
+        # a termination decided by a bound crossed within rounding may differ: require none here
+        same = done_agrees(done, odone, _pre_reset_obs(oobs, ofobs, odone), env.real_ss_bounds)
+        TOL.assert_close(obs.cpu().numpy()[same], oobs[same], TOL.OBS_FLOOR, what='obs t=%d' % t)
+        TOL.assert_close(rew.cpu().numpy(), orew, TOL.REWARD_FLOOR, what='rew t=%d' % t)
+        fin = (done != 0) & same
+        n_done += fin.sum()
+        if fin.any():
+            TOL.assert_close(fobs.cpu().numpy()[fin], ofobs[fin], TOL.OBS_FLOOR, what='final_obs t=%d' % t)
+            st2, ctr2 = env.get_state()
+            st2, ctr2 = st2.cpu().numpy(), ctr2.cpu().numpy()
+            assert np.array_equal(st2[:, fin], ost[:, fin]), 'reset states are Philox draws: bit-exact'
+            assert np.array_equal(ctr2[:, same], octr[:, same])
+            assert (ctr2[0, fin] == 0).all()
+    assert n_done > 3 * n      # every env went through >= 3 episodes (time limit 20)
+
+
+# --------------------------------------------------------------------------------------------
+# properties at full size (BASELINE.json: 65 536 envs; 8 x 32 768 shards)
+# --------------------------------------------------------------------------------------------
+def test_full_size_determinism_permutation_and_shard_invariance():
+    n = 65536
+    torch = torch_()
+    rng = np.random.RandomState(1)
+    st = H.to_dev(H.random_state(rng, n))
+    ctr = H.to_dev(np.zeros((2, n), np.int32))
+    act = H.to_dev(H.random_actions(rng, n, 7))
+    env, _ = H.make_pair('final_cont', n, auto_reset=True, seed=5)
+
+    def run(e, s, c, a, steps=3):
+        e.set_state(s.contiguous(), c.contiguous())
+        outs = []
+        for _ in range(steps):
+            o, r, d, _ = e.step(a)
+            outs.append((o.clone(), r.clone(), d.clone()))
+        s2, c2 = e.get_state()
+        return outs, s2, c2
+
+    a1, s1, c1 = run(env, st, ctr, act)
+    a2, s2, c2 = run(env, st, ctr, act)
+    for (o, r, d), (o_, r_, d_) in zip(a1, a2):
+        assert torch.equal(o, o_) and torch.equal(r, r_) and torch.equal(d, d_), 'not deterministic'
+    assert torch.equal(s1, s2) and torch.equal(c1, c2)
+    assert sum(int(d.ne(0).sum()) for _, _, d in a1) > 100      # auto-reset really happened
+
+    # shard invariance (config 4: 8 x 32768): two half-size handles keyed by env_id_base reproduce the
+    # full batch bit for bit, including the Philox re-draws of finished envs
+    half = n // 2
+    for k in range(2):
+        sl = slice(k * half, (k + 1) * half)
+        e, _ = H.make_pair('final_cont', half, auto_reset=True, seed=5, env_id_base=k * half)
+        ak, sk, ck = run(e, st[:, sl], ctr[:, sl], act[sl].contiguous())
+        for (o, r, d), (o_, r_, d_) in zip(a1, ak):
+            assert torch.equal(o[sl], o_) and torch.equal(r[sl], r_) and torch.equal(d[sl], d_)
+        assert torch.equal(s1[:, sl], sk) and torch.equal(c1[:, sl], ck)
+
+    # permutation equivariance (no auto-reset: the re-draw is keyed by env id)
+    env2, _ = H.make_pair('final_cont', n)
+    perm = torch.randperm(n, device=st.device)
+    b1, t1, _ = run(env2, st, ctr, act, steps=2)
+    b2, t2, _ = run(env2, st[:, perm], ctr[:, perm], act[perm].contiguous(), steps=2)
+    for (o, r, d), (o_, r_, d_) in zip(b1, b2):
+        assert torch.equal(o[perm], o_) and torch.equal(r[perm], r_) and torch.equal(d[perm], d_)
+    assert torch.equal(t1[:, perm], t2)
+
+
+def test_full_size_physical_properties():
+    """65 536 envs: fixed point, reward maximum, port/starboard mirror symmetry, thrust-speed pins."""
+    n = 65536
+    torch = torch_()
+    env, _ = H.make_pair('final_cont', n, terminate=False, time_limit=False)
+    dev = env.device
+    # at rest on the setpoint with zero thrust nothing moves and the reward is its maximum 3.5 (plotters.py:35)
+    env.reset(init=torch.zeros((6, n), device=dev))
+    a0 = torch.zeros((n, 7), device=dev)
+    a0[:, 4] = 1.0
+    a0[:, 6] = 1.0          # azimuth heads (sin, cos) = (0, 1) -> 0 rad = the reset default
+    obs, rew, done, _ = env.step(a0)
+    assert float(obs.abs().max()) == 0.0 and float((rew - 3.5).abs().max()) < 1e-6 and int(done.sum()) == 0
+    # mirror symmetry about the centre line: (E, psi, v, r) -> -(...), port <-> starboard with negated azimuth
+    rng = np.random.RandomState(12)
+    st = H.random_state(rng, n, spread=0.6)
+    st[6:9] = 0
+    st[12] = np.pi / 2
+    act = H.random_actions(rng, n, 7)
+    m = st.copy()
+    m[[1, 2, 4, 5]] *= -1
+    m[9] = -st[9]           # the bow thruster stays at +90 deg: its mirror image is the negated thrust
+    m[10], m[11] = st[11], st[10]
+    m[13], m[14] = -st[14], -st[13]
+    am = act.copy()
+    am[:, 0] = -act[:, 0]
+    am[:, 1], am[:, 2] = act[:, 2], act[:, 1]
+    am[:, 3], am[:, 4], am[:, 5], am[:, 6] = -act[:, 5], act[:, 6], -act[:, 3], act[:, 4]
+    z = H.to_dev(np.zeros((2, n), np.int32))
+    env.set_state(H.to_dev(st), z)
+    o1, r1, _, _ = env.step(H.to_dev(act))
+    o1, r1 = o1.clone(), r1.clone()
+    env.set_state(H.to_dev(m), z)
+    o2, r2, _, _ = env.step(H.to_dev(am))
+    sign = torch.tensor([1, -1, -1, 1, -1, -1, -1, 1, 1], device=dev, dtype=torch.float32)
+    o2m = o2 * sign
+    o2m[:, 7], o2m[:, 8] = o2[:, 8].clone(), o2[:, 7].clone()
+    assert float((o1 - o2m).abs().max()) < 2e-5
+    assert float((r1 - r2).abs().max()) < 2e-5
+    # soft pins of the plant (customEnv.py:13-14, no thrust loss): ~2.2 m/s ahead, ~0.6 rad/s yaw at full thrust
+    env.reset(init=torch.zeros((6, n), device=dev))
+    full = a0.clone()
+    full[:, 1:3] = 1.0
+    for _ in range(500):
+        env.step(full)
+    s, _ = env.get_state()
+    u = s[3]
+    assert float((u - u[0]).abs().max()) == 0.0 and 2.0 < float(u[0]) < 2.4
+
+
+# --------------------------------------------------------------------------------------------
+# single-env adapter = the reference's Gym API
+# --------------------------------------------------------------------------------------------
+def test_single_env_adapter_runs_a_spinup_style_loop():
+    import ml4ca_amd
+    torch_()
+    env = ml4ca_amd.ENVIRONMENTS['final'](None, extended_state=True, cont_ang=True)
+    assert env.name == 'revoltfinal' and env.dt == 0.2 and env.n_steps == 20 and env.max_ep_len == 400
+    assert env.observation_space.shape == (9,) and env.action_space.shape == (7,)
+    np.random.seed(0)
+    o = env.reset(fraction=0.8)
+    assert o.shape == (9,) and o.dtype == np.float64 and np.all(o[6:] == 0)
+    orc = O.Oracle(O.make_config(), np.float32)
+    ep_ret, n_steps = 0.0, 0
+    for t in range(50):
+        a = np.random.normal(0, 0.6, size=7)
+        st, ctr = env._benv.get_state()
+        ost, octr = st.cpu().numpy().copy(), ctr.cpu().numpy().copy()
+        o2, r, d, info = env.step(a)
+        oo, orw, od_ = orc.step(ost, octr, a.astype(np.float32)[None, :])
+        assert isinstance(r, float) and isinstance(d, bool) and info == {'None': 0}
+        TOL.assert_close(o2, oo[0], TOL.OBS_FLOOR, what='adapter obs')
+        TOL.assert_close(r, orw[0], TOL.REWARD_FLOOR, what='adapter reward')
+        assert d == bool(od_[0] & 1)
+        assert np.allclose(env.state_extended(), o2, atol=1e-5)
+        ep_ret += r
+        n_steps += 1
+        if d or n_steps == env.max_ep_len:
+            o = env.reset()
+            ep_ret, n_steps = 0.0, 0
+    # evaluation-harness surface (test_policy.py:114-178)
+    t_env = ml4ca_amd.RevoltFinal(None, testing=True, extended_state=True, cont_ang=True)
+    o = t_env.reset(fixed_point=2)
+    assert np.allclose(t_env.EF.get_NED_pos(), [0.0, 5.0, -15 * np.pi / 180], atol=1e-6)
+    assert t_env.EF.get_NED_ref() == [0.0, 0.0, 0.0]
+    o, r, d, _ = t_env.step(np.zeros(7), new_ref=[5.0, 0.0, 0.0])
+    assert np.allclose(t_env.EF.get_NED_ref(), [5.0, 0.0, 0.0])
+    assert len(t_env.scale_and_clip(np.ones(5) * 2)) == 5
+    rt = ml4ca_amd.RevoltFinal(None, testing=True, realtime=True)
+    assert rt.n_steps == 1 and abs(rt.dt - 0.01) < 1e-12 and rt.max_ep_len == 8000
+
+
+def test_gae_kernel_vs_reference_fixture_and_oracle():
+    """ppo.py:65-105 golden + oracle on a [T][n] batch with random path ends."""
+    from ml4ca_amd import rollout
+    torch = torch_()
+    d = np.load(os.path.join(G, 'gae.npz'))
+    T = len(d['gae_rew'])
+    end = np.zeros((T, 1), np.uint8)
+    boot = np.zeros((T, 1), np.float32)
+    for e, lv in zip(d['gae_path_ends'], d['gae_last_vals']):
+        end[e - 1, 0] = 1
+        boot[e - 1, 0] = lv
+    g, l = [float(x) for x in d['gae_gamma_lam']]
+    adv, ret = rollout.gae(H.to_dev(d['gae_rew'][:, None].astype(np.float32)), H.to_dev(d['gae_val'][:, None].astype(np.float32)),
+                           end=H.to_dev(end), boot=H.to_dev(boot), gamma=g, lam=l)
+    assert np.allclose(adv.cpu().numpy()[:, 0], d['gae_adv_raw'], rtol=1e-5, atol=1e-5)
+    assert np.allclose(ret.cpu().numpy()[:, 0], d['gae_ret'], rtol=1e-5, atol=1e-5)
+    norm, mean, std = rollout.normalize_advantages(H.to_dev(d['gae_adv_raw'].astype(np.float32)))
+    assert np.allclose([float(mean), float(std)], d['gae_mean_std'], rtol=1e-5)
+    assert np.allclose(norm.cpu().numpy(), d['gae_adv_norm'], rtol=1e-4, atol=1e-5)
+    # batched, random ends, against the oracle
+    rng = np.random.RandomState(6)
+    T, n = 400, 3001
+    rew = rng.normal(1, 1, size=(T, n)).astype(np.float32)
+    val = rng.normal(0, 1, size=(T, n)).astype(np.float32)
+    end = (rng.uniform(size=(T, n)) < 0.01).astype(np.uint8)
+    last = rng.normal(size=n).astype(np.float32)
+    orc = O.Oracle(O.make_config(), np.float32)
+    oadv, oret = orc.gae(rew, val, end=end, last_val=last)
+    adv, ret = rollout.gae(H.to_dev(rew), H.to_dev(val), end=H.to_dev(end), last_val=H.to_dev(last))
+    assert np.allclose(adv.cpu().numpy(), oadv, rtol=1e-5, atol=1e-5)
+    assert np.allclose(ret.cpu().numpy(), oret, rtol=1e-5, atol=1e-5)

@@ -91,6 +91,7 @@ extern "C" int dpenv_default_vessel(float* p)
     p[DPENV_P_YV] = 30.0f; p[DPENV_P_YVV] = 58.8f;
     p[DPENV_P_YR] = 2.0f;  p[DPENV_P_NV] = 2.0f;
     p[DPENV_P_NR] = 50.0f; p[DPENV_P_NRR] = 71.1f;
+    p[DPENV_P_NUV] = -60.0f; p[DPENV_P_YUR] = 0.0f;
     p[DPENV_P_KF_BOW] = 0.0009f; p[DPENV_P_KF_PORT] = 0.00205f; p[DPENV_P_KF_STAR] = 0.00205f;
     p[DPENV_P_KR_BOW] = 0.0009f; p[DPENV_P_KR_PORT] = 0.00205f; p[DPENV_P_KR_STAR] = 0.00205f;
     p[DPENV_P_LX_BOW] = 1.08f; p[DPENV_P_LX_PORT] = -1.12f; p[DPENV_P_LX_STAR] = -1.12f;
@@ -147,6 +148,7 @@ static int derive_vessel(const float* p, VesselDev* d, std::string* why)
     d->p[VD_XU] = p[DPENV_P_XU]; d->p[VD_XUU] = p[DPENV_P_XUU]; d->p[VD_YV] = p[DPENV_P_YV];
     d->p[VD_YVV] = p[DPENV_P_YVV]; d->p[VD_YR] = p[DPENV_P_YR]; d->p[VD_NV] = p[DPENV_P_NV];
     d->p[VD_NR] = p[DPENV_P_NR]; d->p[VD_NRR] = p[DPENV_P_NRR];
+    d->p[VD_NUV] = p[DPENV_P_NUV]; d->p[VD_YUR] = p[DPENV_P_YUR];
     for (int i = 0; i < 3; ++i) {
         d->p[VD_KF + i] = p[DPENV_P_KF_BOW + i]; d->p[VD_KR + i] = p[DPENV_P_KR_BOW + i];
         d->p[VD_LX + i] = p[DPENV_P_LX_BOW + i]; d->p[VD_LY + i] = p[DPENV_P_LY_BOW + i];

@@ -24,7 +24,7 @@ enum { DONE_TERMINAL = 1u, DONE_TIMELIMIT = 2u, DONE_FAULT = 4u };
 // derived per-class parameter block (host precomputes the mass-matrix inverse)
 enum {
     VD_M11 = 0, VD_M22, VD_M23, VD_INV11, VD_I22, VD_I23, VD_I33,
-    VD_XU, VD_XUU, VD_YV, VD_YVV, VD_YR, VD_NV, VD_NR, VD_NRR,
+    VD_XU, VD_XUU, VD_YV, VD_YVV, VD_YR, VD_NV, VD_NR, VD_NRR, VD_NUV, VD_YUR,
     VD_KF, VD_KR = VD_KF + 3, VD_LX = VD_KR + 3, VD_LY = VD_LX + 3,
     VD_COUNT = VD_LY + 3
 };

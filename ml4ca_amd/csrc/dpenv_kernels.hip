@@ -92,7 +92,7 @@ __device__ __forceinline__ float clipf(float v, float b) { return fminf(fmaxf(v,
 
 struct Vessel {
     float m11, m22, m23, inv11, i22, i23, i33;
-    float Xu, Xuu, Yv, Yvv, Yr, Nv, Nr, Nrr;
+    float Xu, Xuu, Yv, Yvv, Yr, Nv, Nr, Nrr, Nuv, Yur;
     float Kf[3], Kr[3], lx[3], ly[3];
 };
 
@@ -103,6 +103,7 @@ __device__ __forceinline__ Vessel vessel_from_args(const VesselDev& d)
     v.inv11 = d.p[VD_INV11]; v.i22 = d.p[VD_I22]; v.i23 = d.p[VD_I23]; v.i33 = d.p[VD_I33];
     v.Xu = d.p[VD_XU]; v.Xuu = d.p[VD_XUU]; v.Yv = d.p[VD_YV]; v.Yvv = d.p[VD_YVV];
     v.Yr = d.p[VD_YR]; v.Nv = d.p[VD_NV]; v.Nr = d.p[VD_NR]; v.Nrr = d.p[VD_NRR];
+    v.Nuv = d.p[VD_NUV]; v.Yur = d.p[VD_YUR];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         v.Kf[i] = d.p[VD_KF + i]; v.Kr[i] = d.p[VD_KR + i]; v.lx[i] = d.p[VD_LX + i]; v.ly[i] = d.p[VD_LY + i];
@@ -121,6 +122,7 @@ __device__ __forceinline__ Vessel vessel_from_lds(const float* tab, int ncls, in
     v.Xu = tab[VD_XU * ncls + cls]; v.Xuu = tab[VD_XUU * ncls + cls]; v.Yv = tab[VD_YV * ncls + cls];
     v.Yvv = tab[VD_YVV * ncls + cls]; v.Yr = tab[VD_YR * ncls + cls]; v.Nv = tab[VD_NV * ncls + cls];
     v.Nr = tab[VD_NR * ncls + cls]; v.Nrr = tab[VD_NRR * ncls + cls];
+    v.Nuv = tab[VD_NUV * ncls + cls]; v.Yur = tab[VD_YUR * ncls + cls];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         v.Kf[i] = tab[(VD_KF + i) * ncls + cls]; v.Kr[i] = tab[(VD_KR + i) * ncls + cls];
@@ -330,8 +332,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const StepArgs a)
         const float c13 = -(ve.m22 * v + ve.m23 * r);
         const float c23 = ve.m11 * u;
         const float fx = tx - c13 * r - (ve.Xu + ve.Xuu * fabsf(u)) * u;
-        const float fy = ty - c23 * r - ((ve.Yv + ve.Yvv * fabsf(v)) * v + ve.Yr * r);
-        const float fn = tn + (c13 * u + c23 * v) - (ve.Nv * v + (ve.Nr + ve.Nrr * fabsf(r)) * r);
+        const float fy = ty - c23 * r - ((ve.Yv + ve.Yvv * fabsf(v)) * v + (ve.Yr + ve.Yur * u) * r);
+        const float fn = tn + (c13 * u + c23 * v) - ((ve.Nv + ve.Nuv * u) * v + (ve.Nr + ve.Nrr * fabsf(r)) * r);
         u += h * (fx * ve.inv11);
         v += h * (ve.i22 * fy + ve.i23 * fn);
         r += h * (ve.i23 * fy + ve.i33 * fn);

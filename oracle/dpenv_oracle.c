@@ -7,6 +7,21 @@
 #include <math.h>
 #include <stdint.h>
 #include "dpenv_oracle.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* threads used by the batched step loop (cpu_baseline leg of bench.py); returns the count in force */
+int dpo_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
 
 /* Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11):
  * the build-owned counter-based generator behind the reset sampler (not in the reference,

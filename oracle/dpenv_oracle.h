@@ -62,6 +62,7 @@ enum {
     DPO_P_KR_BOW, DPO_P_KR_PORT, DPO_P_KR_STAR,
     DPO_P_LX_BOW, DPO_P_LX_PORT, DPO_P_LX_STAR,
     DPO_P_LY_BOW, DPO_P_LY_PORT, DPO_P_LY_STAR,
+    DPO_P_NUV, DPO_P_YUR,                          /* lift-type cross-flow terms N_uv u v, Y_ur u r */
     DPO_NPARAM = 32
 };
 
@@ -113,6 +114,7 @@ typedef struct dpo_config {
 DPO_DECL(f64, double)
 DPO_DECL(f32, float)
 
+int dpo_set_threads(int n);
 void dpo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
 #ifdef __cplusplus

@@ -68,6 +68,7 @@ void FN(dpo_default_vessel)(REAL* p)
     p[DPO_P_YV] = R(30.0); p[DPO_P_YVV] = R(58.8);
     p[DPO_P_YR] = R(2.0);  p[DPO_P_NV] = R(2.0);
     p[DPO_P_NR] = R(50.0); p[DPO_P_NRR] = R(71.1);
+    p[DPO_P_NUV] = R(-60.0); p[DPO_P_YUR] = R(0.0);
     p[DPO_P_KF_BOW] = R(0.0009); p[DPO_P_KF_PORT] = R(0.00205); p[DPO_P_KF_STAR] = R(0.00205);
     p[DPO_P_KR_BOW] = R(0.0009); p[DPO_P_KR_PORT] = R(0.00205); p[DPO_P_KR_STAR] = R(0.00205);
     p[DPO_P_LX_BOW] = R(1.08); p[DPO_P_LX_PORT] = R(-1.12); p[DPO_P_LX_STAR] = R(-1.12);
@@ -183,8 +184,8 @@ void FN(dpo_plant)(const dpo_config* c, const REAL* p, REAL eta[3], REAL nu[3], 
         REAL c13 = -(m22 * v + m23 * r);
         REAL c23 = m11 * u;
         REAL fx = tau[0] - c13 * r - (p[DPO_P_XU] + p[DPO_P_XUU] * M_FABS(u)) * u;
-        REAL fy = tau[1] - c23 * r - ((p[DPO_P_YV] + p[DPO_P_YVV] * M_FABS(v)) * v + p[DPO_P_YR] * r);
-        REAL fn = tau[2] + (c13 * u + c23 * v) - (p[DPO_P_NV] * v + (p[DPO_P_NR] + p[DPO_P_NRR] * M_FABS(r)) * r);
+        REAL fy = tau[1] - c23 * r - ((p[DPO_P_YV] + p[DPO_P_YVV] * M_FABS(v)) * v + (p[DPO_P_YR] + p[DPO_P_YUR] * u) * r);
+        REAL fn = tau[2] + (c13 * u + c23 * v) - ((p[DPO_P_NV] + p[DPO_P_NUV] * u) * v + (p[DPO_P_NR] + p[DPO_P_NRR] * M_FABS(r)) * r);
         u += h * (fx * inv11);
         v += h * (i22 * fy + i23 * fn);
         r += h * (i23 * fy + i33 * fn);
@@ -394,6 +395,8 @@ void FN(dpo_step)(const dpo_config* c, const REAL* vessel, int32_t n, REAL* stat
                   REAL* obs, REAL* rew, uint8_t* done, REAL* parts_out, REAL* final_obs)
 {
     const int ad = FN(dpo_act_dim)(c), od = FN(dpo_obs_dim)(c);
+    /* envs are independent (trainer.py:61-75: one simulator per env); threads only split the loop */
+#pragma omp parallel for schedule(static) if (n >= 4096)
     for (int32_t i = 0; i < n; ++i) {
         REAL eta[3], nu[3], ref[3], pt[3], ang_prev[3], ang_cur[3], thrust[3], parts[4];
         REAL* o = obs + (int64_t)i * od;

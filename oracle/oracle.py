@@ -163,6 +163,12 @@ class Oracle(object):
             out.append(fobs)
         return tuple(out)
 
+    def step_into(self, state, counters, action, obs, rew, done, new_ref=None):
+        """step() writing into caller-provided arrays: nothing but the C loop runs (used for CPU timing)."""
+        n = state.shape[1]
+        self._f('dpo_step')(C.byref(self.cfg), _p(self.vessel), C.c_int32(n), _p(state), _p(counters), _p(action),
+                            _p(new_ref), None, None, _p(obs), _p(rew), _p(done), None, None)
+
     def discount_cumsum(self, x, discount):
         x = self._a(x)
         y = np.zeros_like(x)
@@ -192,6 +198,11 @@ class Oracle(object):
         fn.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         fn(_p(a), a.size, _p(ms))
         return a, ms
+
+
+def set_threads(n):
+    """Threads of the batched CPU step loop (OpenMP over envs); returns the count in force."""
+    return int(lib().dpo_set_threads(int(n)))
 
 
 def philox(ctr, key):

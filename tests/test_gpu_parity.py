@@ -267,7 +267,7 @@ def test_vessel_classes_staged_in_lds():
     rng = np.random.RandomState(21)
     base = ml4ca_amd.default_vessel()
     tab = np.stack([base * (1.0 + 0.15 * rng.uniform(-1, 1, size=base.shape)).astype(np.float32) for _ in range(ncls)])
-    tab[:, 24:] = 0
+    tab[:, 26:] = 0
     env, _ = H.make_pair('final_cont', n, vessel_params=tab)
     cls = rng.randint(0, ncls, size=n).astype(np.int32)
     env.set_vessel_class(H.to_dev(cls))

@@ -44,6 +44,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='budget of the CPU baseline leg')
     ap.add_argument('--gather', type=int, default=-1, help='time the config-4 trajectory all-gather (default: on if gpus > 1)')
+    ap.add_argument('--hold-plant', action='store_true', help='diagnostic: skip the plant sub-steps (INVALID as a result)')
     ap.add_argument('--traffic-json', default=os.path.join(ROOT, 'profiles', 'traffic_latest.json'))
     return ap.parse_args()
 
@@ -53,7 +54,9 @@ def cpu_baseline(n_envs, budget_s):
     bounded sample of the same workload: n_envs envs x S steps, S sized to the time budget."""
     import numpy as np
     from oracle import oracle as O
-    threads = O.set_threads(os.cpu_count() or 1)
+    # a GPU box gives each GPU a 16-core CPU share; more threads than that only oversubscribes
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    threads = O.set_threads(min(avail, 16))
     orc = O.Oracle(O.make_config(terminate=0, max_ep_len=0), np.float32)
     rng = np.random.RandomState(0)
     st, ctr = orc.new_state(n_envs)
@@ -95,7 +98,8 @@ def main():
     import ml4ca_amd
     n = args.envs
     env = ml4ca_amd.BatchedRevoltEnv(n, variant='final', extended_state=True, cont_ang=True, device=dev,
-                                     terminate=False, time_limit=False, seed=1, env_id_base=rank * n)
+                                     terminate=False, time_limit=False, seed=1, env_id_base=rank * n,
+                                     hold_plant=args.hold_plant)
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
     # synthetic inputs, resident in HBM before the timed region
@@ -207,7 +211,7 @@ def main():
         except Exception:
             pass
         res = {
-            'metric': 'env-steps/sec at 65536 parallel envs', 'value': total_envs * K / wall, 'unit': 'env-steps/s',
+            'metric': 'env-steps/sec at 65536 parallel envs' + (' [DIAGNOSTIC hold_plant: INVALID]' if args.hold_plant else ''), 'value': total_envs * K / wall, 'unit': 'env-steps/s',
             'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': wall / K * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'BASELINE.json configs[2]: %d parallel envs per GPU, final/ext/cont_ang, 4-corner box '

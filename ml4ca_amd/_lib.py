@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libdpenv.so')
+# DPENV_LIB overrides the path (A/B builds of the kernel library during tuning); still no fallback of any kind
+LIB_PATH = os.environ.get('DPENV_LIB') or os.path.join(_HERE, 'lib', 'libdpenv.so')
 
 OK, EINVAL, ENODEV, ENOMEM, EHIP = 0, -1, -2, -3, -4
 FULL, SIMPLE, LIMITED, FINAL = 0, 1, 2, 3

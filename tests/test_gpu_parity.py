@@ -520,7 +520,9 @@ def test_single_env_adapter_runs_a_spinup_style_loop():
         TOL.assert_close(o2, oo[0], TOL.OBS_FLOOR, what='adapter obs')
         TOL.assert_close(r, orw[0], TOL.REWARD_FLOOR, what='adapter reward')
         assert d == bool(od_[0] & 1)
-        assert np.allclose(env.state_extended(), o2, atol=1e-5)
+        # like the reference, state_extended() called AFTER step() already carries the new thrust command (ENV:126,204)
+        se = env.state_extended()
+        assert np.allclose(se[:6], o2[:6], atol=1e-5) and np.allclose(se[6:], np.clip(a[:3], -1, 1), atol=1e-6)
         ep_ret += r
         n_steps += 1
         if d or n_steps == env.max_ep_len:

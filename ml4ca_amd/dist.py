@@ -1,0 +1,43 @@
+"""Multi-GPU plumbing: one process per GPU, envs sharded with no per-step communication.
+
+The reference's only parallelism is data-parallel env ownership per MPI rank (specific/trainer.py:61-75,
+ppo.py:226) with gradient all-reduce / parameter broadcast per optimiser step (spinup/utils/mpi_tf.py).
+Here envs never interact, so a rank owns a contiguous block of global env ids and steps it locally; the
+single exchange step is the all-gather of trajectory blocks at episode boundaries (BASELINE.json config 4),
+plus the two scalar all-reduces of the advantage statistics (rollout.normalize_advantages).
+Backend: "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
+"""
+
+
+def shard(total_envs, rank, world):
+    """Contiguous block of global env ids owned by `rank`: returns (n_local, env_id_base).
+    Remainder envs go to the first ranks.  Philox reset streams are keyed by the GLOBAL env id
+    (dpenv_config.env_id_base), so results do not depend on the rank count."""
+    if not (0 <= rank < world) or total_envs < world:
+        raise ValueError('bad shard request: total_envs=%d rank=%d world=%d' % (total_envs, rank, world))
+    base, rem = divmod(total_envs, world)
+    n_local = base + (1 if rank < rem else 0)
+    start = rank * base + min(rank, rem)
+    return n_local, start
+
+
+def gather_trajectories(block, group=None, out=None):
+    """All-gather of equally shaped per-rank trajectory blocks [T, n_local, F] -> [world, T, n_local, F]
+    (rank-major = global env order for contiguous shards).  One collective per episode, nothing per step."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return block.unsqueeze(0) if out is None else out.copy_(block.unsqueeze(0))
+    world = dist.get_world_size(group)
+    block = block.contiguous()
+    if out is None:
+        out = torch.empty((world,) + tuple(block.shape), dtype=block.dtype, device=block.device)
+    # concatenated-along-dim-0 view: the form every backend (RCCL and gloo) accepts
+    dist.all_gather_into_tensor(out.view((world * block.shape[0],) + tuple(block.shape[1:])), block, group=group)
+    return out
+
+
+def to_global_env_order(gathered):
+    """[world, T, n_local, F] -> [T, world * n_local, F]: env axis in global id order."""
+    w, T, n, F = gathered.shape
+    return gathered.permute(1, 0, 2, 3).reshape(T, w * n, F)

@@ -1,0 +1,141 @@
+"""CPU tests of host logic: config 1 (pseudo-inverse allocation), reset samplers, sharding, and the
+world_size-2 gloo rehearsal of the episode-boundary trajectory all-gather."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, 'tests', 'golden')
+
+
+def test_config1_pseudoinverse_allocation():
+    """BASELINE.json configs[0] as restated in SURVEY 8(d): B(alpha) K n|n| == tau to 1e-9 (float64)."""
+    from ml4ca_amd import allocation as AL
+    for alpha in ([0.0, 0.0, np.pi / 2], [0.3, -0.4, np.pi / 2]):
+        for tau in ([10.0, 5.0, 3.0], [0.0, 0.0, 0.0], [20.0, -10.0, 15.0]):
+            n, F = AL.pinv_allocate(tau, alpha)
+            back = AL.effectiveness(alpha) @ AL.percent_to_force(n)
+            assert np.allclose(back, tau, rtol=0, atol=1e-9)
+            assert np.allclose(AL.percent_to_force(n), F, rtol=0, atol=1e-12)
+    # the effectiveness matrix is the reference's (SupervisedTau.B fixture, reference order port, star, bow)
+    d = np.load(os.path.join(G, 'forcemap.npz'))
+    for i in range(0, len(d['alpha']), 17):
+        assert np.allclose(AL.effectiveness(d['alpha'][i]), d['B'][i], rtol=0, atol=1e-14)
+    assert np.allclose(AL.LX, d['lx']) and np.allclose(AL.LY, d['ly'])
+    # and the env-order force map of the oracle agrees with it
+    from oracle import oracle as O
+    orc = O.Oracle(O.make_config())
+    n, F = AL.pinv_allocate([10.0, 5.0, 3.0], [0.3, -0.4, np.pi / 2])
+    tau = orc.thrust_map(n[AL.ROS_TO_ENV], np.array([0.3, -0.4, np.pi / 2])[AL.ROS_TO_ENV])
+    assert np.allclose(tau, [10.0, 5.0, 3.0], atol=1e-9)
+    # saturation clips forces at the simulator's limits (qp_allocator.py:52)
+    n, F = AL.pinv_allocate([500.0, 0.0, 0.0], [0.0, 0.0, np.pi / 2], saturate=True)
+    assert np.all(np.abs(F) <= AL.F_MAX + 1e-12) and np.all(np.abs(n) <= 100.0 + 1e-9)
+
+
+def test_host_reset_samplers_match_reference_fixture():
+    from ml4ca_amd import simtools
+    d = np.load(os.path.join(G, 'env_final_cont.npz'))
+    got = np.array([simtools.get_fixed_pose_on_radius(n) for n in range(6)])
+    assert np.allclose(got, d['fixed_pose_on_radius'], rtol=0, atol=1e-15)
+    assert simtools.get_fixed_pose_on_radius(7) == simtools.get_fixed_pose_on_radius(1)   # wraps like the reference
+    np.random.seed(3)
+    rr = np.array([simtools.get_random_pose_on_radius() for _ in range(500)])
+    assert np.allclose(np.hypot(rr[:, 0], rr[:, 1]), 5.0) and np.abs(rr[:, 2]).max() <= 5 * np.pi / 180
+    b = d['real_ss_bounds']
+    tr = np.array([list(simtools.get_pose_on_state_space(b[0:3], 0.8)) + list(simtools.get_vel_on_state_space(b[3:], 0.24))
+                   for _ in range(3000)])
+    lim = np.array([0.8, 0.8, 0.8, 0.24, 0.24, 0.24]) * b
+    assert (np.abs(tr) <= lim).all() and np.allclose(tr.std(0), lim / np.sqrt(3), rtol=0.06)
+
+
+def test_shard_covers_all_envs_once():
+    from ml4ca_amd import dist as D
+    for total, world in [(262144, 8), (65536, 1), (1000, 3), (7, 7)]:
+        spans = [D.shard(total, r, world) for r in range(world)]
+        assert sum(n for n, _ in spans) == total
+        pos = 0
+        for n, base in spans:
+            assert base == pos
+            pos += n
+    assert D.shard(262144, 5, 8) == (32768, 5 * 32768)       # config 4: 8 x 32768
+    with pytest.raises(ValueError):
+        D.shard(4, 4, 4)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gloo_worker(rank, world, port, total, T, q):
+    """One rank: step its env shard with the CPU oracle (standing in for the GPU kernel, which cannot run
+    here), pack the [T, n_local, 19] block, all-gather over gloo, reassemble in global env order."""
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch
+    import torch.distributed as dist
+    from ml4ca_amd import dist as D
+    from oracle import oracle as O
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    n_local, base = D.shard(total, rank, world)
+    orc = O.Oracle(O.make_config(max_ep_len=6, auto_reset=1, seed=99, env_id_base=base), np.float32)
+    st, ctr = orc.new_state(n_local)
+    obs = orc.reset(st, ctr)
+    block = np.zeros((T, n_local, 19), np.float32)
+    for t in range(T):
+        rng = np.random.RandomState(1000 + t)                 # actions are a function of (t, global env id)
+        act = rng.normal(0, 0.7, size=(total, 7)).astype(np.float32)[base:base + n_local]
+        block[t, :, 0:9] = obs
+        block[t, :, 9:16] = act
+        obs, rew, done = orc.step(st, ctr, act)
+        block[t, :, 16] = rew
+        block[t, :, 17] = done
+    g = D.gather_trajectories(torch.from_numpy(block))
+    full = D.to_global_env_order(g).numpy()
+    # scalar statistics the way mpi_statistics_scalar does them: two all-reduces
+    acc = torch.tensor([block[..., 16].sum(dtype=np.float64), block[..., 16].size], dtype=torch.float64)
+    dist.all_reduce(acc)
+    if rank == 0:
+        q.put((full, float(acc[0] / acc[1])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gather_matches_single_process_run():
+    import torch.multiprocessing as mp
+    from oracle import oracle as O
+    total, T, world = 64, 12, 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, total, T, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full, mean_rew = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process run of all 64 envs
+    orc = O.Oracle(O.make_config(max_ep_len=6, auto_reset=1, seed=99, env_id_base=0), np.float32)
+    st, ctr = orc.new_state(total)
+    obs = orc.reset(st, ctr)
+    ref = np.zeros((T, total, 19), np.float32)
+    for t in range(T):
+        act = np.random.RandomState(1000 + t).normal(0, 0.7, size=(total, 7)).astype(np.float32)
+        ref[t, :, 0:9] = obs
+        ref[t, :, 9:16] = act
+        obs, rew, done = orc.step(st, ctr, act)
+        ref[t, :, 16] = rew
+        ref[t, :, 17] = done
+    assert full.shape == ref.shape
+    assert np.array_equal(full, ref), 'sharded + gathered rollout must equal the single-process rollout bit for bit'
+    assert (ref[..., 17] != 0).sum() >= total        # episodes ended and were re-sampled (Philox keyed by global id)
+    assert abs(mean_rew - ref[..., 16].mean(dtype=np.float64)) < 1e-9

@@ -42,6 +42,7 @@ def parse():
     ap.add_argument('--envs', type=int, default=N_ENVS, help='envs per GPU')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of HIP-graph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-fused', action='store_true', help='skip the fused-rollout leg')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='budget of the CPU baseline leg')
     ap.add_argument('--gather', type=int, default=-1, help='time the config-4 trajectory all-gather (default: on if gpus > 1)')
     ap.add_argument('--hold-plant', action='store_true', help='diagnostic: skip the plant sub-steps (INVALID as a result)')
@@ -173,6 +174,42 @@ def main():
     wall = float(tt[0])
     assert bool(torch.isfinite(obs).all()) and bool(torch.isfinite(rew).all()), 'non-finite outputs'
 
+    # ---- fused-rollout leg (dpenv_rollout): same workload, CHUNK env steps per launch, state in registers -----
+    fused = None
+    if not args.no_fused:
+        fobs = torch.empty((CHUNK, n, 9), device=dev)
+        frew = torch.empty((CHUNK, n), device=dev)
+        fdone = torch.empty((CHUNK, n), dtype=torch.uint8, device=dev)
+        env.reset(init=init, new_ref=start.clone())
+        refs1 = ref_buf.view(1, 3, n)
+
+        def run_fused(k):
+            for c in range(k // CHUNK):
+                t = (c * CHUNK) % 1250
+                if t == 0:
+                    ref_buf.copy_(start)
+                if t in BOX_SWITCH_STEPS:
+                    ref_buf.copy_(refs[BOX_SWITCH_STEPS.index(t)])
+                env.rollout(actions, switch_steps=(0,), refs=refs1, out=(fobs, frew, fdone))
+
+        run_fused(max(W, CHUNK))
+        fe0, fe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        tf0 = time.perf_counter()
+        fe0.record()
+        run_fused(K)
+        fe1.record()
+        torch.cuda.synchronize(dev)
+        fwall = time.perf_counter() - tf0
+        fms = fe0.elapsed_time(fe1)
+        assert bool(torch.isfinite(fobs).all())
+        fused = {'what': 'dpenv_rollout: %d env steps per launch, state resident in registers; open-loop action block; '
+                         'same workload; NOT the headline value' % CHUNK,
+                 'env_steps_per_s': n * K / fwall, 'us_per_step': fwall / K * 1e6, 'launch_us_events': fms * 1e3 / (K // CHUNK),
+                 'bytes_per_env_step_moved': 28 + 36 + 4 + 1,
+                 'GBps_at_177B_accounting': ALGO_BYTES_PER_ENV_STEP * n * K / (fms * 1e-3) / 1e9,
+                 'frac_of_8TBps_at_177B_accounting': ALGO_BYTES_PER_ENV_STEP * n * K / (fms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+
     # ---- config-4 leg: episode-boundary all-gather of [T=400, 32768, 19] f32 trajectory blocks ------------
     gather = None
     do_gather = (args.gather == 1) or (args.gather < 0 and world > 1)
@@ -230,6 +267,8 @@ def main():
         }
         if gather:
             res['allgather'] = gather
+        if fused:
+            res['fused_rollout'] = fused
         if not args.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline(n, args.cpu_seconds)
         elif not args.no_cpu_baseline:

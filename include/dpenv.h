@@ -159,6 +159,25 @@ int dpenv_step(dpenv_handle h, const float* action, const float* new_ref, void* 
                uint8_t* done_out, dpenv_stream s);
 int dpenv_step_ex(dpenv_handle h, const dpenv_step_io* io, dpenv_stream s);
 
+/* Fused rollout: T env steps in ONE launch with the state resident in registers.  Exactly the semantics of T
+ * successive dpenv_step calls with actions[t] as the action and, at t == switch_step[k], refs[k] as new_ref
+ * (the setpoint-sequence form of test_policy.py:127,148-153 / results/all_plots/box_test/plot_pos.py:55-59).
+ * obs[t] is the observation returned by step t.  Open loop: the action block must exist before the launch
+ * (recorded command sequences, pre-sampled exploration noise, benchmark input). */
+#define DPENV_MAX_SWITCH 8
+typedef struct dpenv_rollout_io {
+    uint32_t struct_size;
+    int32_t T;
+    const float* actions;    /* [T][n][act_dim] (AOS) or [T][act_dim][n] (SOA) */
+    void* obs;               /* [T][n][obs_dim] or [T][obs_dim][n]; f32 or bf16 */
+    float* reward;           /* [T][n] */
+    uint8_t* done;           /* [T][n], DPENV_DONE_* bits */
+    int32_t n_switch;        /* 0..DPENV_MAX_SWITCH, switch_step strictly increasing */
+    int32_t switch_step[DPENV_MAX_SWITCH];
+    const float* refs;       /* [n_switch][3][n] */
+} dpenv_rollout_io;
+int dpenv_rollout(dpenv_handle h, const dpenv_rollout_io* io, dpenv_stream s);
+
 /* Parity/test access to the library-owned state in the canonical format above. */
 int dpenv_get_state(dpenv_handle h, float* state_out, int32_t* counters_out, dpenv_stream s);
 int dpenv_set_state(dpenv_handle h, const float* state_in, const int32_t* counters_in, dpenv_stream s);

@@ -43,6 +43,12 @@ class StepIO(C.Structure):
                 ('reward', C.c_void_p), ('done', C.c_void_p), ('reward_parts', C.c_void_p), ('final_obs', C.c_void_p)]
 
 
+class RolloutIO(C.Structure):
+    _fields_ = [('struct_size', C.c_uint32), ('T', C.c_int32), ('actions', C.c_void_p), ('obs', C.c_void_p),
+                ('reward', C.c_void_p), ('done', C.c_void_p), ('n_switch', C.c_int32), ('switch_step', C.c_int32 * 8),
+                ('refs', C.c_void_p)]
+
+
 # every symbol include/dpenv.h declares: name -> (restype, argtypes)
 _VP, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SYMBOLS = {
@@ -60,6 +66,7 @@ SYMBOLS = {
     'dpenv_reset': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
     'dpenv_step': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     'dpenv_step_ex': (C.c_int, [_VP, C.POINTER(StepIO), _VP]),
+    'dpenv_rollout': (C.c_int, [_VP, C.POINTER(RolloutIO), _VP]),
     'dpenv_get_state': (C.c_int, [_VP, _VP, _VP, _VP]),
     'dpenv_set_state': (C.c_int, [_VP, _VP, _VP, _VP]),
     'dpenv_thrust_map': (C.c_int, [C.POINTER(C.c_float), _VP, _VP, _VP, _I32, _VP]),

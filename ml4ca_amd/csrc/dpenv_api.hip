@@ -363,6 +363,30 @@ extern "C" int dpenv_step(dpenv_handle h, const float* action, const float* new_
     return dpenv_step_ex(h, &io, s);
 }
 
+extern "C" int dpenv_rollout(dpenv_handle h, const dpenv_rollout_io* io, dpenv_stream s)
+{
+    if (!h) return DPENV_EINVAL;
+    if (!io || io->struct_size != sizeof(dpenv_rollout_io)) return fail(h, DPENV_EINVAL, "dpenv_rollout_io ABI mismatch");
+    if (io->T <= 0 || !io->actions || !io->obs || !io->reward || !io->done)
+        return fail(h, DPENV_EINVAL, "T > 0 and action, obs, reward, done blocks are required");
+    if (io->n_switch < 0 || io->n_switch > DPENV_MAX_SWITCH || (io->n_switch > 0 && !io->refs))
+        return fail(h, DPENV_EINVAL, "bad setpoint schedule");
+    for (int k = 0; k < io->n_switch; ++k)
+        if (io->switch_step[k] < 0 || io->switch_step[k] >= io->T || (k > 0 && io->switch_step[k] <= io->switch_step[k - 1]))
+            return fail(h, DPENV_EINVAL, "switch_step must be strictly increasing within [0, T)");
+    if (h->n_classes > 1 && !h->classes_assigned)
+        return fail(h, DPENV_EINVAL, "n_classes > 1 but dpenv_set_vessel_class was never called");
+    StepArgs a = h->args;
+    bind_optional(h, a);
+    RolloutArgs ra;
+    std::memset(&ra, 0, sizeof ra);
+    ra.T = io->T; ra.actions = io->actions; ra.obs = io->obs; ra.rew = io->reward; ra.done = io->done;
+    ra.n_switch = io->n_switch; ra.refs = io->refs;
+    for (int k = 0; k < io->n_switch; ++k) ra.switch_step[k] = io->switch_step[k];
+    HIP_TRY(h, dpenv_dev_launch_rollout(&a, &ra, h->mode, h->cfg.extended_state, h->n_classes > 1, (hipStream_t)s));
+    return DPENV_OK;
+}
+
 extern "C" int dpenv_get_state(dpenv_handle h, float* state_out, int32_t* counters_out, dpenv_stream s)
 {
     if (!h) return DPENV_EINVAL;

@@ -7,12 +7,14 @@
 #include <stdint.h>
 
 #ifndef DPENV_BLOCK
-#define DPENV_BLOCK 256   // threads per workgroup = 4 wave64; one lane per environment
+#define DPENV_BLOCK 64    // threads per workgroup = one wave64; one lane per environment; LDS staging is wave-private
 #endif
 
 namespace dpenv {
 
 constexpr int BLOCK = DPENV_BLOCK;
+constexpr int RBLOCK = 64;        // rollout kernel: one wave per workgroup (wave-private LDS transposes)
+constexpr int MAX_SWITCH = 8;
 constexpr int MAX_CLASSES = 64;
 
 // kernel specialisations: variant x azimuth-head style (customEnv.py:11,327,351,373 + cont_ang :90)
@@ -72,9 +74,23 @@ struct StepArgs {
     float reset_fraction;
 };
 
+// fused T-step rollout (dpenv_rollout)
+struct RolloutArgs {
+    int32_t T;
+    const float* actions;     // [T][n][A] or [T][A][n]
+    void* obs;                // [T][n][OD] or [T][OD][n]
+    float* rew;               // [T][n]
+    uint8_t* done;            // [T][n]
+    int32_t n_switch;
+    int32_t switch_step[MAX_SWITCH];
+    const float* refs;        // [n_switch][3][n]
+};
+
 }  // namespace dpenv
 
 extern "C" {
+hipError_t dpenv_dev_launch_rollout(const dpenv::StepArgs* a, const dpenv::RolloutArgs* ra, int mode, int ext,
+                                    int per_class, hipStream_t s);
 hipError_t dpenv_dev_launch_step(const dpenv::StepArgs* a, int mode, int ext, int per_class, hipStream_t s);
 hipError_t dpenv_dev_launch_reset(const dpenv::StepArgs* a, int mode, int ext, const uint8_t* mask, const float* init,
                                   const float* ref, hipStream_t s);

@@ -142,9 +142,9 @@ __device__ __forceinline__ void thrust_map(const Vessel& ve, const float n[3], c
         const float F = K * fabsf(n[i]) * n[i];
         float sa, ca;
         sincosf(al[i], &sa, &ca);
-        tx += ca * F;
-        ty += sa * F;
-        tn += (ve.lx[i] * sa - ve.ly[i] * ca) * F;
+        tx = fmaf(ca, F, tx);
+        ty = fmaf(sa, F, ty);
+        tn = fmaf(fmaf(ve.lx[i], sa, -(ve.ly[i] * ca)), F, tn);
     }
 }
 
@@ -156,8 +156,8 @@ __device__ __forceinline__ void make_obs(float N, float E, float psi, float u, f
     const float rot = wrap_angle(psi, deg);
     float sr, cr;
     sincosf(rot, &sr, &cr);
-    o[0] = cr * eN + sr * eE;
-    o[1] = cr * eE - sr * eN;
+    o[0] = fmaf(cr, eN, sr * eE);
+    o[1] = fmaf(cr, eE, -(sr * eN));
     o[2] = wrap_angle(psi - refPsi, deg);
     o[3] = u; o[4] = v; o[5] = r;
     o[6] = pt[0] * 0.01f; o[7] = pt[1] * 0.01f; o[8] = pt[2] * 0.01f;
@@ -182,10 +182,65 @@ __device__ __forceinline__ void sample_reset(const StepArgs& a, int64_t gid, uin
     nu[2] = (b[5] * fv) * u01_sym(w1[1]);
 }
 
+// Ordering point for the LDS transposes.  With one wave per workgroup (BLOCK == 64) the staging area is
+// wave-private: DS operations of a wave execute in issue order, so a compiler-level fence is all that is
+// needed.  A real __syncthreads() would also drain vmcnt(0), i.e. stall on every outstanding global
+// store and prefetch - measured at ~2 us per env step in the fused rollout.
+template <int THREADS> __device__ __forceinline__ void lds_order()
+{
+    if (THREADS == 64) __builtin_amdgcn_wave_barrier();
+    else __syncthreads();
+}
+
 __device__ __forceinline__ uint16_t f2bf(float x)
 {
     // plain cast: v_cvt_pk_bf16_f32 (RNE, NaN stays NaN)
     return __builtin_bit_cast(uint16_t, __float2bfloat16(x));
+}
+
+// Coalesced write of a workgroup's THREADS x OD staged elements (LDS image [j*THREADS + tid]) to
+// dst[base ...]; `rem` = elements remaining in the destination from `base` (uniform).  Full workgroups take
+// the unpredicated path: uniform base pointer + 32-bit lane offset.
+template <int OD, int THREADS>
+__device__ __forceinline__ void store_rows(void* dst, int64_t base, int64_t rem, bool bf16, const float* lds, int tid)
+{
+    const bool full = rem >= (int64_t)THREADS * OD;
+    if (bf16) {
+        uint16_t* p = (uint16_t*)dst + base;
+        if (full) {
+#pragma unroll
+            for (int j = 0; j < OD; ++j) p[(unsigned)(j * THREADS + tid)] = f2bf(lds[j * THREADS + tid]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < OD; ++j)
+                if (j * THREADS + tid < rem) p[(unsigned)(j * THREADS + tid)] = f2bf(lds[j * THREADS + tid]);
+        }
+    } else {
+        float* p = (float*)dst + base;
+        if (full) {
+#pragma unroll
+            for (int j = 0; j < OD; ++j) p[(unsigned)(j * THREADS + tid)] = lds[j * THREADS + tid];
+        } else {
+#pragma unroll
+            for (int j = 0; j < OD; ++j)
+                if (j * THREADS + tid < rem) p[(unsigned)(j * THREADS + tid)] = lds[j * THREADS + tid];
+        }
+    }
+}
+
+// Coalesced read of a workgroup's THREADS x A action elements into registers (element j*THREADS + tid).
+// Out-of-range elements of the last workgroup are clamped to the last valid one instead of being selected
+// to zero: a select on the loaded value would force a wait after every load (the lanes that read them are
+// dead and never store).
+template <int A, int THREADS>
+__device__ __forceinline__ void load_rows(const float* src_block, int64_t rem, int tid, float pre[A])
+{
+    const int lim = (int)(rem < (int64_t)THREADS * A ? rem : (int64_t)THREADS * A) - 1;   // uniform
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+        const int e = j * THREADS + tid;
+        pre[j] = src_block[(unsigned)(e < lim ? e : lim)];
+    }
 }
 
 // Write one observation row per lane.  AOS: through LDS so that the global stores are coalesced
@@ -209,31 +264,189 @@ __device__ __forceinline__ void store_obs(const StepArgs& a, void* dst, const fl
         }
         return;
     }
-    __syncthreads();   // previous users of the LDS staging area are done
+    lds_order<BLOCK>();   // previous users of the LDS staging area are done
 #pragma unroll
     for (int k = 0; k < OD; ++k) lds[tid * OD + k] = o[k];
-    __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * (BLOCK * OD);
-    const int64_t total = (int64_t)n * OD;
-    if (a.obs_bf16) {
-        uint16_t* p = (uint16_t*)dst;
-#pragma unroll
-        for (int j = 0; j < OD; ++j) {
-            const int64_t idx = base + j * BLOCK + tid;
-            if (idx < total) p[idx] = f2bf(lds[j * BLOCK + tid]);
-        }
-    } else {
-        float* p = (float*)dst;
-#pragma unroll
-        for (int j = 0; j < OD; ++j) {
-            const int64_t idx = base + j * BLOCK + tid;
-            if (idx < total) p[idx] = lds[j * BLOCK + tid];
-        }
-    }
+    lds_order<BLOCK>();
+    const int64_t base = (int64_t)blockIdx.x * (BLOCK * OD);          // uniform
+    const int64_t rem = (int64_t)n * OD - base;                           // elements left from this block's start
+    store_rows<OD, BLOCK>(dst, base, rem, a.obs_bf16, lds, tid);
 }
 
 // =============================================================================================
-//  env.step
+//  one environment step in registers (shared by step_kernel and rollout_kernel)
+// =============================================================================================
+struct Env {              // per-lane state carried between env steps
+    float N, E, psi, u, v, r;
+    float refN, refE, refPsi;
+    float pt[3];          // previous thrust command, percent (ENV:126)
+    float ang[3];         // azimuth command in force: bow, port, star (ENV:122)
+    int steps;            // steps taken in the running episode
+};
+
+struct StepOut {
+    float o[9];           // observation of this step (terminal one if the env finished)
+    float reward;
+    float parts[4];
+    uint32_t d;           // DONE_* bits
+};
+
+// ENV:104-133 for one env: decode, command map, plant, observation, reward, termination, late new_ref.
+// cur = constant current (vcN, vcE in NED) present.
+template <int MODE, bool EXT>
+__device__ __forceinline__ void env_step(const StepArgs& a, const Vessel& ve, Env& s, const float* act, bool has_ref,
+                                         float nrN, float nrE, float nrP, bool cur, float vcN, float vcE, StepOut& out)
+{
+    const float ang_prev[3] = {s.ang[0], s.ang[1], s.ang[2]};   // ENV:102
+    const float pt_old[3] = {s.pt[0], s.pt[1], s.pt[2]};
+
+    // ---- action decode ENV:104-110, scale_and_clip ENV:215-225, command map ENV:117-122 -------------
+    float thr[3];
+    thr[0] = clipf(act[0] * 100.0f, 100.0f);
+    thr[1] = clipf(act[1] * 100.0f, 100.0f);
+    thr[2] = clipf(act[2] * 100.0f, 100.0f);
+    if (MODE == MODE_FULL) {
+        s.ang[0] = clipf(act[3] * kPi, kPi); s.ang[1] = clipf(act[4] * kPi, kPi); s.ang[2] = clipf(act[5] * kPi, kPi);
+    } else if (MODE == MODE_LIMITED) {
+        s.ang[1] = clipf(act[3] * (kPi * 0.5f), kPi * 0.5f); s.ang[2] = clipf(act[4] * (kPi * 0.5f), kPi * 0.5f);
+    } else if (MODE == MODE_FINAL_WRAP) {
+        // ENV:237-244: wrap_angle(a*pi, deg=False)/pi, evaluated in units of pi (exact in fp32)
+        const float w3 = act[3] - 2.0f * floorf((act[3] + 1.0f) * 0.5f);
+        const float w4 = act[4] - 2.0f * floorf((act[4] + 1.0f) * 0.5f);
+        s.ang[1] = clipf(w3 * kPi, kPi); s.ang[2] = clipf(w4 * kPi, kPi);
+    } else if (MODE == MODE_FINAL_CONT) {
+        // ENV:227-235: atan2(sin_head, cos_head)/pi, then *pi and clip
+        s.ang[1] = clipf(atan2f(act[3], act[4]), kPi); s.ang[2] = clipf(atan2f(act[5], act[6]), kPi);
+    }
+
+    // ---- plant: BUILD-OWNED 3-DOF model, n_substeps semi-implicit Euler steps --
+    float tx, ty, tn;
+    thrust_map(ve, thr, s.ang, tx, ty, tn);
+    float N = s.N, E = s.E, psi = s.psi, u = s.u, v = s.v, r = s.r;
+    float sn, cs;
+    sincosf(psi, &sn, &cs);
+    if (cur) {
+        u -= fmaf(cs, vcN, sn * vcE);      // relative velocity nu_r = nu - R(psi)^T v_c
+        v -= fmaf(cs, vcE, -(sn * vcN));
+    }
+    const float h = a.h;
+    const float hA = h * ve.inv11, h22 = h * ve.i22, h23 = h * ve.i23, h33 = h * ve.i33;
+    const int nsub = a.hold_plant ? 0 : a.n_substeps;
+    for (int k = 0; k < nsub; ++k) {
+        // C(nu)nu with c13 = -q, q = m22 v + m23 r; c23 = m11 u
+        const float q = fmaf(ve.m22, v, ve.m23 * r);
+        const float c23 = ve.m11 * u;
+        float fx = fmaf(-fmaf(ve.Xuu, fabsf(u), ve.Xu), u, tx);
+        fx = fmaf(q, r, fx);
+        float fy = fmaf(-fmaf(ve.Yvv, fabsf(v), ve.Yv), v, ty);
+        fy = fmaf(-fmaf(ve.Yur, u, ve.Yr), r, fy);
+        fy = fmaf(-c23, r, fy);
+        float fn = fmaf(-q, u, tn);
+        fn = fmaf(c23, v, fn);
+        fn = fmaf(-fmaf(ve.Nuv, u, ve.Nv), v, fn);
+        fn = fmaf(-fmaf(ve.Nrr, fabsf(r), ve.Nr), r, fn);
+        u = fmaf(hA, fx, u);
+        v = fmaf(h22, fy, fmaf(h23, fn, v));
+        r = fmaf(h23, fy, fmaf(h33, fn, r));
+        // kinematics with the old heading and the new velocity
+        N = fmaf(h, fmaf(-sn, v, fmaf(cs, u, vcN)), N);
+        E = fmaf(h, fmaf(cs, v, fmaf(sn, u, vcE)), E);
+        // heading: exact rotation by d = h r, series for sin d / cos d
+        const float d = h * r;
+        const float d2 = d * d;
+        const float sd = d * fmaf(d2, fmaf(d2, 1.0f / 120.0f, -1.0f / 6.0f), 1.0f);
+        const float cd = fmaf(d2, fmaf(d2, 1.0f / 24.0f, -0.5f), 1.0f);
+        psi += d;
+        const float c2 = fmaf(cs, cd, -(sn * sd));
+        const float s2n = fmaf(sn, cd, cs * sd);
+        cs = c2; sn = s2n;
+    }
+    if (cur) {
+        float se, ce;
+        sincosf(psi, &se, &ce);
+        u += fmaf(ce, vcN, se * vcE);
+        v += fmaf(ce, vcE, -(se * vcN));
+    }
+    s.N = N; s.E = E; s.psi = psi; s.u = u; s.v = v; s.r = r;
+
+    // ---- observation (previous thrust: quirk Q2), reward, termination --------------------------------
+    const bool deg = (a.wrap_mode == WRAP_REFERENCE);
+    float* o = out.o;
+    make_obs(N, E, psi, u, v, r, s.refN, s.refE, s.refPsi, pt_old, deg, o);
+
+    float p_der = 0.0f;
+    const float p_vel = -sqrtf(fmaf(o[3] * o[3], 0.5f, fmaf(o[4] * o[4], 0.5f, o[5] * o[5])));   // ENV:267-273
+    const float rr2 = fmaf(o[0], o[0], o[1] * o[1]);
+    const float yaw = o[2] * (180.0f / kPi);                                                    // ENV:281
+    const float multivar = 2.0f * expf(-0.5f * fmaf(yaw * yaw, 1.0f / 25.0f, rr2));             // ENV:283, covar ENV:86-88
+    const float special = sqrtf(fmaf(yaw * 0.25f, yaw * 0.25f, rr2));                           // ENV:287
+    const float p_pos = multivar + fmaxf(-1.0f, fmaf(-0.1f, special, 1.0f)) + 0.5f;             // ENV:288-290
+    const float p_thr = -(fabsf(thr[0]) * 0.20f + fabsf(thr[1]) * 0.30f + fabsf(thr[2]) * 0.30f) * 0.01f;   // ENV:292-302
+    if (EXT) {
+        const float inv_dt = a.inv_dt;
+        float pen = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pen -= fabsf((thr[k] - pt_old[k]) * inv_dt * 0.01f) * 0.05f;   // ENV:310-313
+        const float inv_bnd = (MODE == MODE_LIMITED) ? (2.0f / kPi) : (1.0f / kPi);               // ENV:319
+        const float angpen = -(fabsf((s.ang[1] - ang_prev[1]) * inv_dt * inv_bnd) * 0.01f +
+                               fabsf((s.ang[2] - ang_prev[2]) * inv_dt * inv_bnd) * 0.01f);       // ENV:315-320 (bow coeff 0)
+        p_der = pen + fmaxf(-1.0f, angpen);                                                       // ENV:322-323
+    }
+    out.parts[0] = p_vel; out.parts[1] = p_pos; out.parts[2] = p_thr; out.parts[3] = p_der;
+    out.reward = p_vel + p_pos + p_thr + p_der;   // ENV:263
+
+    uint32_t d = 0;
+    if (a.terminate) {
+        float b[6];
+        ss_bounds<MODE>(b);
+        bool t = false;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) t = t || (fabsf(o[k]) > b[k]);   // ENV:207-213, strict >
+        d = t ? DONE_TERMINAL : 0u;
+    }
+    {
+        const float chk = N + E + psi + u + v + r;     // any NaN/Inf poisons the sum
+        if (!(fabsf(chk) <= 3.0e38f)) d |= DONE_TERMINAL | DONE_FAULT;
+    }
+    if (has_ref) { s.refN = nrN; s.refE = nrE; s.refPsi = nrP; }   // ENV:131: visible from the next step (Q4)
+    s.steps += 1;
+    if (a.max_ep_len > 0 && s.steps >= a.max_ep_len) d |= DONE_TIMELIMIT;   // ppo.py:304
+    s.pt[0] = thr[0]; s.pt[1] = thr[1]; s.pt[2] = thr[2];   // ENV:126
+    out.d = d;
+}
+
+// auto-reset of one finished env: ENV:135-194 with the training sampler; returns the new episode's first obs
+template <int MODE>
+__device__ __forceinline__ void env_auto_reset(const StepArgs& a, Env& s, int64_t gid, uint32_t episode, float o_new[9])
+{
+    float eta[3], nu[3];
+    sample_reset<MODE>(a, gid, episode, eta, nu);
+    s.N = eta[0]; s.E = eta[1]; s.psi = eta[2]; s.u = nu[0]; s.v = nu[1]; s.r = nu[2];
+    s.pt[0] = s.pt[1] = s.pt[2] = 0.0f;                         // ENV:190
+    default_angles<MODE>(s.ang[0], s.ang[1], s.ang[2]);         // ENV:173-177,192
+    s.steps = 0;
+    make_obs(s.N, s.E, s.psi, s.u, s.v, s.r, s.refN, s.refE, s.refPsi, s.pt, a.wrap_mode == WRAP_REFERENCE, o_new);
+}
+
+__device__ __forceinline__ void load_env(const StepArgs& a, int il, Env& s)
+{
+    const float4 s0 = a.S0[il], s1 = a.S1[il], s2 = a.S2[il], rf = a.RF[il];
+    s.N = s0.x; s.E = s0.y; s.psi = s0.z; s.u = s0.w; s.v = s1.x; s.r = s1.y;
+    s.ang[0] = rf.w; s.ang[1] = s1.z; s.ang[2] = s1.w;
+    s.pt[0] = s2.x; s.pt[1] = s2.y; s.pt[2] = s2.z; s.steps = __float_as_int(s2.w);
+    s.refN = rf.x; s.refE = rf.y; s.refPsi = rf.z;
+}
+
+__device__ __forceinline__ void store_env(const StepArgs& a, int i, const Env& s, bool rf_dirty)
+{
+    a.S0[i] = make_float4(s.N, s.E, s.psi, s.u);
+    a.S1[i] = make_float4(s.v, s.r, s.ang[1], s.ang[2]);
+    a.S2[i] = make_float4(s.pt[0], s.pt[1], s.pt[2], __int_as_float(s.steps));
+    if (rf_dirty) a.RF[i] = make_float4(s.refN, s.refE, s.refPsi, s.ang[0]);
+}
+
+// =============================================================================================
+//  env.step: one launch = one step of every env
 // =============================================================================================
 template <int MODE, bool EXT, bool PER_CLASS>
 __global__ __launch_bounds__(BLOCK) void step_kernel(const StepArgs a)
@@ -253,24 +466,22 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const StepArgs a)
     float act[A];
     if (a.action_layout == LAYOUT_AOS) {
         const int64_t base = (int64_t)blockIdx.x * (BLOCK * A);
-        const int64_t total = (int64_t)n * A;
-#pragma unroll
-        for (int j = 0; j < A; ++j) {
-            const int64_t idx = base + j * BLOCK + tid;
-            lds_io[j * BLOCK + tid] = (idx < total) ? a.action[idx] : 0.0f;
-        }
+        load_rows<A, BLOCK>(a.action + base, (int64_t)n * A - base, tid, act);
     } else {
 #pragma unroll
         for (int k = 0; k < A; ++k) act[k] = a.action[(int64_t)k * n + il];
     }
-    const float4 s0 = a.S0[il];
-    const float4 s1 = a.S1[il];
-    const float4 s2 = a.S2[il];
-    const float4 rf = a.RF[il];
+    Env s;
+    load_env(a, il, s);
     float nrN = 0.0f, nrE = 0.0f, nrP = 0.0f;
     if (a.new_ref) { nrN = a.new_ref[il]; nrE = a.new_ref[(int64_t)n + il]; nrP = a.new_ref[2 * (int64_t)n + il]; }
-    float vc = 0.0f, beta = 0.0f;
-    if (a.cur_vc) { vc = a.cur_vc[il]; beta = a.cur_beta[il]; }
+    float vcN = 0.0f, vcE = 0.0f;
+    if (a.cur_vc) {
+        float sb, cb;
+        sincosf(a.cur_beta[il], &sb, &cb);
+        const float vc = a.cur_vc[il];
+        vcN = vc * cb; vcE = vc * sb;
+    }
     int cls = 0;
     if (PER_CLASS) {
         cls = a.class_id[il];
@@ -279,174 +490,175 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const StepArgs a)
             lds_cls[p * a.n_classes + c] = a.class_tab[k];
         }
     }
-    if (a.action_layout == LAYOUT_AOS || PER_CLASS) __syncthreads();
+    if (a.action_layout == LAYOUT_AOS) {
+#pragma unroll
+        for (int j = 0; j < A; ++j) lds_io[j * BLOCK + tid] = act[j];
+    }
+    if (a.action_layout == LAYOUT_AOS || PER_CLASS) lds_order<BLOCK>();
     if (a.action_layout == LAYOUT_AOS) {
 #pragma unroll
         for (int k = 0; k < A; ++k) act[k] = lds_io[tid * A + k];
     }
     const Vessel ve = PER_CLASS ? vessel_from_lds(lds_cls, a.n_classes, cls) : vessel_from_args(a.v0);
 
-    float N = s0.x, E = s0.y, psi = s0.z, u = s0.w;
-    float v = s1.x, r = s1.y;
-    float refN = rf.x, refE = rf.y, refPsi = rf.z;
-    const float pt_old[3] = {s2.x, s2.y, s2.z};
-    int steps = __float_as_int(s2.w);
-    const float ang_prev[3] = {rf.w, s1.z, s1.w};   // ENV:102 (bow, port, star)
-    float ang[3] = {rf.w, s1.z, s1.w};
+    StepOut out;
+    env_step<MODE, EXT>(a, ve, s, act, a.new_ref != nullptr, nrN, nrE, nrP, a.cur_vc != nullptr, vcN, vcE, out);
 
-    // ---- action decode, ENV:104-110 + scale_and_clip ENV:215-225 + command map ENV:117-122 ------
-    float thr[3];
-    thr[0] = clipf(act[0] * 100.0f, 100.0f);
-    thr[1] = clipf(act[1] * 100.0f, 100.0f);
-    thr[2] = clipf(act[2] * 100.0f, 100.0f);
-    if (MODE == MODE_FULL) {
-        ang[0] = clipf(act[3] * kPi, kPi); ang[1] = clipf(act[4] * kPi, kPi); ang[2] = clipf(act[5] * kPi, kPi);
-    } else if (MODE == MODE_LIMITED) {
-        ang[1] = clipf(act[3] * (kPi * 0.5f), kPi * 0.5f); ang[2] = clipf(act[4] * (kPi * 0.5f), kPi * 0.5f);
-    } else if (MODE == MODE_FINAL_WRAP) {
-        // ENV:237-244: wrap_angle(a*pi, deg=False)/pi, evaluated in units of pi (exact in fp32)
-        const float w3 = act[3] - 2.0f * floorf((act[3] + 1.0f) * 0.5f);
-        const float w4 = act[4] - 2.0f * floorf((act[4] + 1.0f) * 0.5f);
-        ang[1] = clipf(w3 * kPi, kPi); ang[2] = clipf(w4 * kPi, kPi);
-    } else if (MODE == MODE_FINAL_CONT) {
-        // ENV:227-235: atan2(sin_head, cos_head)/pi, then *pi and clip
-        ang[1] = clipf(atan2f(act[3], act[4]), kPi); ang[2] = clipf(atan2f(act[5], act[6]), kPi);
-    }
-
-    // ---- plant: BUILD-OWNED 3-DOF model, n_substeps semi-implicit Euler steps ------------------
-    float tx, ty, tn;
-    thrust_map(ve, thr, ang, tx, ty, tn);
-    float sn, cs;
-    sincosf(psi, &sn, &cs);
-    float vcN = 0.0f, vcE = 0.0f;
-    if (a.cur_vc) {
-        float sb, cb;
-        sincosf(beta, &sb, &cb);
-        vcN = vc * cb; vcE = vc * sb;
-        u -= cs * vcN + sn * vcE;      // relative velocity nu_r = nu - R(psi)^T v_c
-        v -= cs * vcE - sn * vcN;
-    }
-    const float h = a.h;
-    const int nsub = a.hold_plant ? 0 : a.n_substeps;
-    for (int k = 0; k < nsub; ++k) {
-        const float c13 = -(ve.m22 * v + ve.m23 * r);
-        const float c23 = ve.m11 * u;
-        const float fx = tx - c13 * r - (ve.Xu + ve.Xuu * fabsf(u)) * u;
-        const float fy = ty - c23 * r - ((ve.Yv + ve.Yvv * fabsf(v)) * v + (ve.Yr + ve.Yur * u) * r);
-        const float fn = tn + (c13 * u + c23 * v) - ((ve.Nv + ve.Nuv * u) * v + (ve.Nr + ve.Nrr * fabsf(r)) * r);
-        u += h * (fx * ve.inv11);
-        v += h * (ve.i22 * fy + ve.i23 * fn);
-        r += h * (ve.i23 * fy + ve.i33 * fn);
-        N += h * (cs * u - sn * v + vcN);
-        E += h * (sn * u + cs * v + vcE);
-        const float d = h * r;
-        const float d2 = d * d;
-        const float sd = d * (1.0f - d2 * (1.0f / 6.0f) * (1.0f - d2 * (1.0f / 20.0f)));
-        const float cd = 1.0f - d2 * 0.5f * (1.0f - d2 * (1.0f / 12.0f));
-        psi += d;
-        const float c2 = cs * cd - sn * sd;
-        const float s2n = sn * cd + cs * sd;
-        cs = c2; sn = s2n;
-    }
-    if (a.cur_vc) {
-        float se, ce;
-        sincosf(psi, &se, &ce);
-        u += ce * vcN + se * vcE;
-        v += ce * vcE - se * vcN;
-    }
-
-    // ---- observation (previous thrust: quirk Q2), reward, termination --------------------------
-    const bool deg = (a.wrap_mode == WRAP_REFERENCE);
-    float o[9];
-    make_obs(N, E, psi, u, v, r, refN, refE, refPsi, pt_old, deg, o);
-
-    float p_vel, p_pos, p_thr, p_der = 0.0f;
-    {
-        p_vel = -sqrtf(o[3] * o[3] * 0.5f + o[4] * o[4] * 0.5f + o[5] * o[5]);            // ENV:267-273
-        const float rr2 = o[0] * o[0] + o[1] * o[1];
-        const float yaw = o[2] * (180.0f / kPi);                                           // ENV:281
-        const float multivar = 2.0f * expf(-0.5f * (rr2 + yaw * yaw * (1.0f / 25.0f)));    // ENV:283, covar ENV:86-88
-        const float special = sqrtf(rr2 + (yaw * 0.25f) * (yaw * 0.25f));                  // ENV:287
-        p_pos = multivar + fmaxf(-1.0f, 1.0f - 0.1f * special) + 0.5f;                     // ENV:288-290
-        p_thr = -(fabsf(thr[0]) * 0.20f + fabsf(thr[1]) * 0.30f + fabsf(thr[2]) * 0.30f) * 0.01f;   // ENV:292-302
-        if (EXT) {
-            const float inv_dt = a.inv_dt;
-            float pen = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) pen -= fabsf((thr[k] - pt_old[k]) * inv_dt * 0.01f) * 0.05f;   // ENV:310-313
-            const float inv_bnd = (MODE == MODE_LIMITED) ? (2.0f / kPi) : (1.0f / kPi);   // ENV:319
-            float angpen = -(fabsf((ang[1] - ang_prev[1]) * inv_dt * inv_bnd) * 0.01f +
-                             fabsf((ang[2] - ang_prev[2]) * inv_dt * inv_bnd) * 0.01f);   // ENV:315-320 (bow coeff 0)
-            p_der = pen + fmaxf(-1.0f, angpen);                                           // ENV:322-323
-        }
-    }
-    const float reward = p_vel + p_pos + p_thr + p_der;   // ENV:263
-
-    uint32_t d = 0;
-    if (a.terminate) {
-        float b[6];
-        ss_bounds<MODE>(b);
-        bool t = false;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) t = t || (fabsf(o[k]) > b[k]);   // ENV:207-213, strict >
-        d = t ? DONE_TERMINAL : 0u;
-    }
-    {
-        const float chk = N + E + psi + u + v + r;     // any NaN/Inf poisons the sum
-        if (!(fabsf(chk) <= 3.0e38f)) d |= DONE_TERMINAL | DONE_FAULT;
-    }
-    if (a.new_ref) { refN = nrN; refE = nrE; refPsi = nrP; }   // ENV:131: visible from the next step (Q4)
-    steps += 1;
-    if (a.max_ep_len > 0 && steps >= a.max_ep_len) d |= DONE_TIMELIMIT;   // ppo.py:304
-
-    float pt_new[3] = {thr[0], thr[1], thr[2]};   // ENV:126
     bool rf_dirty = (a.new_ref != nullptr) || (MODE == MODE_FULL);
-    float o_out[9];
+    float o_next[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) o_out[k] = o[k];
+    for (int k = 0; k < 9; ++k) o_next[k] = out.o[k];
 
-    // ---- auto-reset (divergent, rare): ENV:135-194 with the training sampler --------------------
-    if (a.auto_reset && d != 0u && live) {
+    // ---- auto-reset (divergent, rare): the batched form of ppo.py:305-322 -------------------------
+    if (a.auto_reset && out.d != 0u && live) {
         if (a.final_obs) {
             // scattered 36-byte rows, only from lanes that finished an episode
-            if (a.obs_layout == LAYOUT_SOA) {
-                for (int k = 0; k < OD; ++k) {
-                    if (a.obs_bf16) ((uint16_t*)a.final_obs)[(int64_t)k * n + i] = f2bf(o[k]);
-                    else ((float*)a.final_obs)[(int64_t)k * n + i] = o[k];
-                }
-            } else {
-                for (int k = 0; k < OD; ++k) {
-                    if (a.obs_bf16) ((uint16_t*)a.final_obs)[(int64_t)i * OD + k] = f2bf(o[k]);
-                    else ((float*)a.final_obs)[(int64_t)i * OD + k] = o[k];
-                }
+            for (int k = 0; k < OD; ++k) {
+                const int64_t idx = (a.obs_layout == LAYOUT_SOA) ? (int64_t)k * n + i : (int64_t)i * OD + k;
+                if (a.obs_bf16) ((uint16_t*)a.final_obs)[idx] = f2bf(out.o[k]);
+                else ((float*)a.final_obs)[idx] = out.o[k];
             }
         }
         const uint32_t ep = (uint32_t)a.episode[i];
         a.episode[i] = (int)(ep + 1u);
-        float eta[3], nu[3];
-        sample_reset<MODE>(a, a.env_id_base + i, ep, eta, nu);
-        N = eta[0]; E = eta[1]; psi = eta[2]; u = nu[0]; v = nu[1]; r = nu[2];
-        pt_new[0] = pt_new[1] = pt_new[2] = 0.0f;                    // ENV:190
-        default_angles<MODE>(ang[0], ang[1], ang[2]);                // ENV:173-177,192
-        steps = 0;
+        env_auto_reset<MODE>(a, s, a.env_id_base + i, ep, o_next);
         rf_dirty = true;
-        make_obs(N, E, psi, u, v, r, refN, refE, refPsi, pt_new, deg, o_out);
     }
 
     // ---- stores ---------------------------------------------------------------------------------
+    store_obs<OD>(a, a.obs, o_next, i, live, lds_io);
     if (live) {
-        a.S0[i] = make_float4(N, E, psi, u);
-        a.S1[i] = make_float4(v, r, ang[1], ang[2]);
-        a.S2[i] = make_float4(pt_new[0], pt_new[1], pt_new[2], __int_as_float(steps));
-        if (rf_dirty) a.RF[i] = make_float4(refN, refE, refPsi, ang[0]);
-        a.rew[i] = reward;
-        a.done[i] = (uint8_t)d;
+        store_env(a, i, s, rf_dirty);
+        a.rew[i] = out.reward;
+        a.done[i] = (uint8_t)out.d;
         if (a.parts) {
-            a.parts[i] = p_vel; a.parts[(int64_t)n + i] = p_pos;
-            a.parts[2 * (int64_t)n + i] = p_thr; a.parts[3 * (int64_t)n + i] = p_der;
+            a.parts[i] = out.parts[0]; a.parts[(int64_t)n + i] = out.parts[1];
+            a.parts[2 * (int64_t)n + i] = out.parts[2]; a.parts[3 * (int64_t)n + i] = out.parts[3];
         }
     }
-    store_obs<OD>(a, a.obs, o_out, i, live, lds_io);
+}
+
+// =============================================================================================
+//  fused rollout: one launch = T steps of every env, state resident in registers.
+//  Same semantics as T successive step_kernel launches with actions[t] (and refs[k] passed as
+//  new_ref at step switch_step[k]); per env-step only the action row is read and the
+//  observation / reward / done row written (69 B instead of 177 B).
+//  One wave per workgroup: the LDS transposes are wave-private, barriers are free.
+// =============================================================================================
+template <int MODE, bool EXT, bool PER_CLASS>
+__global__ __launch_bounds__(RBLOCK) void rollout_kernel(const StepArgs a, const RolloutArgs ra)
+{
+    constexpr int A = ModeTraits<MODE>::A;
+    constexpr int OD = EXT ? 9 : 6;
+    __shared__ float lds_act[RBLOCK * 7];
+    __shared__ float lds_obs[RBLOCK * 9];
+    __shared__ float lds_cls[PER_CLASS ? VD_COUNT * MAX_CLASSES : 1];
+
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * RBLOCK + tid;
+    const int n = a.n;
+    const bool live = i < n;
+    const int il = live ? i : n - 1;
+
+    Env s;
+    load_env(a, il, s);
+    float vcN = 0.0f, vcE = 0.0f;
+    if (a.cur_vc) {
+        float sb, cb;
+        sincosf(a.cur_beta[il], &sb, &cb);
+        const float vc = a.cur_vc[il];
+        vcN = vc * cb; vcE = vc * sb;
+    }
+    int cls = 0;
+    if (PER_CLASS) {
+        cls = a.class_id[il];
+        for (int k = tid; k < VD_COUNT * a.n_classes; k += RBLOCK) {
+            const int c = k / VD_COUNT, p = k - c * VD_COUNT;
+            lds_cls[p * a.n_classes + c] = a.class_tab[k];
+        }
+        lds_order<RBLOCK>();
+    }
+    const Vessel ve = PER_CLASS ? vessel_from_lds(lds_cls, a.n_classes, cls) : vessel_from_args(a.v0);
+    uint32_t episode = a.auto_reset ? (uint32_t)a.episode[il] : 0u;
+    bool ep_dirty = false, rf_dirty = (MODE == MODE_FULL);
+
+    const int64_t step_stride_act = (int64_t)n * A;
+    const int64_t step_stride_obs = (int64_t)n * OD;
+    const int64_t blk_act = (int64_t)blockIdx.x * (RBLOCK * A);
+    const int64_t blk_obs = (int64_t)blockIdx.x * (RBLOCK * OD);
+
+    // software pipeline: the action row of step t+1 is in flight while step t computes
+    float pre[A];
+    auto fetch = [&](int t) {
+        const float* src = ra.actions + (int64_t)t * step_stride_act;   // uniform
+        if (a.action_layout == LAYOUT_AOS) {
+            load_rows<A, RBLOCK>(src + blk_act, step_stride_act - blk_act, tid, pre);
+        } else {
+#pragma unroll
+            for (int k = 0; k < A; ++k) pre[k] = src[(int64_t)k * n + il];
+        }
+    };
+    fetch(0);
+    int next_switch = 0;
+    for (int t = 0; t < ra.T; ++t) {
+        float act[A];
+        if (a.action_layout == LAYOUT_AOS) {
+            lds_order<RBLOCK>();
+#pragma unroll
+            for (int j = 0; j < A; ++j) lds_act[j * RBLOCK + tid] = pre[j];
+            lds_order<RBLOCK>();
+#pragma unroll
+            for (int k = 0; k < A; ++k) act[k] = lds_act[tid * A + k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < A; ++k) act[k] = pre[k];
+        }
+        if (t + 1 < ra.T) fetch(t + 1);
+
+        bool has_ref = false;
+        float nrN = 0.0f, nrE = 0.0f, nrP = 0.0f;
+        if (next_switch < ra.n_switch && ra.switch_step[next_switch] == t) {   // wave-uniform
+            const float* rp = ra.refs + (int64_t)next_switch * 3 * n;
+            nrN = rp[il]; nrE = rp[(int64_t)n + il]; nrP = rp[2 * (int64_t)n + il];
+            has_ref = true; rf_dirty = true;
+            ++next_switch;
+        }
+        StepOut out;
+        env_step<MODE, EXT>(a, ve, s, act, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, vcN, vcE, out);
+        float o_next[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o_next[k] = out.o[k];
+        if (a.auto_reset && out.d != 0u && live) {
+            env_auto_reset<MODE>(a, s, a.env_id_base + i, episode, o_next);
+            ++episode; ep_dirty = true; rf_dirty = true;
+        }
+        if (live) {
+            (ra.rew + (int64_t)t * n)[(unsigned)i] = out.reward;          // uniform row base + lane offset
+            (ra.done + (int64_t)t * n)[(unsigned)i] = (uint8_t)out.d;
+        }
+        // observation row -> [T][n][OD] through the wave-private LDS transpose
+        if (a.obs_layout == LAYOUT_SOA) {
+            if (live) {
+#pragma unroll
+                for (int k = 0; k < OD; ++k) {
+                    const int64_t idx = (int64_t)t * step_stride_obs + (int64_t)k * n + i;
+                    if (a.obs_bf16) ((uint16_t*)ra.obs)[idx] = f2bf(o_next[k]);
+                    else ((float*)ra.obs)[idx] = o_next[k];
+                }
+            }
+        } else {
+            lds_order<RBLOCK>();
+#pragma unroll
+            for (int k = 0; k < OD; ++k) lds_obs[tid * OD + k] = o_next[k];
+            lds_order<RBLOCK>();
+            store_rows<OD, RBLOCK>(ra.obs, (int64_t)t * step_stride_obs + blk_obs, step_stride_obs - blk_obs, a.obs_bf16,
+                                   lds_obs, tid);
+        }
+    }
+    if (live) {
+        store_env(a, i, s, rf_dirty);
+        if (ep_dirty) a.episode[i] = (int)episode;
+    }
 }
 
 // =============================================================================================
@@ -628,6 +840,33 @@ extern "C" hipError_t dpenv_dev_launch_step(const StepArgs* a, int mode, int ext
     case MODE_LIMITED: return launch_step_mode<MODE_LIMITED>(*a, ext, per_class, s);
     case MODE_FINAL_WRAP: return launch_step_mode<MODE_FINAL_WRAP>(*a, ext, per_class, s);
     case MODE_FINAL_CONT: return launch_step_mode<MODE_FINAL_CONT>(*a, ext, per_class, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+template <int MODE>
+static hipError_t launch_rollout_mode(const StepArgs& a, const RolloutArgs& ra, bool ext, bool per_class, hipStream_t s)
+{
+    const dim3 grid((a.n + RBLOCK - 1) / RBLOCK), block(RBLOCK);
+    if (ext) {
+        if (per_class) hipLaunchKernelGGL((rollout_kernel<MODE, true, true>), grid, block, 0, s, a, ra);
+        else hipLaunchKernelGGL((rollout_kernel<MODE, true, false>), grid, block, 0, s, a, ra);
+    } else {
+        if (per_class) hipLaunchKernelGGL((rollout_kernel<MODE, false, true>), grid, block, 0, s, a, ra);
+        else hipLaunchKernelGGL((rollout_kernel<MODE, false, false>), grid, block, 0, s, a, ra);
+    }
+    return hipGetLastError();
+}
+
+extern "C" hipError_t dpenv_dev_launch_rollout(const StepArgs* a, const RolloutArgs* ra, int mode, int ext, int per_class,
+                                               hipStream_t s)
+{
+    switch (mode) {
+    case MODE_FULL: return launch_rollout_mode<MODE_FULL>(*a, *ra, ext, per_class, s);
+    case MODE_SIMPLE: return launch_rollout_mode<MODE_SIMPLE>(*a, *ra, ext, per_class, s);
+    case MODE_LIMITED: return launch_rollout_mode<MODE_LIMITED>(*a, *ra, ext, per_class, s);
+    case MODE_FINAL_WRAP: return launch_rollout_mode<MODE_FINAL_WRAP>(*a, *ra, ext, per_class, s);
+    case MODE_FINAL_CONT: return launch_rollout_mode<MODE_FINAL_CONT>(*a, *ra, ext, per_class, s);
     }
     return hipErrorInvalidValue;
 }

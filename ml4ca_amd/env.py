@@ -253,6 +253,43 @@ class BatchedRevoltEnv(object):
         _lib.check(self.lib.dpenv_step_ex(self._h, C.byref(io), self._stream()), self._h)
         return obs, rew, done, {'None': 0}
 
+    def rollout(self, actions, switch_steps=(), refs=None, out=None):
+        """T env steps in one launch (dpenv_rollout): exactly T successive step() calls with actions[t], passing
+        refs[k] as new_ref at step switch_steps[k] (setpoint sequences, test_policy.py:127,148-153), but with the
+        state kept in registers between steps.  actions: float32 [T, n, act_dim] (or [T, act_dim, n] for 'soa').
+        Returns (obs [T, n, obs_dim], reward [T, n], done_bits [T, n]); obs[t] is what step t returned."""
+        torch = _torch()
+        T = int(actions.shape[0])
+        n = self.n_envs
+        self._chk(actions, (T,) + self.action_shape, torch.float32, 'actions')
+        k = len(switch_steps)
+        if k > 8:
+            raise ValueError('at most 8 setpoint switches per rollout launch')
+        if k:
+            self._chk(refs, (k, 3, n), torch.float32, 'refs')
+        if out is None:
+            obs = torch.empty((T,) + self.obs_shape, dtype=self.obs_torch_dtype, device=self.device)
+            rew = torch.empty((T, n), dtype=torch.float32, device=self.device)
+            done = torch.empty((T, n), dtype=torch.uint8, device=self.device)
+        else:
+            obs, rew, done = out
+            self._chk(obs, (T,) + self.obs_shape, self.obs_torch_dtype, 'out[0]')
+            self._chk(rew, (T, n), torch.float32, 'out[1]')
+            self._chk(done, (T, n), torch.uint8, 'out[2]')
+        io = _lib.RolloutIO()
+        io.struct_size = C.sizeof(_lib.RolloutIO)
+        io.T = T
+        io.actions = actions.data_ptr()
+        io.obs = obs.data_ptr()
+        io.reward = rew.data_ptr()
+        io.done = done.data_ptr()
+        io.n_switch = k
+        for j, st in enumerate(switch_steps):
+            io.switch_step[j] = int(st)
+        io.refs = refs.data_ptr() if k else None
+        _lib.check(self.lib.dpenv_rollout(self._h, C.byref(io), self._stream()), self._h)
+        return obs, rew, done
+
     # -- state access (parity tests, checkpoints) ----------------------------------------------
     def get_state(self):
         torch = _torch()

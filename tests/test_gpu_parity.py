@@ -497,6 +497,79 @@ def test_full_size_physical_properties():
 
 
 # --------------------------------------------------------------------------------------------
+# fused rollout == T single steps
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('mode,ext,layout,kw', [
+    ('final_cont', True, 'aos', dict(auto_reset=True, max_ep_len=30, seed=4)),
+    ('final_cont', True, 'soa', dict(auto_reset=True, max_ep_len=30, seed=4)),
+    ('final_cont', True, 'aos', dict(terminate=False, time_limit=False, current=True)),
+    ('final_cont', True, 'aos', dict(obs_dtype='bfloat16', auto_reset=True, max_ep_len=30)),
+    ('final_wrap', False, 'aos', dict(auto_reset=True, max_ep_len=30)),
+    ('full', True, 'aos', dict(auto_reset=True, max_ep_len=30)),
+    ('limited', True, 'soa', dict()),
+    ('simple', False, 'aos', dict(auto_reset=True, max_ep_len=30)),
+])
+def test_fused_rollout_equals_single_steps(mode, ext, layout, kw):
+    """dpenv_rollout(T) must reproduce T dpenv_step calls bit for bit: outputs, setpoint switches, auto-resets,
+    final state and counters."""
+    torch = torch_()
+    n, T = 3000 + 17, 37
+    rng = np.random.RandomState(31)
+    e1, orc = H.make_pair(mode, n, ext=ext, layout=layout, **kw)
+    e2, _ = H.make_pair(mode, n, ext=ext, layout=layout, **kw)
+    A = orc.act_dim
+    acts = rng.normal(0, 0.8, size=(T, n, A)).astype(np.float32)
+    acts_dev = H.to_dev(acts if layout == 'aos' else np.ascontiguousarray(acts.transpose(0, 2, 1)))
+    st = H.to_dev(H.random_state(rng, n, spread=0.5))
+    ctr = H.to_dev(np.zeros((2, n), np.int32))
+    switch = (0, 5, 20, T - 1)
+    refs = H.to_dev(rng.uniform(-3, 3, size=(len(switch), 3, n)).astype(np.float32))
+    if kw.get('current'):
+        vc = H.to_dev((0.2 + 0.05 * rng.normal(size=n)).astype(np.float32))
+        beta = H.to_dev(rng.uniform(-3, 3, size=n).astype(np.float32))
+        e1.set_current(vc, beta)
+        e2.set_current(vc, beta)
+    e1.set_state(st, ctr)
+    e2.set_state(st, ctr)
+    obs_r, rew_r, done_r = e2.rollout(acts_dev, switch_steps=switch, refs=refs)
+    for t in range(T):
+        nr = refs[switch.index(t)] if t in switch else None
+        o, r, d, _ = e1.step(acts_dev[t], new_ref=nr)
+        assert torch.equal(o, obs_r[t]), 'obs t=%d' % t
+        assert torch.equal(r, rew_r[t]), 'reward t=%d' % t
+        assert torch.equal(d, done_r[t]), 'done t=%d' % t
+    s1, c1 = e1.get_state()
+    s2, c2 = e2.get_state()
+    assert torch.equal(s1, s2) and torch.equal(c1, c2)
+    if kw.get('auto_reset'):
+        assert int(c1[1].min()) >= 1          # every env was re-sampled at least once
+    # and the first step of the fused launch matches the oracle like any single step
+    ost, octr = st.cpu().numpy().copy(), ctr.cpu().numpy().copy()
+    if not kw.get('current'):
+        oo, orw, od_ = orc.step(ost, octr, acts[0], new_ref=refs[0].cpu().numpy())
+        got = obs_r[0].float().cpu().numpy()
+        if layout == 'soa':
+            got = got.T
+        keep = od_ == 0 if kw.get('auto_reset') else np.ones(n, bool)
+        tol_rt = 8e-3 if kw.get('obs_dtype') == 'bfloat16' else TOL.RTOL_F32
+        TOL.assert_close(got[keep], oo[keep], TOL.OBS_FLOOR[:orc.obs_dim], rtol=tol_rt, what='rollout step 0 vs oracle')
+        TOL.assert_close(rew_r[0].cpu().numpy(), orw, TOL.REWARD_FLOOR, what='rollout reward 0 vs oracle')
+
+
+def test_rollout_argument_validation():
+    import ml4ca_amd
+    torch = torch_()
+    env, _ = H.make_pair('final_cont', 64)
+    a = torch.zeros((4, 64, 7), device=env.device)
+    with pytest.raises(ml4ca_amd.DpenvError):
+        env.rollout(a, switch_steps=(2, 1), refs=torch.zeros((2, 3, 64), device=env.device))
+    with pytest.raises(ml4ca_amd.DpenvError):
+        env.rollout(a, switch_steps=(4,), refs=torch.zeros((1, 3, 64), device=env.device))
+    with pytest.raises(ValueError):
+        env.rollout(torch.zeros((4, 64, 6), device=env.device))
+
+
+# --------------------------------------------------------------------------------------------
 # single-env adapter = the reference's Gym API
 # --------------------------------------------------------------------------------------------
 def test_single_env_adapter_runs_a_spinup_style_loop():

@@ -84,11 +84,63 @@ template <int MODE> __device__ __forceinline__ void default_angles(float& a_bow,
 __device__ __forceinline__ float wrap_angle(float x, bool deg)
 {
     const float ref = deg ? 180.0f : kPi;
-    const float k = floorf((x + ref) / (2.0f * ref));
-    return x - k * (2.0f * ref);
+    const float inv = deg ? (1.0f / 360.0f) : (0.5f / kPi);
+    const float k = floorf((x + ref) * inv);
+    return fmaf(-k, 2.0f * ref, x);
 }
 
 __device__ __forceinline__ float clipf(float v, float b) { return fminf(fmaxf(v, -b), b); }
+
+// ---- lean transcendental code (validated in tools/lean_math_check.py against float64 libm) -------------
+// sincos: 3-constant Cody-Waite reduction by pi/2 + degree-7/6 kernels (Cephes single-precision
+// coefficients); max abs error 9.2e-8 for |x| <= 3e4 (a heading of 4775 turns).  Larger arguments - where a
+// float heading has lost all sub-radian meaning anyway - are first folded by 2 pi in plain fp32 so that the
+// result stays a valid (if inaccurate) rotation; no library call, so the kernels stay call-free.
+__device__ __forceinline__ void sincos_lean(float x, float& s, float& c)
+{
+    if (__builtin_expect(fabsf(x) > 30000.0f, 0)) x = fmaf(-rintf(x * (0.5f / kPi)), 2.0f * kPi, x);
+    const float kf = rintf(x * 0.6366197723675814f);
+    float r = fmaf(kf, -1.5703125f, x);
+    r = fmaf(kf, -4.837512969970703125e-4f, r);
+    r = fmaf(kf, -7.54978995489188216e-8f, r);
+    const float r2 = r * r;
+    float p = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    p = fmaf(r2, p, -1.6666654611e-1f);
+    const float sv = fmaf(r * r2, p, r);
+    float q = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    q = fmaf(r2, q, 4.166664568298827e-2f);
+    const float cv = fmaf(r2 * r2, q, fmaf(r2, -0.5f, 1.0f));
+    const int n = (int)kf;
+    const float so = (n & 1) ? cv : sv;
+    const float co = (n & 1) ? sv : cv;
+    s = (n & 2) ? -so : so;
+    c = ((n + 1) & 2) ? -co : co;
+}
+
+// atan2: a = min/max in [0,1], odd polynomial of degree 17 in a (coefficients fitted in
+// tools/lean_math_check.py: max abs error 2.6e-7, 2 ulp), octant fix-up, sign of y (signed zeros kept:
+// atan2(-0, -1) = -pi like numpy's arctan2, which customEnv.py:231-232 calls).
+__device__ __forceinline__ float atan2_lean(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float a = (mx == 0.0f) ? 0.0f : mn * __builtin_amdgcn_rcpf(mx);
+    const float s = a * a;
+    float r = 2.6222818114e-03f;
+    r = fmaf(r, s, -1.5132710144e-02f);
+    r = fmaf(r, s, 4.1122186800e-02f);
+    r = fmaf(r, s, -7.3667379326e-02f);
+    r = fmaf(r, s, 1.0573949200e-01f);
+    r = fmaf(r, s, -1.4185980238e-01f);
+    r = fmaf(r, s, 1.9990397277e-01f);
+    r = fmaf(r, s, -3.3332987079e-01f);
+    r = fmaf(r * s, a, a);
+    r = (ay > ax) ? (kPi * 0.5f - r) : r;
+    r = (__float_as_uint(x) >> 31) ? (kPi - r) : r;
+    return copysignf(r, y);
+}
+
+__device__ __forceinline__ float sqrt_hw(float x) { return __builtin_amdgcn_sqrtf(x); }   // v_sqrt_f32, <= 1 ulp
 
 struct Vessel {
     float m11, m22, m23, inv11, i22, i23, i33;
@@ -141,7 +193,13 @@ __device__ __forceinline__ void thrust_map(const Vessel& ve, const float n[3], c
         const float K = (n[i] >= 0.0f) ? ve.Kf[i] : ve.Kr[i];
         const float F = K * fabsf(n[i]) * n[i];
         float sa, ca;
-        sincosf(al[i], &sa, &ca);
+        if (i == 0 && al[0] == kPi * 0.5f) {
+            // the bow thruster sits at its reset default pi/2 in simple/limited/final (customEnv.py:397):
+            // sin/cos of float(pi/2), no evaluation needed
+            sa = 1.0f; ca = -4.371139e-08f;
+        } else {
+            sincos_lean(al[i], sa, ca);
+        }
         tx = fmaf(ca, F, tx);
         ty = fmaf(sa, F, ty);
         tn = fmaf(fmaf(ve.lx[i], sa, -(ve.ly[i] * ca)), F, tn);
@@ -150,12 +208,13 @@ __device__ __forceinline__ void thrust_map(const Vessel& ve, const float n[3], c
 
 // observation, errorFrame.py:25-32 + ENV:196-205
 __device__ __forceinline__ void make_obs(float N, float E, float psi, float u, float v, float r, float refN, float refE,
-                                         float refPsi, const float pt[3], bool deg, float o[9])
+                                         float refPsi, const float pt[3], bool deg, float o[9], float& sr, float& cr,
+                                         bool& rot_is_psi)
 {
     const float eN = N - refN, eE = E - refE;
     const float rot = wrap_angle(psi, deg);
-    float sr, cr;
-    sincosf(rot, &sr, &cr);
+    rot_is_psi = (rot == psi);     // true unless the (degree-mode) wrap fired: sr, cr are then sin/cos of psi itself
+    sincos_lean(rot, sr, cr);
     o[0] = fmaf(cr, eN, sr * eE);
     o[1] = fmaf(cr, eE, -(sr * eN));
     o[2] = wrap_angle(psi - refPsi, deg);
@@ -282,6 +341,7 @@ struct Env {              // per-lane state carried between env steps
     float pt[3];          // previous thrust command, percent (ENV:126)
     float ang[3];         // azimuth command in force: bow, port, star (ENV:122)
     int steps;            // steps taken in the running episode
+    float sn, cs;         // sin/cos of psi (cache: refreshed by every observation, reused by the next plant step)
 };
 
 struct StepOut {
@@ -316,15 +376,14 @@ __device__ __forceinline__ void env_step(const StepArgs& a, const Vessel& ve, En
         s.ang[1] = clipf(w3 * kPi, kPi); s.ang[2] = clipf(w4 * kPi, kPi);
     } else if (MODE == MODE_FINAL_CONT) {
         // ENV:227-235: atan2(sin_head, cos_head)/pi, then *pi and clip
-        s.ang[1] = clipf(atan2f(act[3], act[4]), kPi); s.ang[2] = clipf(atan2f(act[5], act[6]), kPi);
+        s.ang[1] = clipf(atan2_lean(act[3], act[4]), kPi); s.ang[2] = clipf(atan2_lean(act[5], act[6]), kPi);
     }
 
     // ---- plant: BUILD-OWNED 3-DOF model, n_substeps semi-implicit Euler steps --
     float tx, ty, tn;
     thrust_map(ve, thr, s.ang, tx, ty, tn);
     float N = s.N, E = s.E, psi = s.psi, u = s.u, v = s.v, r = s.r;
-    float sn, cs;
-    sincosf(psi, &sn, &cs);
+    float sn = s.sn, cs = s.cs;
     if (cur) {
         u -= fmaf(cs, vcN, sn * vcE);      // relative velocity nu_r = nu - R(psi)^T v_c
         v -= fmaf(cs, vcE, -(sn * vcN));
@@ -361,25 +420,30 @@ __device__ __forceinline__ void env_step(const StepArgs& a, const Vessel& ve, En
         const float s2n = fmaf(sn, cd, cs * sd);
         cs = c2; sn = s2n;
     }
+    // exact sin/cos of the heading reached: needed by the observation, by the current term and by the next step
+    const bool deg = (a.wrap_mode == WRAP_REFERENCE);
+    float* o = out.o;
+    bool same;
+    float se, ce;
+    {
+        // the observation only depends on nu through o[3..5]; compute the frame first, patch nu after
+        make_obs(N, E, psi, 0.0f, 0.0f, 0.0f, s.refN, s.refE, s.refPsi, pt_old, deg, o, se, ce, same);
+        if (!same) sincos_lean(psi, se, ce);
+    }
     if (cur) {
-        float se, ce;
-        sincosf(psi, &se, &ce);
         u += fmaf(ce, vcN, se * vcE);
         v += fmaf(ce, vcE, -(se * vcN));
     }
+    o[3] = u; o[4] = v; o[5] = r;
     s.N = N; s.E = E; s.psi = psi; s.u = u; s.v = v; s.r = r;
-
-    // ---- observation (previous thrust: quirk Q2), reward, termination --------------------------------
-    const bool deg = (a.wrap_mode == WRAP_REFERENCE);
-    float* o = out.o;
-    make_obs(N, E, psi, u, v, r, s.refN, s.refE, s.refPsi, pt_old, deg, o);
+    s.sn = se; s.cs = ce;
 
     float p_der = 0.0f;
-    const float p_vel = -sqrtf(fmaf(o[3] * o[3], 0.5f, fmaf(o[4] * o[4], 0.5f, o[5] * o[5])));   // ENV:267-273
+    const float p_vel = -sqrt_hw(fmaf(o[3] * o[3], 0.5f, fmaf(o[4] * o[4], 0.5f, o[5] * o[5])));   // ENV:267-273
     const float rr2 = fmaf(o[0], o[0], o[1] * o[1]);
     const float yaw = o[2] * (180.0f / kPi);                                                    // ENV:281
     const float multivar = 2.0f * expf(-0.5f * fmaf(yaw * yaw, 1.0f / 25.0f, rr2));             // ENV:283, covar ENV:86-88
-    const float special = sqrtf(fmaf(yaw * 0.25f, yaw * 0.25f, rr2));                           // ENV:287
+    const float special = sqrt_hw(fmaf(yaw * 0.25f, yaw * 0.25f, rr2));                         // ENV:287
     const float p_pos = multivar + fmaxf(-1.0f, fmaf(-0.1f, special, 1.0f)) + 0.5f;             // ENV:288-290
     const float p_thr = -(fabsf(thr[0]) * 0.20f + fabsf(thr[1]) * 0.30f + fabsf(thr[2]) * 0.30f) * 0.01f;   // ENV:292-302
     if (EXT) {
@@ -425,7 +489,10 @@ __device__ __forceinline__ void env_auto_reset(const StepArgs& a, Env& s, int64_
     s.pt[0] = s.pt[1] = s.pt[2] = 0.0f;                         // ENV:190
     default_angles<MODE>(s.ang[0], s.ang[1], s.ang[2]);         // ENV:173-177,192
     s.steps = 0;
-    make_obs(s.N, s.E, s.psi, s.u, s.v, s.r, s.refN, s.refE, s.refPsi, s.pt, a.wrap_mode == WRAP_REFERENCE, o_new);
+    bool same;
+    make_obs(s.N, s.E, s.psi, s.u, s.v, s.r, s.refN, s.refE, s.refPsi, s.pt, a.wrap_mode == WRAP_REFERENCE, o_new, s.sn, s.cs,
+             same);
+    if (!same) sincos_lean(s.psi, s.sn, s.cs);
 }
 
 __device__ __forceinline__ void load_env(const StepArgs& a, int il, Env& s)
@@ -473,12 +540,13 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const StepArgs a)
     }
     Env s;
     load_env(a, il, s);
+    sincos_lean(s.psi, s.sn, s.cs);
     float nrN = 0.0f, nrE = 0.0f, nrP = 0.0f;
     if (a.new_ref) { nrN = a.new_ref[il]; nrE = a.new_ref[(int64_t)n + il]; nrP = a.new_ref[2 * (int64_t)n + il]; }
     float vcN = 0.0f, vcE = 0.0f;
     if (a.cur_vc) {
         float sb, cb;
-        sincosf(a.cur_beta[il], &sb, &cb);
+        sincos_lean(a.cur_beta[il], sb, cb);
         const float vc = a.cur_vc[il];
         vcN = vc * cb; vcE = vc * sb;
     }
@@ -562,10 +630,11 @@ __global__ __launch_bounds__(RBLOCK) void rollout_kernel(const StepArgs a, const
 
     Env s;
     load_env(a, il, s);
+    sincos_lean(s.psi, s.sn, s.cs);
     float vcN = 0.0f, vcE = 0.0f;
     if (a.cur_vc) {
         float sb, cb;
-        sincosf(a.cur_beta[il], &sb, &cb);
+        sincos_lean(a.cur_beta[il], sb, cb);
         const float vc = a.cur_vc[il];
         vcN = vc * cb; vcE = vc * sb;
     }
@@ -700,7 +769,9 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(const StepArgs a, const ui
     if (a.obs) {
         const float pt[3] = {s2.x, s2.y, s2.z};
         float o[9];
-        make_obs(s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, rf.x, rf.y, rf.z, pt, a.wrap_mode == WRAP_REFERENCE, o);
+        float sr_, cr_;
+        bool same_;
+        make_obs(s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, rf.x, rf.y, rf.z, pt, a.wrap_mode == WRAP_REFERENCE, o, sr_, cr_, same_);
         store_obs<OD>(a, a.obs, o, i, live, lds_io);
     }
 }

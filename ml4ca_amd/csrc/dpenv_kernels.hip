@@ -163,6 +163,20 @@ __device__ __forceinline__ Vessel vessel_from_args(const VesselDev& d)
     return v;
 }
 
+// Keep the (wave-uniform) parameter block in VGPRs.  gfx9 VALU instructions read at most one SGPR, so
+// two-parameter FMAs need a v_mov each time they execute, and 31 live SGPR parameters push the long
+// rollout loop into SGPR->VGPR-lane spills (v_writelane/v_readlane).  An empty asm with a "+v" constraint
+// pins each value in a vector register once.
+__device__ __forceinline__ void pin_vgpr(float& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin_vessel_in_vgprs(Vessel& v)
+{
+    pin_vgpr(v.m11); pin_vgpr(v.m22); pin_vgpr(v.m23); pin_vgpr(v.inv11); pin_vgpr(v.i22); pin_vgpr(v.i23); pin_vgpr(v.i33);
+    pin_vgpr(v.Xu); pin_vgpr(v.Xuu); pin_vgpr(v.Yv); pin_vgpr(v.Yvv); pin_vgpr(v.Yr); pin_vgpr(v.Nv); pin_vgpr(v.Nr);
+    pin_vgpr(v.Nrr); pin_vgpr(v.Nuv); pin_vgpr(v.Yur);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { pin_vgpr(v.Kf[i]); pin_vgpr(v.Kr[i]); pin_vgpr(v.lx[i]); pin_vgpr(v.ly[i]); }
+}
+
 // LDS image of the class table is [param][class]: for a fixed parameter, lanes of different
 // classes hit different banks (n_classes <= 32 distinct banks) and lanes of one class broadcast.
 __device__ __forceinline__ Vessel vessel_from_lds(const float* tab, int ncls, int cls)
@@ -390,19 +404,20 @@ __device__ __forceinline__ void env_step(const StepArgs& a, const Vessel& ve, En
     }
     const float h = a.h;
     const float hA = h * ve.inv11, h22 = h * ve.i22, h23 = h * ve.i23, h33 = h * ve.i33;
+    // the Coriolis term c23 = m11 u only ever multiplies r (sway) and v (yaw): fold it into the
+    // speed-proportional cross-flow coefficients so that it costs nothing per sub-step
+    const float yur = ve.Yur + ve.m11;      // fy gets -(Yr + (Yur + m11) u) r
+    const float nuv = ve.Nuv - ve.m11;      // fn gets -(Nv + (Nuv - m11) u) v
     const int nsub = a.hold_plant ? 0 : a.n_substeps;
     for (int k = 0; k < nsub; ++k) {
-        // C(nu)nu with c13 = -q, q = m22 v + m23 r; c23 = m11 u
+        // C(nu)nu with c13 = -q, q = m22 v + m23 r
         const float q = fmaf(ve.m22, v, ve.m23 * r);
-        const float c23 = ve.m11 * u;
         float fx = fmaf(-fmaf(ve.Xuu, fabsf(u), ve.Xu), u, tx);
         fx = fmaf(q, r, fx);
         float fy = fmaf(-fmaf(ve.Yvv, fabsf(v), ve.Yv), v, ty);
-        fy = fmaf(-fmaf(ve.Yur, u, ve.Yr), r, fy);
-        fy = fmaf(-c23, r, fy);
+        fy = fmaf(-fmaf(yur, u, ve.Yr), r, fy);
         float fn = fmaf(-q, u, tn);
-        fn = fmaf(c23, v, fn);
-        fn = fmaf(-fmaf(ve.Nuv, u, ve.Nv), v, fn);
+        fn = fmaf(-fmaf(nuv, u, ve.Nv), v, fn);
         fn = fmaf(-fmaf(ve.Nrr, fabsf(r), ve.Nr), r, fn);
         u = fmaf(hA, fx, u);
         v = fmaf(h22, fy, fmaf(h23, fn, v));
@@ -647,7 +662,8 @@ __global__ __launch_bounds__(RBLOCK) void rollout_kernel(const StepArgs a, const
         }
         lds_order<RBLOCK>();
     }
-    const Vessel ve = PER_CLASS ? vessel_from_lds(lds_cls, a.n_classes, cls) : vessel_from_args(a.v0);
+    Vessel ve = PER_CLASS ? vessel_from_lds(lds_cls, a.n_classes, cls) : vessel_from_args(a.v0);
+    if (!PER_CLASS) pin_vessel_in_vgprs(ve);
     uint32_t episode = a.auto_reset ? (uint32_t)a.episode[il] : 0u;
     bool ep_dirty = false, rf_dirty = (MODE == MODE_FULL);
 

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile_round.sh output directory into profiles/<tag>_*.{csv,json}."""
+import collections
+import csv
+import glob
+import json
+import shutil
+import statistics as st
+import sys
+
+tag = sys.argv[1]
+src = 'gpurun_out/prof_%s' % tag
+out = {'tag': tag, 'n_envs': 65536,
+       'commands': {'kernel_trace': 'rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline',
+                    'pmc': 'rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ_*> --output-format csv -- python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline (one pass per counter set)'},
+       'correction': 'gfx950: FETCH_SIZE tallies 128-B requests of wide coalesced reads at 64 B -> x2 (MI355X_MICROARCH.md, HBM); '
+                     'WRITE_SIZE exact; both in KiB', 'kernels': {}}
+shutil.copy(glob.glob(src + '/kt/*/*_kernel_stats.csv')[0], 'profiles/%s_kernel_stats.csv' % tag)
+rows = list(csv.DictReader(open(glob.glob(src + '/kt/*/*_kernel_trace.csv')[0])))
+
+
+def kname(k):
+    return 'step_kernel' if 'step_kernel' in k else 'rollout_kernel' if 'rollout_kernel' in k else None
+
+
+for kn in ('step_kernel', 'rollout_kernel'):
+    ks = [r for r in rows if kname(r['Kernel_Name']) == kn]
+    if not ks:
+        continue
+    d = [int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in ks]
+    out['kernels'][kn] = {'full_name': ks[0]['Kernel_Name'], 'dispatches': len(d), 'avg_ns': st.mean(d), 'median_ns': st.median(d),
+                          'min_ns': min(d), 'max_ns': max(d), 'vgpr': ks[0]['VGPR_Count'], 'sgpr': ks[0]['SGPR_Count'],
+                          'lds_bytes': ks[0]['LDS_Block_Size'], 'workgroup': ks[0]['Workgroup_Size_X'], 'grid': ks[0]['Grid_Size_X']}
+for name in ('pmc_fetch', 'pmc_write', 'pmc_sq'):
+    f = glob.glob(src + '/%s/*/*_counter_collection.csv' % name)
+    if not f:
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f[0])):
+        kn = kname(r['Kernel_Name'])
+        if kn:
+            agg[(kn, r['Counter_Name'])].append(float(r['Counter_Value']))
+    for (kn, c), v in agg.items():
+        out['kernels'].setdefault(kn, {}).setdefault('pmc_median_per_launch', {})[c] = st.median(v)
+steps_per_launch = {'step_kernel': 1, 'rollout_kernel': 50}
+for kn, k in out['kernels'].items():
+    p = k.get('pmc_median_per_launch', {})
+    if 'FETCH_SIZE' in p and 'WRITE_SIZE' in p:
+        k['hbm_bytes_per_launch'] = (2 * p['FETCH_SIZE'] + p['WRITE_SIZE']) * 1024
+        k['hbm_bytes_per_env_step'] = k['hbm_bytes_per_launch'] / 65536 / steps_per_launch[kn]
+    if 'SQ_WAVES' in p:
+        w = p['SQ_WAVES']
+        k['per_wave_per_env_step'] = {c: p[c] / w / steps_per_launch[kn] for c in p if c.startswith('SQ_') and c != 'SQ_WAVES'}
+    k['algorithmic_bytes_per_launch'] = 177 * 65536 * steps_per_launch[kn]
+try:
+    out['bench_line'] = json.loads(open(src + '/bench_plain.json').read())
+except Exception as e:
+    out['bench_line'] = str(e)
+json.dump(out, open('profiles/%s_summary.json' % tag, 'w'), indent=1)
+if 'step_kernel' in out['kernels'] and 'hbm_bytes_per_launch' in out['kernels']['step_kernel']:
+    json.dump({'n_envs': 65536, 'hbm_bytes_per_launch': out['kernels']['step_kernel']['hbm_bytes_per_launch'],
+               'source': 'profiles/%s_summary.json' % tag}, open('profiles/traffic_latest.json', 'w'))
+print(json.dumps({k: v for k, v in out.items() if k != 'bench_line'}, indent=1))

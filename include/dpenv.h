@@ -109,7 +109,12 @@ typedef struct dpenv_config {
     int32_t hold_plant;      /* 1: hull state is held while the step runs, like Hull.StateResetOn=1
                                 (customEnv.py:164-167); lets parity tests replay the reference's scripted-plant
                                 fixtures through the kernel.  0 in production. */
-    int32_t reserved[6];
+    int32_t current_drift;   /* 1: V_c and beta_c follow a first-order Gauss-Markov process around the values given to
+                                dpenv_set_current (config 5's slowly varying disturbance; build-defined) */
+    float current_tau;       /* correlation time [s], 100 */
+    float current_sigma_v;   /* stationary std of V_c [m/s], 0.02 */
+    float current_sigma_beta;/* stationary std of beta_c [rad], 5 deg */
+    int32_t reserved[2];
 } dpenv_config;
 
 /* Optional outputs / inputs of one step beyond the Gym tuple.  All device pointers, any may be NULL. */
@@ -144,8 +149,11 @@ const char* dpenv_last_error(dpenv_handle h);
 int dpenv_set_reset_fraction(dpenv_handle h, float fraction);
 /* class_id: device int32[n_envs], values in [0, n_classes).  Copied. */
 int dpenv_set_vessel_class(dpenv_handle h, const int32_t* class_id, dpenv_stream s);
-/* vc, beta: device float[n_envs] current speed [m/s] and NED direction [rad].  Copied. */
+/* vc, beta: device float[n_envs] current speed [m/s] and NED direction [rad].  Copied; they are both the
+ * present value and the mean the drift process reverts to. */
 int dpenv_set_current(dpenv_handle h, const float* vc, const float* beta, dpenv_stream s);
+/* present current of every env (differs from the set values only with current_drift) */
+int dpenv_get_current(dpenv_handle h, float* vc_out, float* beta_out, dpenv_stream s);
 
 /* Revolt.reset (customEnv.py:135-194) for the envs selected by mask (device uint8[n], NULL = all).
  * init: device float[6][n] = N, E, psi, u, v, r (the **init override, customEnv.py:141,152), NULL =

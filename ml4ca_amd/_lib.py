@@ -35,7 +35,8 @@ class Config(C.Structure):
                 ('max_ep_len', C.c_int32), ('auto_reset', C.c_int32), ('action_layout', C.c_int32),
                 ('obs_layout', C.c_int32), ('obs_dtype', C.c_int32), ('current_enabled', C.c_int32),
                 ('seed', C.c_uint64), ('env_id_base', C.c_int64), ('reset_fraction', C.c_float),
-                ('hold_plant', C.c_int32), ('reserved', C.c_int32 * 6)]
+                ('hold_plant', C.c_int32), ('current_drift', C.c_int32), ('current_tau', C.c_float),
+                ('current_sigma_v', C.c_float), ('current_sigma_beta', C.c_float), ('reserved', C.c_int32 * 2)]
 
 
 class StepIO(C.Structure):
@@ -63,6 +64,7 @@ SYMBOLS = {
     'dpenv_set_reset_fraction': (C.c_int, [_VP, _F]),
     'dpenv_set_vessel_class': (C.c_int, [_VP, _VP, _VP]),
     'dpenv_set_current': (C.c_int, [_VP, _VP, _VP, _VP]),
+    'dpenv_get_current': (C.c_int, [_VP, _VP, _VP, _VP]),
     'dpenv_reset': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
     'dpenv_step': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     'dpenv_step_ex': (C.c_int, [_VP, C.POINTER(StepIO), _VP]),

@@ -25,6 +25,9 @@ struct dpenv_s {
     size_t blob_bytes;
     float* cur_vc;
     float* cur_beta;
+    float* cur_vc0;
+    float* cur_beta0;
+    uint32_t* drift_ctr;
     int32_t* class_id;
     bool classes_assigned;
     bool current_set;
@@ -77,6 +80,10 @@ extern "C" int dpenv_default_config(dpenv_config* c)
     c->seed = 0;
     c->env_id_base = 0;
     c->reset_fraction = 0.8f;      // customEnv.py:135
+    c->current_drift = 0;
+    c->current_tau = 100.0f;                           // SURVEY 8(d) config 5 (build-defined)
+    c->current_sigma_v = 0.02f;
+    c->current_sigma_beta = 5.0f * 3.14159265358979f / 180.0f;
     return DPENV_OK;
 }
 
@@ -178,6 +185,9 @@ extern "C" int dpenv_create(const dpenv_config* cfg, const float* vessel_params,
         return fail(nullptr, DPENV_EINVAL, "bad layout");
     if (cfg->obs_dtype != DPENV_F32 && cfg->obs_dtype != DPENV_BF16) return fail(nullptr, DPENV_EINVAL, "bad obs_dtype");
     if (cfg->max_ep_len < 0) return fail(nullptr, DPENV_EINVAL, "max_ep_len < 0");
+    if (cfg->current_drift && (!cfg->current_enabled || !(cfg->current_tau > 0.0f) || cfg->current_sigma_v < 0.0f ||
+                               cfg->current_sigma_beta < 0.0f))
+        return fail(nullptr, DPENV_EINVAL, "current_drift needs current_enabled, tau > 0 and non-negative sigmas");
     if (vessel_params == nullptr) n_classes = 1;
     if (n_classes < 1 || n_classes > MAX_CLASSES)
         return fail(nullptr, DPENV_EINVAL, "n_classes must be in [1, %d]", MAX_CLASSES);
@@ -226,6 +236,9 @@ extern "C" int dpenv_create(const dpenv_config* cfg, const float* vessel_params,
     const size_t o_ep = off; off += npad * 4;
     const size_t o_vc = off; off += npad * 4;
     const size_t o_be = off; off += npad * 4;
+    const size_t o_v0 = off; off += npad * 4;
+    const size_t o_b0 = off; off += npad * 4;
+    const size_t o_dc = off; off += npad * 4;
     const size_t o_ci = off; off += npad * 4;
     const size_t o_ct = off; off += align_up(sizeof(VesselDev) * MAX_CLASSES, 256);
     h->blob_bytes = off;
@@ -250,6 +263,8 @@ extern "C" int dpenv_create(const dpenv_config* cfg, const float* vessel_params,
     a.S0 = (float4*)(b + o_s0); a.S1 = (float4*)(b + o_s1); a.S2 = (float4*)(b + o_s2); a.RF = (float4*)(b + o_rf);
     a.episode = (int32_t*)(b + o_ep);
     h->cur_vc = (float*)(b + o_vc); h->cur_beta = (float*)(b + o_be);
+    h->cur_vc0 = (float*)(b + o_v0); h->cur_beta0 = (float*)(b + o_b0);
+    h->drift_ctr = (uint32_t*)(b + o_dc);
     h->class_id = (int32_t*)(b + o_ci);
     a.class_tab = (const float*)(b + o_ct);
     a.n_classes = n_classes;
@@ -266,6 +281,13 @@ extern "C" int dpenv_create(const dpenv_config* cfg, const float* vessel_params,
     a.obs_layout = cfg->obs_layout;
     a.obs_bf16 = (cfg->obs_dtype == DPENV_BF16);
     a.hold_plant = cfg->hold_plant;
+    {
+        const float dt = cfg->substep_dt * (float)cfg->n_substeps;
+        a.current_drift = cfg->current_drift;
+        a.drift_a = cfg->current_drift ? dt / cfg->current_tau : 0.0f;
+        a.drift_sv = cfg->current_drift ? cfg->current_sigma_v * sqrtf(2.0f * dt / cfg->current_tau) : 0.0f;
+        a.drift_sb = cfg->current_drift ? cfg->current_sigma_beta * sqrtf(2.0f * dt / cfg->current_tau) : 0.0f;
+    }
     a.seed_lo = (uint32_t)(cfg->seed & 0xffffffffu);
     a.seed_hi = (uint32_t)(cfg->seed >> 32);
     a.env_id_base = cfg->env_id_base;
@@ -309,7 +331,19 @@ extern "C" int dpenv_set_current(dpenv_handle h, const float* vc, const float* b
     const size_t bytes = sizeof(float) * (size_t)h->cfg.n_envs;
     HIP_TRY(h, hipMemcpyAsync(h->cur_vc, vc, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
     HIP_TRY(h, hipMemcpyAsync(h->cur_beta, beta, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
+    HIP_TRY(h, hipMemcpyAsync(h->cur_vc0, vc, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
+    HIP_TRY(h, hipMemcpyAsync(h->cur_beta0, beta, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
     h->current_set = true;
+    return DPENV_OK;
+}
+
+extern "C" int dpenv_get_current(dpenv_handle h, float* vc_out, float* beta_out, dpenv_stream s)
+{
+    if (!h || !vc_out || !beta_out) return fail(h, DPENV_EINVAL, "dpenv_get_current: NULL argument");
+    if (!h->cfg.current_enabled) return fail(h, DPENV_EINVAL, "config.current_enabled is 0");
+    const size_t bytes = sizeof(float) * (size_t)h->cfg.n_envs;
+    HIP_TRY(h, hipMemcpyAsync(vc_out, h->cur_vc, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
+    HIP_TRY(h, hipMemcpyAsync(beta_out, h->cur_beta, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
     return DPENV_OK;
 }
 
@@ -318,6 +352,9 @@ static void bind_optional(dpenv_handle h, StepArgs& a)
     // current_enabled without dpenv_set_current = zero current (the block is zero-initialised)
     a.cur_vc = h->cfg.current_enabled ? h->cur_vc : nullptr;
     a.cur_beta = h->cfg.current_enabled ? h->cur_beta : nullptr;
+    a.cur_vc0 = h->cur_vc0;
+    a.cur_beta0 = h->cur_beta0;
+    a.drift_ctr = h->drift_ctr;
     a.class_id = h->class_id;
 }
 

@@ -51,8 +51,15 @@ struct StepArgs {
     float* parts;
     void* final_obs;
     // optional per-env inputs owned by the library
-    const float* cur_vc;
-    const float* cur_beta;
+    float* cur_vc;            // present current speed / direction (read-write with drift)
+    float* cur_beta;
+    const float* cur_vc0;     // means the drift reverts to
+    const float* cur_beta0;
+    uint32_t* drift_ctr;      // per-env draw counter of the drift noise
+    int32_t current_drift;
+    float drift_a;            // dt / tau
+    float drift_sv;           // sigma_v * sqrt(2 dt / tau)
+    float drift_sb;           // sigma_beta * sqrt(2 dt / tau)
     const int32_t* class_id;
     const float* class_tab;   // [n_classes][VD_COUNT]
     int32_t n_classes;

@@ -265,6 +265,38 @@ template <int THREADS> __device__ __forceinline__ void lds_order()
     else __syncthreads();
 }
 
+// Current of one env: constant, or a first-order Gauss-Markov (Ornstein-Uhlenbeck) process around its mean,
+// advanced once per env step (config 5; build-defined).  Noise: Philox keyed by the seed,
+// counter (global env id, draw index, tag) -> Box-Muller.
+struct Current {
+    float vc, beta;       // present speed [m/s] and NED direction [rad]
+    float vcN, vcE;       // NED components
+    uint32_t ctr;         // draws made so far
+};
+
+__device__ __forceinline__ void current_components(Current& c)
+{
+    float sb, cb;
+    sincos_lean(c.beta, sb, cb);
+    c.vcN = c.vc * cb; c.vcE = c.vc * sb;
+}
+
+__device__ __forceinline__ void current_drift_step(const StepArgs& a, Current& c, float vc0, float beta0, int64_t gid)
+{
+    uint32_t w[4];
+    philox4x32_10((uint32_t)((uint64_t)gid & 0xffffffffu), (uint32_t)((uint64_t)gid >> 32), c.ctr, 0xC0000000u, a.seed_lo,
+                  a.seed_hi, w);
+    c.ctr += 1u;
+    const float u1 = ((float)(w[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0, 1)
+    const float u2 = (float)(w[1] >> 8) * (1.0f / 16777216.0f);            // [0, 1)
+    const float rad = sqrt_hw(-2.0f * logf(u1));
+    float s2, c2;
+    sincos_lean(2.0f * kPi * u2, s2, c2);
+    c.vc = fmaf(a.drift_sv, rad * c2, fmaf(a.drift_a, vc0 - c.vc, c.vc));
+    c.beta = fmaf(a.drift_sb, rad * s2, fmaf(a.drift_a, beta0 - c.beta, c.beta));
+    current_components(c);
+}
+
 __device__ __forceinline__ uint16_t f2bf(float x)
 {
     // plain cast: v_cvt_pk_bf16_f32 (RNE, NaN stays NaN)
@@ -558,12 +590,12 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const StepArgs a)
     sincos_lean(s.psi, s.sn, s.cs);
     float nrN = 0.0f, nrE = 0.0f, nrP = 0.0f;
     if (a.new_ref) { nrN = a.new_ref[il]; nrE = a.new_ref[(int64_t)n + il]; nrP = a.new_ref[2 * (int64_t)n + il]; }
-    float vcN = 0.0f, vcE = 0.0f;
+    Current cur = {0.0f, 0.0f, 0.0f, 0.0f, 0u};
+    float vc0 = 0.0f, beta0 = 0.0f;
     if (a.cur_vc) {
-        float sb, cb;
-        sincos_lean(a.cur_beta[il], sb, cb);
-        const float vc = a.cur_vc[il];
-        vcN = vc * cb; vcE = vc * sb;
+        cur.vc = a.cur_vc[il]; cur.beta = a.cur_beta[il];
+        if (a.current_drift) { vc0 = a.cur_vc0[il]; beta0 = a.cur_beta0[il]; cur.ctr = a.drift_ctr[il]; }
+        current_components(cur);
     }
     int cls = 0;
     if (PER_CLASS) {
@@ -585,7 +617,11 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const StepArgs a)
     const Vessel ve = PER_CLASS ? vessel_from_lds(lds_cls, a.n_classes, cls) : vessel_from_args(a.v0);
 
     StepOut out;
-    env_step<MODE, EXT>(a, ve, s, act, a.new_ref != nullptr, nrN, nrE, nrP, a.cur_vc != nullptr, vcN, vcE, out);
+    env_step<MODE, EXT>(a, ve, s, act, a.new_ref != nullptr, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out);
+    if (a.current_drift) {
+        current_drift_step(a, cur, vc0, beta0, a.env_id_base + i);
+        if (live) { a.cur_vc[i] = cur.vc; a.cur_beta[i] = cur.beta; a.drift_ctr[i] = cur.ctr; }
+    }
 
     bool rf_dirty = (a.new_ref != nullptr) || (MODE == MODE_FULL);
     float o_next[9];
@@ -646,12 +682,12 @@ __global__ __launch_bounds__(RBLOCK) void rollout_kernel(const StepArgs a, const
     Env s;
     load_env(a, il, s);
     sincos_lean(s.psi, s.sn, s.cs);
-    float vcN = 0.0f, vcE = 0.0f;
+    Current cur = {0.0f, 0.0f, 0.0f, 0.0f, 0u};
+    float vc0 = 0.0f, beta0 = 0.0f;
     if (a.cur_vc) {
-        float sb, cb;
-        sincos_lean(a.cur_beta[il], sb, cb);
-        const float vc = a.cur_vc[il];
-        vcN = vc * cb; vcE = vc * sb;
+        cur.vc = a.cur_vc[il]; cur.beta = a.cur_beta[il];
+        if (a.current_drift) { vc0 = a.cur_vc0[il]; beta0 = a.cur_beta0[il]; cur.ctr = a.drift_ctr[il]; }
+        current_components(cur);
     }
     int cls = 0;
     if (PER_CLASS) {
@@ -709,7 +745,8 @@ __global__ __launch_bounds__(RBLOCK) void rollout_kernel(const StepArgs a, const
             ++next_switch;
         }
         StepOut out;
-        env_step<MODE, EXT>(a, ve, s, act, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, vcN, vcE, out);
+        env_step<MODE, EXT>(a, ve, s, act, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out);
+        if (a.current_drift) current_drift_step(a, cur, vc0, beta0, a.env_id_base + i);
         float o_next[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) o_next[k] = out.o[k];
@@ -743,6 +780,7 @@ __global__ __launch_bounds__(RBLOCK) void rollout_kernel(const StepArgs a, const
     if (live) {
         store_env(a, i, s, rf_dirty);
         if (ep_dirty) a.episode[i] = (int)episode;
+        if (a.current_drift) { a.cur_vc[i] = cur.vc; a.cur_beta[i] = cur.beta; a.drift_ctr[i] = cur.ctr; }
     }
 }
 

@@ -85,7 +85,8 @@ class BatchedRevoltEnv(object):
     def __init__(self, n_envs, variant='final', extended_state=True, cont_ang=True, device='cuda:0',
                  testing=False, realtime=False, max_ep_len=800, auto_reset=False, terminate=True,
                  wrap_mode='reference', seed=0, env_id_base=0, obs_dtype='float32', current=False,
-                 vessel_params=None, layout='aos', reset_fraction=0.8, time_limit=True, hold_plant=False):
+                 vessel_params=None, layout='aos', reset_fraction=0.8, time_limit=True, hold_plant=False,
+                 current_drift=False, current_tau=100.0, current_sigma_v=0.02, current_sigma_beta=5.0 * math.pi / 180.0):
         torch = _torch()
         if not torch.cuda.is_available():
             raise RuntimeError('BatchedRevoltEnv needs a ROCm device: the env.step path is a HIP kernel and has no CPU fallback')
@@ -136,6 +137,10 @@ class BatchedRevoltEnv(object):
         cfg.env_id_base = int(env_id_base)
         cfg.reset_fraction = float(reset_fraction)
         cfg.hold_plant = int(bool(hold_plant))
+        cfg.current_drift = int(bool(current_drift))
+        cfg.current_tau = float(current_tau)
+        cfg.current_sigma_v = float(current_sigma_v)
+        cfg.current_sigma_beta = float(current_sigma_beta)
         self.cfg = cfg
         self.layout = layout
         self.auto_reset = bool(auto_reset)
@@ -310,6 +315,14 @@ class BatchedRevoltEnv(object):
         self._chk(vc, (self.n_envs,), torch.float32, 'vc')
         self._chk(beta, (self.n_envs,), torch.float32, 'beta')
         _lib.check(self.lib.dpenv_set_current(self._h, self._ptr(vc), self._ptr(beta), self._stream()), self._h)
+
+    def get_current(self):
+        """Present (vc, beta) of every env; differs from what set_current gave only with current_drift."""
+        torch = _torch()
+        vc = torch.empty(self.n_envs, dtype=torch.float32, device=self.device)
+        beta = torch.empty(self.n_envs, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.dpenv_get_current(self._h, self._ptr(vc), self._ptr(beta), self._stream()), self._h)
+        return vc, beta
 
     def set_vessel_class(self, class_id):
         torch = _torch()

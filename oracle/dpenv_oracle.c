@@ -54,6 +54,7 @@ void dpo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 #define M_EXP exp
 #define M_FABS fabs
 #define M_FLOOR floor
+#define M_LOG log
 #define WRAP_LITERAL 1
 #include "dpenv_oracle_impl.h"
 #undef REAL
@@ -67,6 +68,7 @@ void dpo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 #undef M_EXP
 #undef M_FABS
 #undef M_FLOOR
+#undef M_LOG
 #undef WRAP_LITERAL
 
 #define REAL float
@@ -80,5 +82,6 @@ void dpo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 #define M_EXP expf
 #define M_FABS fabsf
 #define M_FLOOR floorf
+#define M_LOG logf
 #define WRAP_LITERAL 0
 #include "dpenv_oracle_impl.h"

@@ -80,6 +80,10 @@ typedef struct dpo_config {
     uint64_t seed;
     int64_t env_id_base;      /* global id of local env 0 (rank-count invariance) */
     double  reset_fraction;   /* 0.8 (customEnv.py:135, ppo.py:286) */
+    int32_t current_drift;    /* build-defined (config 5): Gauss-Markov drift of the current, once per env step */
+    double  current_tau;      /* s */
+    double  current_sigma_v;  /* m/s */
+    double  current_sigma_beta; /* rad */
 } dpo_config;
 
 #define DPO_DECL(suffix, REAL)                                                                         \
@@ -103,8 +107,9 @@ typedef struct dpo_config {
                             const uint8_t* mask, const REAL* init, const REAL* ref, REAL* obs);        \
     void dpo_step_##suffix(const dpo_config* c, const REAL* vessel, int32_t n, REAL* state,            \
                            int32_t* counters, const REAL* action, const REAL* new_ref,                 \
-                           const REAL* plant_override, const REAL* current, REAL* obs, REAL* rew,      \
-                           uint8_t* done, REAL* parts, REAL* final_obs);                               \
+                           const REAL* plant_override, REAL* current, REAL* obs, REAL* rew,            \
+                           uint8_t* done, REAL* parts, REAL* final_obs, const REAL* current_mean,      \
+                           uint32_t* drift_ctr);                                                       \
     void dpo_discount_cumsum_##suffix(const REAL* x, int32_t n, REAL discount, REAL* y);               \
     void dpo_gae_##suffix(const REAL* rew, const REAL* val, const uint8_t* end, const REAL* boot,      \
                           const REAL* last_val, int32_t T, int32_t n, REAL gamma, REAL lam,            \

@@ -390,9 +390,32 @@ void FN(dpo_reset)(const dpo_config* c, int32_t n, REAL* state, int32_t* counter
  * parts [n][4] or NULL; final_obs [n][obs_dim] or NULL (terminal obs of envs that auto-reset).
  * done bits: 1 = is_terminal, 2 = time limit reached (ppo.py:304), 4 = non-finite state.
  */
+/* Build-defined (config 5): first-order Gauss-Markov drift of one env's current, applied once per env
+ * step AFTER the plant step: x <- x + (dt/tau)(x0 - x) + sigma sqrt(2 dt/tau) xi, xi ~ N(0,1) by Box-Muller on a
+ * Philox draw keyed (seed; global env id, draw index, tag 0xC0000000). */
+static void FN(current_drift)(const dpo_config* c, int64_t gid, uint32_t* ctr, REAL* vc, REAL* beta, REAL vc0, REAL beta0)
+{
+    const REAL dt = R(c->substep_dt) * R(c->n_substeps);
+    const REAL a = dt / R(c->current_tau);
+    const REAL sv = R(c->current_sigma_v) * M_SQRT(R(2) * dt / R(c->current_tau));
+    const REAL sb = R(c->current_sigma_beta) * M_SQRT(R(2) * dt / R(c->current_tau));
+    uint32_t key[2] = {(uint32_t)(c->seed & 0xffffffffu), (uint32_t)(c->seed >> 32)};
+    uint32_t ctrv[4] = {(uint32_t)((uint64_t)gid & 0xffffffffu), (uint32_t)((uint64_t)gid >> 32), *ctr, 0xC0000000u};
+    uint32_t w[4];
+    dpo_philox4x32_10(ctrv, key, w);
+    *ctr += 1u;
+    const REAL u1 = (R(w[0] >> 8) + R(0.5)) * R(1.0 / 16777216.0);
+    const REAL u2 = R(w[1] >> 8) * R(1.0 / 16777216.0);
+    const REAL rad = M_SQRT(R(-2) * M_LOG(u1));
+    const REAL ang = R(2) * PI_R * u2;
+    *vc = *vc + a * (vc0 - *vc) + sv * (rad * M_COS(ang));
+    *beta = *beta + a * (beta0 - *beta) + sb * (rad * M_SIN(ang));
+}
+
 void FN(dpo_step)(const dpo_config* c, const REAL* vessel, int32_t n, REAL* state, int32_t* counters,
-                  const REAL* action, const REAL* new_ref, const REAL* plant_override, const REAL* current,
-                  REAL* obs, REAL* rew, uint8_t* done, REAL* parts_out, REAL* final_obs)
+                  const REAL* action, const REAL* new_ref, const REAL* plant_override, REAL* current,
+                  REAL* obs, REAL* rew, uint8_t* done, REAL* parts_out, REAL* final_obs, const REAL* current_mean,
+                  uint32_t* drift_ctr)
 {
     const int ad = FN(dpo_act_dim)(c), od = FN(dpo_obs_dim)(c);
     /* envs are independent (trainer.py:61-75: one simulator per env); threads only split the loop */
@@ -413,6 +436,9 @@ void FN(dpo_step)(const dpo_config* c, const REAL* vessel, int32_t n, REAL* stat
             if (current) { cur[0] = current[i]; cur[1] = current[n + i]; }
             FN(dpo_plant)(c, vessel, eta, nu, thrust, ang_cur, current ? cur : (const REAL*)0);   /* ENV:124 */
         }
+        if (current && c->current_drift && current_mean && drift_ctr)
+            FN(current_drift)(c, c->env_id_base + i, &drift_ctr[i], &current[i], &current[n + i], current_mean[i],
+                              current_mean[n + i]);
         FN(dpo_obs)(c, eta, nu, ref, pt, o);                               /* ENV:125 */
         FN(dpo_reward)(c, o, thrust, ang_cur, ang_prev, parts);            /* ENV:126-128 */
         uint8_t d = (uint8_t)FN(dpo_done)(c, o);                           /* ENV:129 */

@@ -28,14 +28,17 @@ class Config(C.Structure):
                 ('n_substeps', C.c_int32), ('substep_dt', C.c_double), ('wrap_mode', C.c_int32),
                 ('terminate', C.c_int32), ('max_ep_len', C.c_int32), ('auto_reset', C.c_int32),
                 ('current_enabled', C.c_int32), ('seed', C.c_uint64), ('env_id_base', C.c_int64),
-                ('reset_fraction', C.c_double)]
+                ('reset_fraction', C.c_double), ('current_drift', C.c_int32), ('current_tau', C.c_double),
+                ('current_sigma_v', C.c_double), ('current_sigma_beta', C.c_double)]
 
 
 def make_config(variant=FINAL, extended_state=1, cont_ang=1, n_substeps=20, substep_dt=0.01,
                 wrap_mode=WRAP_REFERENCE, terminate=1, max_ep_len=0, auto_reset=0, current_enabled=0,
-                seed=0, env_id_base=0, reset_fraction=0.8):
+                seed=0, env_id_base=0, reset_fraction=0.8, current_drift=0, current_tau=100.0, current_sigma_v=0.02,
+                current_sigma_beta=5.0 * np.pi / 180.0):
     return Config(variant, extended_state, cont_ang, n_substeps, substep_dt, wrap_mode, terminate,
-                  max_ep_len, auto_reset, current_enabled, seed, env_id_base, reset_fraction)
+                  max_ep_len, auto_reset, current_enabled, seed, env_id_base, reset_fraction,
+                  current_drift, current_tau, current_sigma_v, current_sigma_beta)
 
 
 def build(force=False):
@@ -144,7 +147,9 @@ class Oracle(object):
         return obs
 
     def step(self, state, counters, action, new_ref=None, plant_override=None, current=None,
-             want_parts=False, want_final_obs=False):
+             want_parts=False, want_final_obs=False, current_mean=None, drift_ctr=None):
+        """current [2][n] is updated IN PLACE when the config enables drift (pass a contiguous array of the
+        oracle's dtype together with current_mean [2][n] and drift_ctr uint32[n])."""
         n = state.shape[1]
         assert state.dtype == self.dtype and state.flags.c_contiguous and counters.dtype == np.int32
         a = self._a(action, (n, self.act_dim))
@@ -153,9 +158,16 @@ class Oracle(object):
         done = np.zeros(n, np.uint8)
         parts = np.zeros((n, 4), self.dtype) if want_parts else None
         fobs = np.zeros((n, self.obs_dim), self.dtype) if want_final_obs else None
+        if current is not None and self.cfg.current_drift:
+            assert current.dtype == self.dtype and current.flags.c_contiguous and current.shape == (2, n)
+            assert drift_ctr is not None and drift_ctr.dtype == np.uint32 and current_mean is not None
+            cur = current
+        else:
+            cur = self._a(current, (2, n))
         self._f('dpo_step')(C.byref(self.cfg), _p(self.vessel), C.c_int32(n), _p(state), _p(counters), _p(a),
                             _p(self._a(new_ref, (3, n))), _p(self._a(plant_override, (6, n))),
-                            _p(self._a(current, (2, n))), _p(obs), _p(rew), _p(done), _p(parts), _p(fobs))
+                            _p(cur), _p(obs), _p(rew), _p(done), _p(parts), _p(fobs),
+                            _p(self._a(current_mean, (2, n))), _p(drift_ctr))
         out = [obs, rew, done]
         if want_parts:
             out.append(parts)
@@ -167,7 +179,7 @@ class Oracle(object):
         """step() writing into caller-provided arrays: nothing but the C loop runs (used for CPU timing)."""
         n = state.shape[1]
         self._f('dpo_step')(C.byref(self.cfg), _p(self.vessel), C.c_int32(n), _p(state), _p(counters), _p(action),
-                            _p(new_ref), None, None, _p(obs), _p(rew), _p(done), None, None)
+                            _p(new_ref), None, None, _p(obs), _p(rew), _p(done), None, None, None, None)
 
     def discount_cumsum(self, x, discount):
         x = self._a(x)

@@ -22,14 +22,18 @@ def make_pair(mode, n, ext=True, dtype=np.float32, device='cuda:0', **kw):
         obs_dtype=kw.get('obs_dtype', 'float32'), current=kw.get('current', False),
         vessel_params=kw.get('vessel_params'), layout=kw.get('layout', 'aos'),
         reset_fraction=kw.get('reset_fraction', 0.8), time_limit=kw.get('time_limit', True),
-        max_ep_len=kw.get('max_ep_len', 800), hold_plant=kw.get('hold_plant', False))
+        max_ep_len=kw.get('max_ep_len', 800), hold_plant=kw.get('hold_plant', False),
+        current_drift=kw.get('current_drift', False), current_tau=kw.get('current_tau', 100.0),
+        current_sigma_v=kw.get('current_sigma_v', 0.02), current_sigma_beta=kw.get('current_sigma_beta', 5.0 * np.pi / 180.0))
     cfg = O.make_config(variant=ovar, extended_state=int(ext), cont_ang=ocont,
                         wrap_mode=O.WRAP_RADIANS if kw.get('wrap_mode') == 'radians' else O.WRAP_REFERENCE,
                         terminate=int(kw.get('terminate', True)),
                         max_ep_len=env.max_ep_len if kw.get('time_limit', True) else 0,
                         auto_reset=int(kw.get('auto_reset', False)), current_enabled=int(kw.get('current', False)),
                         seed=kw.get('seed', 0), env_id_base=kw.get('env_id_base', 0),
-                        reset_fraction=kw.get('reset_fraction', 0.8))
+                        reset_fraction=kw.get('reset_fraction', 0.8), current_drift=int(kw.get('current_drift', False)),
+                        current_tau=kw.get('current_tau', 100.0), current_sigma_v=kw.get('current_sigma_v', 0.02),
+                        current_sigma_beta=kw.get('current_sigma_beta', 5.0 * np.pi / 180.0))
     vessel = None
     if kw.get('vessel_params') is not None and np.asarray(kw['vessel_params']).ndim == 1:
         vessel = np.asarray(kw['vessel_params'], dtype)

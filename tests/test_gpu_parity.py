@@ -260,6 +260,59 @@ def test_constant_current_matches_oracle():
     assert abs(np.hypot(vN, vE) - 0.2) < 0.02 and abs(np.arctan2(vE, vN) - np.deg2rad(135)) < 0.15
 
 
+def test_current_drift_matches_oracle_and_fused_equals_single():
+    """Config 5: Gauss-Markov current drift.  One step vs the oracle (current after the step included), then a
+    fused rollout against single steps (bitwise), then the drift statistics on the GPU."""
+    torch = torch_()
+    n = 4096 + 5
+    rng = np.random.RandomState(14)
+    kw = dict(current=True, current_drift=True, current_tau=20.0, current_sigma_v=0.03, current_sigma_beta=0.1, seed=21,
+              terminate=False, time_limit=False)
+    env, orc = H.make_pair('final_cont', n, **kw)
+    env2, _ = H.make_pair('final_cont', n, **kw)
+    vc = (0.2 + 0.02 * rng.normal(size=n)).astype(np.float32)
+    beta = (np.deg2rad(135) + 0.1 * rng.normal(size=n)).astype(np.float32)
+    for e in (env, env2):
+        e.set_current(H.to_dev(vc), H.to_dev(beta))
+    st = H.random_state(rng, n, spread=0.3)
+    ctr = np.zeros((2, n), np.int32)
+    act = H.random_actions(rng, n, 7)
+    mean = np.stack([vc, beta])
+    cur = mean.copy()
+    dctr = np.zeros(n, np.uint32)
+    env.set_state(H.to_dev(st), H.to_dev(ctr))
+    obs, rew, done, _ = env.step(H.to_dev(act))
+    ost, octr = st.copy(), ctr.copy()
+    oo, orw, od_ = orc.step(ost, octr, act, current=cur, current_mean=mean, drift_ctr=dctr)
+    TOL.assert_close(obs.cpu().numpy(), oo, TOL.OBS_FLOOR, what='obs with drifting current')
+    gvc, gbeta = env.get_current()
+    TOL.assert_close(gvc.cpu().numpy(), cur[0], 0.1, what='V_c after drift step')
+    TOL.assert_close(gbeta.cpu().numpy(), cur[1], 1.0, what='beta_c after drift step')
+    assert np.abs(gvc.cpu().numpy() - vc).max() > 1e-3       # it moved
+    # fused == single steps, bit for bit, drift included
+    T = 23
+    acts = H.to_dev(rng.normal(0, 0.5, size=(T, n, 7)).astype(np.float32))
+    env2.set_state(H.to_dev(st), H.to_dev(ctr))
+    env2.step(H.to_dev(act))
+    o_r, r_r, d_r = env2.rollout(acts)
+    for t in range(T):
+        o, r, d, _ = env.step(acts[t])
+        assert torch.equal(o, o_r[t]) and torch.equal(r, r_r[t]) and torch.equal(d, d_r[t]), t
+    a1, b1 = env.get_current()
+    a2, b2 = env2.get_current()
+    assert torch.equal(a1, a2) and torch.equal(b1, b2)
+    s1, _ = env.get_state()
+    s2, _ = env2.get_state()
+    assert torch.equal(s1, s2)
+    # statistics after many steps: stationary std = sigma around the set mean
+    for _ in range(12):
+        env2.rollout(torch.zeros((50, n, 7), device=env2.device))
+    a2, b2 = env2.get_current()
+    dv = (a2.cpu().numpy() - vc)
+    db = (b2.cpu().numpy() - beta)
+    assert abs(dv.std() - 0.03) < 0.004 and abs(db.std() - 0.1) < 0.012 and abs(dv.mean()) < 0.003
+
+
 def test_vessel_classes_staged_in_lds():
     """Per-class 3x3 mass / damping / thruster blocks (LDS table path) against per-class oracle runs."""
     import ml4ca_amd

@@ -139,3 +139,40 @@ def test_two_rank_gloo_gather_matches_single_process_run():
     assert np.array_equal(full, ref), 'sharded + gathered rollout must equal the single-process rollout bit for bit'
     assert (ref[..., 17] != 0).sum() >= total        # episodes ended and were re-sampled (Philox keyed by global id)
     assert abs(mean_rew - ref[..., 16].mean(dtype=np.float64)) < 1e-9
+
+
+def test_current_drift_is_a_stationary_gauss_markov_process():
+    """Config 5's slowly varying current (build-defined): mean reversion to the set value, stationary std sigma,
+    correlation time tau - checked on the oracle (the GPU kernel is checked against the oracle in -m gpu)."""
+    from oracle import oracle as O
+    n, T = 4096, 600
+    tau, sv, sb = 20.0, 0.03, 0.1
+    orc = O.Oracle(O.make_config(terminate=0, current_enabled=1, current_drift=1, current_tau=tau, current_sigma_v=sv,
+                                 current_sigma_beta=sb, seed=12), np.float32)
+    st, ctr = orc.new_state(n)
+    orc.reset(st, ctr, init=np.zeros((6, n), np.float32))
+    mean = np.stack([np.full(n, 0.2, np.float32), np.full(n, np.deg2rad(135), np.float32)])
+    cur = mean.copy()
+    dctr = np.zeros(n, np.uint32)
+    act = np.zeros((n, 7), np.float32)
+    hist = []
+    for t in range(T):
+        orc.step(st, ctr, act, current=cur, current_mean=mean, drift_ctr=dctr)
+        hist.append(cur.copy())
+    hist = np.array(hist)                      # [T, 2, n]
+    assert (dctr == T).all()
+    tail = hist[300:]
+    assert abs(tail[:, 0].mean() - 0.2) < 2e-3 and abs(tail[:, 1].mean() - np.deg2rad(135)) < 5e-3
+    assert abs(tail[:, 0].std() - sv) < 0.1 * sv and abs(tail[:, 1].std() - sb) < 0.1 * sb
+    # lag-k autocorrelation of an OU process sampled every dt: (1 - dt/tau)^k
+    x = tail[:, 0] - 0.2
+    k = 25
+    rho = (x[:-k] * x[k:]).mean() / (x * x).mean()
+    assert abs(rho - (1 - 0.2 / tau) ** k) < 0.05
+    # different envs draw independent noise; the same (seed, env, draw) repeats exactly
+    assert abs(np.corrcoef(hist[:, 0, 0], hist[:, 0, 1])[0, 1]) < 0.3
+    cur2, dctr2 = mean.copy(), np.zeros(n, np.uint32)
+    st2, ctr2 = orc.new_state(n)
+    orc.reset(st2, ctr2, init=np.zeros((6, n), np.float32))
+    orc.step(st2, ctr2, act, current=cur2, current_mean=mean, drift_ctr=dctr2)
+    assert np.array_equal(cur2, hist[0])

@@ -46,6 +46,8 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='budget of the CPU baseline leg')
     ap.add_argument('--gather', type=int, default=-1, help='time the config-4 trajectory all-gather (default: on if gpus > 1)')
     ap.add_argument('--hold-plant', action='store_true', help='diagnostic: skip the plant sub-steps (INVALID as a result)')
+    ap.add_argument('--backend', default='nccl', help="'nccl' (= RCCL; default) or 'gloo' (rehearsal only)")
+    ap.add_argument('--same-device', action='store_true', help='rehearsal: every rank uses cuda:0 (needs --backend gloo)')
     ap.add_argument('--traffic-json', default=os.path.join(ROOT, 'profiles', 'traffic_latest.json'))
     return ap.parse_args()
 
@@ -90,11 +92,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit('--gpus %d needs torch.distributed.run --nproc-per-node %d' % (args.gpus, args.gpus))
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback for the product path)'
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     import ml4ca_amd
     n = args.envs
@@ -217,13 +224,14 @@ def main():
         T, nl = 400, 32768
         traj = torch.randn((T, nl, 19), device=dev)
         out = torch.empty((world, T, nl, 19), device=dev)
-        dist.all_gather_into_tensor(out, traj)
+        from ml4ca_amd.dist import gather_trajectories
+        gather_trajectories(traj, out=out)
         torch.cuda.synchronize(dev)
         dist.barrier()
         t1 = time.perf_counter()
         reps = 3
         for _ in range(reps):
-            dist.all_gather_into_tensor(out, traj)
+            gather_trajectories(traj, out=out)
         torch.cuda.synchronize(dev)
         gt = torch.tensor([(time.perf_counter() - t1) / reps], device=dev, dtype=torch.float64)
         dist.all_reduce(gt, op=dist.ReduceOp.MAX)
@@ -255,7 +263,8 @@ def main():
                                    'setpoint sequence (switch steps 50/300/550/700/950 of 1250), terminate off, fp32' % n,
                        'envs_per_gpu': n, 'total_envs': total_envs, 'integrator': 'semi-implicit Euler 20 x 10 ms',
                        'launch': 'eager' if graph is None else 'hipGraph replay, %d steps per graph' % CHUNK,
-                       'sharding': 'independent env shards, no data-path collective'},
+                       'sharding': 'independent env shards, no data-path collective',
+                       'backend': args.backend if world > 1 else None},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'kernel': 'dpenv::step_kernel<4,true,false>', 'algorithmic_bytes_per_launch': per_launch_bytes,

@@ -186,6 +186,46 @@ typedef struct dpenv_rollout_io {
 } dpenv_rollout_io;
 int dpenv_rollout(dpenv_handle h, const dpenv_rollout_io* io, dpenv_stream s);
 
+/* ---- actor-critic in the loop -------------------------------------------------
+ * The PPO actor-critic of the reference (mlp_gaussian_policy / mlp_actor_critic, spinup/algos/tf1/ppo/core.py:29-33,
+ * 80-107; shipped model 9-80-80-80-7 + 9-80-80-80-1, leaky_relu 0.2, config.json) evaluated inside the rollout
+ * launch on the matrix cores (f16 weights/activations, f32 accumulate), so that one launch produces T rows of the
+ * trajectory buffer (o, a, r, v, logp) of ppo.py:298 for every env. */
+typedef struct dpenv_mlp {
+    int32_t n_layers;        /* dense layers = hidden layers + 1, in [2, 5] */
+    int32_t sizes[6];        /* n_layers + 1 widths, e.g. {9, 80, 80, 80, 7}; hidden widths equal and <= 95 */
+    const float* W[5];       /* HOST pointers, W[l][in][out] row-major (tf.layers.dense kernel layout) */
+    const float* b[5];       /* HOST pointers, b[l][out] */
+} dpenv_mlp;
+/* pi: obs_dim -> act_dim, v: obs_dim -> 1 (same hidden shape); log_std: host float[act_dim]; leak: hidden
+ * leaky-relu slope (0.2 = tf.nn.leaky_relu default; 0 = relu).  Packs and uploads; may be called again after
+ * every PPO update. */
+int dpenv_set_policy(dpenv_handle h, const dpenv_mlp* pi, const dpenv_mlp* v, const float* log_std, float leak);
+/* mu_out [n][act_dim], v_out [n] for obs [n][obs_dim] (all device, row-major): the deterministic policy of
+ * test_policy.py:90 and the critic. */
+int dpenv_policy_forward(dpenv_handle h, const float* obs, float* mu_out, float* v_out, int32_t n, dpenv_stream s);
+
+typedef struct dpenv_policy_rollout_io {
+    uint32_t struct_size;
+    int32_t T;
+    const float* noise;      /* [T][n][act_dim] N(0,1) draws (a = mu + exp(log_std) * noise, core.py:85); NULL: a = mu */
+    float* obs;              /* [T][n][obs_dim]  policy input of step t */
+    float* act;              /* [T][n][act_dim] */
+    float* reward;           /* [T][n] */
+    float* value;            /* [T][n]  V(obs[t]) */
+    float* logp;             /* [T][n]  log-likelihood of act[t] (core.py:42-46) */
+    uint8_t* done;           /* [T][n]  DPENV_DONE_* bits */
+    float* boot;             /* [T][n]  value appended at a path end (ppo.py:311): 0 if terminal, V(next obs) if only the
+                                time limit or the end of the launch cut the path; 0 elsewhere.  Feed to dpenv_gae. */
+    float* last_obs;         /* [n][obs_dim] policy input of the next launch */
+    float* last_value;       /* [n] */
+    int32_t n_switch;
+    int32_t switch_step[DPENV_MAX_SWITCH];
+    const float* refs;       /* [n_switch][3][n] */
+} dpenv_policy_rollout_io;
+/* Requires AOS layouts and f32 observations. */
+int dpenv_policy_rollout(dpenv_handle h, const dpenv_policy_rollout_io* io, dpenv_stream s);
+
 /* Parity/test access to the library-owned state in the canonical format above. */
 int dpenv_get_state(dpenv_handle h, float* state_out, int32_t* counters_out, dpenv_stream s);
 int dpenv_set_state(dpenv_handle h, const float* state_in, const int32_t* counters_in, dpenv_stream s);

@@ -50,6 +50,17 @@ class RolloutIO(C.Structure):
                 ('refs', C.c_void_p)]
 
 
+class Mlp(C.Structure):
+    _fields_ = [('n_layers', C.c_int32), ('sizes', C.c_int32 * 6), ('W', C.c_void_p * 5), ('b', C.c_void_p * 5)]
+
+
+class PolicyRolloutIO(C.Structure):
+    _fields_ = [('struct_size', C.c_uint32), ('T', C.c_int32), ('noise', C.c_void_p), ('obs', C.c_void_p),
+                ('act', C.c_void_p), ('reward', C.c_void_p), ('value', C.c_void_p), ('logp', C.c_void_p),
+                ('done', C.c_void_p), ('boot', C.c_void_p), ('last_obs', C.c_void_p), ('last_value', C.c_void_p),
+                ('n_switch', C.c_int32), ('switch_step', C.c_int32 * 8), ('refs', C.c_void_p)]
+
+
 # every symbol include/dpenv.h declares: name -> (restype, argtypes)
 _VP, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SYMBOLS = {
@@ -69,6 +80,9 @@ SYMBOLS = {
     'dpenv_step': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     'dpenv_step_ex': (C.c_int, [_VP, C.POINTER(StepIO), _VP]),
     'dpenv_rollout': (C.c_int, [_VP, C.POINTER(RolloutIO), _VP]),
+    'dpenv_set_policy': (C.c_int, [_VP, C.POINTER(Mlp), C.POINTER(Mlp), C.POINTER(C.c_float), _F]),
+    'dpenv_policy_forward': (C.c_int, [_VP, _VP, _VP, _VP, _I32, _VP]),
+    'dpenv_policy_rollout': (C.c_int, [_VP, C.POINTER(PolicyRolloutIO), _VP]),
     'dpenv_get_state': (C.c_int, [_VP, _VP, _VP, _VP]),
     'dpenv_set_state': (C.c_int, [_VP, _VP, _VP, _VP]),
     'dpenv_thrust_map': (C.c_int, [C.POINTER(C.c_float), _VP, _VP, _VP, _I32, _VP]),

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/dpenv.h"
 #include "dpenv_dev.h"
@@ -31,6 +32,9 @@ struct dpenv_s {
     int32_t* class_id;
     bool classes_assigned;
     bool current_set;
+    PolicyArgs pol;         // persistent part (weights, std) of the policy kernel arguments
+    uint4* pol_frags;
+    bool has_policy;
     int device;
     std::string err;
 };
@@ -213,6 +217,9 @@ extern "C" int dpenv_create(const dpenv_config* cfg, const float* vessel_params,
     h->device = dev;
     h->classes_assigned = false;
     h->current_set = false;
+    h->pol_frags = nullptr;
+    h->has_policy = false;
+    std::memset(&h->pol, 0, sizeof h->pol);
 
     VesselDev tab[MAX_CLASSES];
     float defp[DPENV_NPARAM];
@@ -300,6 +307,7 @@ extern "C" int dpenv_destroy(dpenv_handle h)
 {
     if (!h) return DPENV_EINVAL;
     if (h->blob) (void)hipFree(h->blob);
+    if (h->pol_frags) (void)hipFree(h->pol_frags);
     delete h;
     return DPENV_OK;
 }
@@ -421,6 +429,156 @@ extern "C" int dpenv_rollout(dpenv_handle h, const dpenv_rollout_io* io, dpenv_s
     ra.n_switch = io->n_switch; ra.refs = io->refs;
     for (int k = 0; k < io->n_switch; ++k) ra.switch_step[k] = io->switch_step[k];
     HIP_TRY(h, dpenv_dev_launch_rollout(&a, &ra, h->mode, h->cfg.extended_state, h->n_classes > 1, (hipStream_t)s));
+    return DPENV_OK;
+}
+
+// ---- actor-critic ------------------------------------------------------------------------------------------
+static uint16_t float_to_half(float f)
+{
+    // IEEE binary32 -> binary16, round to nearest even
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const int32_t e = (int32_t)((x >> 23) & 0xff) - 127 + 15;
+    uint32_t m = x & 0x7fffffu;
+    if (((x >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7c00u | (m ? 0x200u : 0u));
+    if (e >= 31) return (uint16_t)(sign | 0x7c00u);
+    if (e <= 0) {
+        if (e < -10) return (uint16_t)sign;
+        m |= 0x800000u;
+        const int shift = 14 - e;
+        uint32_t hm = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (hm & 1u))) hm++;
+        return (uint16_t)(sign | hm);
+    }
+    uint32_t hm = m >> 13;
+    const uint32_t rem = m & 0x1fffu;
+    uint32_t out = sign | ((uint32_t)e << 10) | hm;
+    if (rem > 0x1000u || (rem == 0x1000u && (hm & 1u))) out++;
+    return (uint16_t)out;
+}
+
+// Pack one MLP into MFMA A-operand fragments (see dpenv_policy.hip).  Fragment f, lane l = (r = l & 31, h = l >> 5),
+// element j holds W^T[out row 32 mo + r][input slot k(f, h, j)]:
+//   first layer : k = 8 h + j                                  (slots 0..in-1 = inputs, slot 15 = bias)
+//   later layers: k = 32 mt + 16 s + 8 (j >> 2) + 4 h + (j & 3) (the accumulator-as-operand order; feature H = bias)
+static int pack_net(const dpenv_mlp* m, int in_dim, int out_dim, std::vector<uint16_t>& out, std::string* why)
+{
+    const int nl = m->n_layers;
+    if (nl < 2 || nl > 5) { *why = "n_layers must be in [2, 5]"; return DPENV_EINVAL; }
+    const int H = m->sizes[1];
+    if (m->sizes[0] != in_dim || m->sizes[nl] != out_dim) { *why = "network input/output width does not match the env"; return DPENV_EINVAL; }
+    if (in_dim > 15 || out_dim > 8 || H < 1 || H > 95) { *why = "limits: obs_dim <= 15, out <= 8, hidden width <= 95"; return DPENV_EINVAL; }
+    for (int l = 1; l < nl; ++l) if (m->sizes[l] != H) { *why = "hidden widths must be equal"; return DPENV_EINVAL; }
+    for (int l = 0; l < nl; ++l) if (!m->W[l] || !m->b[l]) { *why = "NULL weight pointer"; return DPENV_EINVAL; }
+    const int n_hidden = nl - 1;
+    const int nfrag = 3 + 18 * (n_hidden - 1) + 6;
+    out.assign((size_t)nfrag * 64 * 8, 0);
+    auto put = [&](int f, int lane, int j, float v) { out[((size_t)f * 64 + lane) * 8 + j] = float_to_half(v); };
+    for (int lane = 0; lane < 64; ++lane) {
+        const int r = lane & 31, hh = lane >> 5;
+        for (int j = 0; j < 8; ++j) {
+            for (int mo = 0; mo < 3; ++mo) {                       // first layer
+                const int k = 8 * hh + j, row = 32 * mo + r;
+                float v = 0.0f;
+                if (row < H) v = (k < in_dim) ? m->W[0][(size_t)k * H + row] : (k == 15 ? m->b[0][row] : 0.0f);
+                else if (row == H) v = (k == 15) ? 1.0f : 0.0f;
+                put(mo, lane, j, v);
+            }
+            for (int ks = 0; ks < 6; ++ks) {
+                const int mt = ks >> 1, s2 = ks & 1;
+                const int f = 32 * mt + 16 * s2 + 8 * (j >> 2) + 4 * hh + (j & 3);
+                for (int l = 1; l < n_hidden; ++l)                 // hidden -> hidden
+                    for (int mo = 0; mo < 3; ++mo) {
+                        const int row = 32 * mo + r;
+                        float v = 0.0f;
+                        if (row < H) v = (f < H) ? m->W[l][(size_t)f * H + row] : (f == H ? m->b[l][row] : 0.0f);
+                        else if (row == H) v = (f == H) ? 1.0f : 0.0f;
+                        put(3 + 18 * (l - 1) + mo * 6 + ks, lane, j, v);
+                    }
+                float v = 0.0f;                                    // output layer
+                if (r < out_dim) v = (f < H) ? m->W[nl - 1][(size_t)f * out_dim + r] : (f == H ? m->b[nl - 1][r] : 0.0f);
+                put(3 + 18 * (n_hidden - 1) + ks, lane, j, v);
+            }
+        }
+    }
+    return nfrag;
+}
+
+extern "C" int dpenv_set_policy(dpenv_handle h, const dpenv_mlp* pi, const dpenv_mlp* v, const float* log_std, float leak)
+{
+    if (!h) return DPENV_EINVAL;
+    if (!pi || !v || !log_std) return fail(h, DPENV_EINVAL, "dpenv_set_policy: NULL argument");
+    if (pi->n_layers != v->n_layers || pi->sizes[1] != v->sizes[1])
+        return fail(h, DPENV_EINVAL, "actor and critic must have the same hidden shape");
+    const int od = dpenv_obs_dim(&h->cfg), ad = dpenv_act_dim(&h->cfg);
+    std::vector<uint16_t> fp, fv;
+    std::string why;
+    const int nf = pack_net(pi, od, ad, fp, &why);
+    if (nf < 0) return fail(h, DPENV_EINVAL, "actor: %s", why.c_str());
+    const int nf2 = pack_net(v, od, 1, fv, &why);
+    if (nf2 < 0) return fail(h, DPENV_EINVAL, "critic: %s", why.c_str());
+    const size_t bytes_net = (size_t)nf * 64 * 16;
+    if (2 * bytes_net + 4 * 64 * 9 * 4 > 160 * 1024) return fail(h, DPENV_EINVAL, "networks do not fit the 160 KiB LDS");
+    if (h->pol_frags && h->pol.nfrag != nf) { (void)hipFree(h->pol_frags); h->pol_frags = nullptr; }
+    if (!h->pol_frags) {
+        void* p = nullptr;
+        if (hipMalloc(&p, 2 * bytes_net) != hipSuccess) return fail(h, DPENV_ENOMEM, "hipMalloc of the policy fragments failed");
+        h->pol_frags = (uint4*)p;
+    }
+    HIP_TRY(h, hipMemcpy(h->pol_frags, fp.data(), bytes_net, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy((char*)h->pol_frags + bytes_net, fv.data(), bytes_net, hipMemcpyHostToDevice));
+    PolicyArgs& pa = h->pol;
+    std::memset(&pa, 0, sizeof pa);
+    pa.frags = h->pol_frags;
+    pa.nfrag = nf;
+    pa.n_hidden = pi->n_layers - 1;
+    pa.leak = leak;
+    for (int k = 0; k < 8; ++k) {
+        const float ls = k < ad ? log_std[k] : 0.0f;
+        pa.std[k] = expf(ls);
+        pa.inv_std_eps[k] = 1.0f / (expf(ls) + 1e-8f);                       // core.py:45, EPS = 1e-8
+        pa.logp_const[k] = k < ad ? (-ls - 0.5f * logf(2.0f * 3.14159265358979323846f)) : 0.0f;
+    }
+    h->has_policy = true;
+    return DPENV_OK;
+}
+
+extern "C" int dpenv_policy_forward(dpenv_handle h, const float* obs, float* mu_out, float* v_out, int32_t n, dpenv_stream s)
+{
+    if (!h) return DPENV_EINVAL;
+    if (!h->has_policy) return fail(h, DPENV_EINVAL, "dpenv_set_policy has not been called");
+    if (!obs || !mu_out || !v_out || n <= 0) return fail(h, DPENV_EINVAL, "dpenv_policy_forward: bad argument");
+    HIP_TRY(h, dpenv_dev_launch_policy_forward(&h->pol, dpenv_obs_dim(&h->cfg), dpenv_act_dim(&h->cfg), obs, mu_out, v_out, n,
+                                               (hipStream_t)s));
+    return DPENV_OK;
+}
+
+extern "C" int dpenv_policy_rollout(dpenv_handle h, const dpenv_policy_rollout_io* io, dpenv_stream s)
+{
+    if (!h) return DPENV_EINVAL;
+    if (!h->has_policy) return fail(h, DPENV_EINVAL, "dpenv_set_policy has not been called");
+    if (!io || io->struct_size != sizeof(dpenv_policy_rollout_io)) return fail(h, DPENV_EINVAL, "dpenv_policy_rollout_io ABI mismatch");
+    if (io->T <= 0 || !io->obs || !io->act || !io->reward || !io->value || !io->logp || !io->done || !io->boot ||
+        !io->last_obs || !io->last_value)
+        return fail(h, DPENV_EINVAL, "T > 0 and every output block are required");
+    if (h->cfg.action_layout != DPENV_AOS || h->cfg.obs_layout != DPENV_AOS || h->cfg.obs_dtype != DPENV_F32)
+        return fail(h, DPENV_EINVAL, "policy rollout needs AOS layouts and f32 observations");
+    if (h->n_classes > 1) return fail(h, DPENV_EINVAL, "policy rollout supports one vessel class");
+    if (io->n_switch < 0 || io->n_switch > DPENV_MAX_SWITCH || (io->n_switch > 0 && !io->refs))
+        return fail(h, DPENV_EINVAL, "bad setpoint schedule");
+    for (int k = 0; k < io->n_switch; ++k)
+        if (io->switch_step[k] < 0 || io->switch_step[k] >= io->T || (k > 0 && io->switch_step[k] <= io->switch_step[k - 1]))
+            return fail(h, DPENV_EINVAL, "switch_step must be strictly increasing within [0, T)");
+    StepArgs a = h->args;
+    bind_optional(h, a);
+    PolicyArgs pa = h->pol;
+    pa.T = io->T; pa.noise = io->noise; pa.obs_out = io->obs; pa.act_out = io->act; pa.rew = io->reward; pa.val = io->value;
+    pa.logp = io->logp; pa.done = io->done; pa.boot = io->boot; pa.last_obs = io->last_obs; pa.last_val = io->last_value;
+    pa.n_switch = io->n_switch; pa.refs = io->refs;
+    for (int k = 0; k < io->n_switch; ++k) pa.switch_step[k] = io->switch_step[k];
+    HIP_TRY(h, dpenv_dev_launch_policy_rollout(&a, &pa, h->mode, h->cfg.extended_state, (hipStream_t)s));
     return DPENV_OK;
 }
 

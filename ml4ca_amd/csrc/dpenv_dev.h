@@ -93,9 +93,39 @@ struct RolloutArgs {
     const float* refs;        // [n_switch][3][n]
 };
 
+// actor-critic evaluated in-kernel (dpenv_policy.hip)
+struct PolicyArgs {
+    const uint4* frags;       // [2][nfrag][64] x 16 B: MFMA A-operand fragments (f16), actor then critic
+    int32_t nfrag;            // fragments per net = 3 + 18 (n_hidden - 1) + 6
+    int32_t n_hidden;
+    float leak;               // leaky-relu slope (0.2)
+    float std[8];             // exp(log_std)                        (core.py:84)
+    float inv_std_eps[8];     // 1 / (exp(log_std) + 1e-8)           (core.py:45)
+    float logp_const[8];      // -log_std - 0.5 log(2 pi)            (core.py:45)
+    // rollout I/O
+    int32_t T;
+    const float* noise;       // [T][n][A] standard normal draws, NULL = deterministic (a = mu)
+    float* obs_out;           // [T][n][OD]  policy input of step t   (ppo.py:298 'o')
+    float* act_out;           // [T][n][A]   action taken             ('a')
+    float* rew;               // [T][n]
+    float* val;               // [T][n]      V(o_t)                   ('v_t')
+    float* logp;              // [T][n]                               ('logp_t')
+    uint8_t* done;            // [T][n]
+    float* boot;              // [T][n]      bootstrap value where a path ends (ppo.py:311), else 0
+    float* last_obs;          // [n][OD]     policy input of the next launch
+    float* last_val;          // [n]
+    int32_t n_switch;
+    int32_t switch_step[MAX_SWITCH];
+    const float* refs;
+};
+
 }  // namespace dpenv
 
 extern "C" {
+hipError_t dpenv_dev_launch_policy_forward(const dpenv::PolicyArgs* pa, int od, int adim, const float* obs, float* mu,
+                                           float* v, int n, hipStream_t s);
+hipError_t dpenv_dev_launch_policy_rollout(const dpenv::StepArgs* a, const dpenv::PolicyArgs* pa, int mode, int ext,
+                                           hipStream_t s);
 hipError_t dpenv_dev_launch_rollout(const dpenv::StepArgs* a, const dpenv::RolloutArgs* ra, int mode, int ext,
                                     int per_class, hipStream_t s);
 hipError_t dpenv_dev_launch_step(const dpenv::StepArgs* a, int mode, int ext, int per_class, hipStream_t s);

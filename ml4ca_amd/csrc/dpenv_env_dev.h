@@ -1,0 +1,543 @@
+// dpenv_env_dev.h - device-side building blocks shared by the kernels of libdpenv.so
+// (dpenv_kernels.hip: step / rollout / reset ...; dpenv_policy.hip: policy-in-the-loop rollout).
+// Everything here is __device__ __forceinline__ code in namespace dpenv; see dpenv_kernels.hip for the
+// reference citations of the path as a whole.
+#ifndef DPENV_ENV_DEV_H
+#define DPENV_ENV_DEV_H
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+
+#include "dpenv_dev.h"
+
+namespace dpenv {
+
+constexpr float kPi = 3.14159265358979323846f;
+
+// ---- Philox4x32-10 (Salmon et al. SC'11): counter-based RNG of the reset sampler -------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ float u01_sym(uint32_t w)
+{
+    // 24-bit uniform mapped to [-1, 1): every step is exact in fp32
+    return 2.0f * (float)(w >> 8) * (1.0f / 16777216.0f) - 1.0f;
+}
+
+template <int MODE> struct ModeTraits;
+template <> struct ModeTraits<MODE_FULL> { static constexpr int A = 6; };
+template <> struct ModeTraits<MODE_SIMPLE> { static constexpr int A = 3; };
+template <> struct ModeTraits<MODE_LIMITED> { static constexpr int A = 5; };
+template <> struct ModeTraits<MODE_FINAL_WRAP> { static constexpr int A = 5; };
+template <> struct ModeTraits<MODE_FINAL_CONT> { static constexpr int A = 7; };
+
+// state-space bounds, ENV:26,337,361,386 (intended per-variant values)
+template <int MODE> __device__ __forceinline__ void ss_bounds(float b[6])
+{
+    b[0] = 8.0f; b[1] = 8.0f; b[2] = kPi * 0.5f; b[3] = 1.4f; b[4] = 0.30f; b[5] = 0.52f;
+    if (MODE == MODE_SIMPLE) { b[3] = 1.75f; b[5] = 0.51f; }
+    if (MODE == MODE_LIMITED || MODE == MODE_FINAL_WRAP || MODE == MODE_FINAL_CONT) b[2] = 45.0f * kPi / 180.0f;
+}
+
+// default azimuth commands, ENV:58,341-346,366-371,394-399
+template <int MODE> __device__ __forceinline__ void default_angles(float& a_bow, float& a_port, float& a_star)
+{
+    a_bow = 0.0f; a_port = 0.0f; a_star = 0.0f;
+    if (MODE == MODE_SIMPLE) { a_bow = kPi * 0.5f; a_port = -3.0f * kPi * 0.25f; a_star = 3.0f * kPi * 0.25f; }
+    if (MODE == MODE_LIMITED || MODE == MODE_FINAL_WRAP || MODE == MODE_FINAL_CONT) a_bow = kPi * 0.5f;
+}
+
+// mathematics.py:14-17 wrap_angle in the cancellation-free form x - 2ref*floor((x+ref)/(2ref));
+// deg=true is what errorFrame.py:29,31 actually calls (quirk Q1: degrees constant on radians).
+__device__ __forceinline__ float wrap_angle(float x, bool deg)
+{
+    const float ref = deg ? 180.0f : kPi;
+    const float inv = deg ? (1.0f / 360.0f) : (0.5f / kPi);
+    const float k = floorf((x + ref) * inv);
+    return fmaf(-k, 2.0f * ref, x);
+}
+
+__device__ __forceinline__ float clipf(float v, float b) { return fminf(fmaxf(v, -b), b); }
+
+// ---- lean transcendental code (validated in tools/lean_math_check.py against float64 libm) -------------
+// sincos: 3-constant Cody-Waite reduction by pi/2 + degree-7/6 kernels (Cephes single-precision
+// coefficients); max abs error 9.2e-8 for |x| <= 3e4 (a heading of 4775 turns).  Larger arguments - where a
+// float heading has lost all sub-radian meaning anyway - are first folded by 2 pi in plain fp32 so that the
+// result stays a valid (if inaccurate) rotation; no library call, so the kernels stay call-free.
+__device__ __forceinline__ void sincos_lean(float x, float& s, float& c)
+{
+    if (__builtin_expect(fabsf(x) > 30000.0f, 0)) x = fmaf(-rintf(x * (0.5f / kPi)), 2.0f * kPi, x);
+    const float kf = rintf(x * 0.6366197723675814f);
+    float r = fmaf(kf, -1.5703125f, x);
+    r = fmaf(kf, -4.837512969970703125e-4f, r);
+    r = fmaf(kf, -7.54978995489188216e-8f, r);
+    const float r2 = r * r;
+    float p = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    p = fmaf(r2, p, -1.6666654611e-1f);
+    const float sv = fmaf(r * r2, p, r);
+    float q = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    q = fmaf(r2, q, 4.166664568298827e-2f);
+    const float cv = fmaf(r2 * r2, q, fmaf(r2, -0.5f, 1.0f));
+    const int n = (int)kf;
+    const float so = (n & 1) ? cv : sv;
+    const float co = (n & 1) ? sv : cv;
+    s = (n & 2) ? -so : so;
+    c = ((n + 1) & 2) ? -co : co;
+}
+
+// atan2: a = min/max in [0,1], odd polynomial of degree 17 in a (coefficients fitted in
+// tools/lean_math_check.py: max abs error 2.6e-7, 2 ulp), octant fix-up, sign of y (signed zeros kept:
+// atan2(-0, -1) = -pi like numpy's arctan2, which customEnv.py:231-232 calls).
+__device__ __forceinline__ float atan2_lean(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float a = (mx == 0.0f) ? 0.0f : mn * __builtin_amdgcn_rcpf(mx);
+    const float s = a * a;
+    float r = 2.6222818114e-03f;
+    r = fmaf(r, s, -1.5132710144e-02f);
+    r = fmaf(r, s, 4.1122186800e-02f);
+    r = fmaf(r, s, -7.3667379326e-02f);
+    r = fmaf(r, s, 1.0573949200e-01f);
+    r = fmaf(r, s, -1.4185980238e-01f);
+    r = fmaf(r, s, 1.9990397277e-01f);
+    r = fmaf(r, s, -3.3332987079e-01f);
+    r = fmaf(r * s, a, a);
+    r = (ay > ax) ? (kPi * 0.5f - r) : r;
+    r = (__float_as_uint(x) >> 31) ? (kPi - r) : r;
+    return copysignf(r, y);
+}
+
+__device__ __forceinline__ float sqrt_hw(float x) { return __builtin_amdgcn_sqrtf(x); }   // v_sqrt_f32, <= 1 ulp
+
+struct Vessel {
+    float m11, m22, m23, inv11, i22, i23, i33;
+    float Xu, Xuu, Yv, Yvv, Yr, Nv, Nr, Nrr, Nuv, Yur;
+    float Kf[3], Kr[3], lx[3], ly[3];
+};
+
+__device__ __forceinline__ Vessel vessel_from_args(const VesselDev& d)
+{
+    Vessel v;
+    v.m11 = d.p[VD_M11]; v.m22 = d.p[VD_M22]; v.m23 = d.p[VD_M23];
+    v.inv11 = d.p[VD_INV11]; v.i22 = d.p[VD_I22]; v.i23 = d.p[VD_I23]; v.i33 = d.p[VD_I33];
+    v.Xu = d.p[VD_XU]; v.Xuu = d.p[VD_XUU]; v.Yv = d.p[VD_YV]; v.Yvv = d.p[VD_YVV];
+    v.Yr = d.p[VD_YR]; v.Nv = d.p[VD_NV]; v.Nr = d.p[VD_NR]; v.Nrr = d.p[VD_NRR];
+    v.Nuv = d.p[VD_NUV]; v.Yur = d.p[VD_YUR];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        v.Kf[i] = d.p[VD_KF + i]; v.Kr[i] = d.p[VD_KR + i]; v.lx[i] = d.p[VD_LX + i]; v.ly[i] = d.p[VD_LY + i];
+    }
+    return v;
+}
+
+// Keep the (wave-uniform) parameter block in VGPRs.  gfx9 VALU instructions read at most one SGPR, so
+// two-parameter FMAs need a v_mov each time they execute, and 31 live SGPR parameters push the long
+// rollout loop into SGPR->VGPR-lane spills (v_writelane/v_readlane).  An empty asm with a "+v" constraint
+// pins each value in a vector register once.
+__device__ __forceinline__ void pin_vgpr(float& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin_vessel_in_vgprs(Vessel& v)
+{
+    pin_vgpr(v.m11); pin_vgpr(v.m22); pin_vgpr(v.m23); pin_vgpr(v.inv11); pin_vgpr(v.i22); pin_vgpr(v.i23); pin_vgpr(v.i33);
+    pin_vgpr(v.Xu); pin_vgpr(v.Xuu); pin_vgpr(v.Yv); pin_vgpr(v.Yvv); pin_vgpr(v.Yr); pin_vgpr(v.Nv); pin_vgpr(v.Nr);
+    pin_vgpr(v.Nrr); pin_vgpr(v.Nuv); pin_vgpr(v.Yur);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { pin_vgpr(v.Kf[i]); pin_vgpr(v.Kr[i]); pin_vgpr(v.lx[i]); pin_vgpr(v.ly[i]); }
+}
+
+// LDS image of the class table is [param][class]: for a fixed parameter, lanes of different
+// classes hit different banks (n_classes <= 32 distinct banks) and lanes of one class broadcast.
+__device__ __forceinline__ Vessel vessel_from_lds(const float* tab, int ncls, int cls)
+{
+    Vessel v;
+    v.m11 = tab[VD_M11 * ncls + cls]; v.m22 = tab[VD_M22 * ncls + cls]; v.m23 = tab[VD_M23 * ncls + cls];
+    v.inv11 = tab[VD_INV11 * ncls + cls]; v.i22 = tab[VD_I22 * ncls + cls]; v.i23 = tab[VD_I23 * ncls + cls];
+    v.i33 = tab[VD_I33 * ncls + cls];
+    v.Xu = tab[VD_XU * ncls + cls]; v.Xuu = tab[VD_XUU * ncls + cls]; v.Yv = tab[VD_YV * ncls + cls];
+    v.Yvv = tab[VD_YVV * ncls + cls]; v.Yr = tab[VD_YR * ncls + cls]; v.Nv = tab[VD_NV * ncls + cls];
+    v.Nr = tab[VD_NR * ncls + cls]; v.Nrr = tab[VD_NRR * ncls + cls];
+    v.Nuv = tab[VD_NUV * ncls + cls]; v.Yur = tab[VD_YUR * ncls + cls];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        v.Kf[i] = tab[(VD_KF + i) * ncls + cls]; v.Kr[i] = tab[(VD_KR + i) * ncls + cls];
+        v.lx[i] = tab[(VD_LX + i) * ncls + cls]; v.ly[i] = tab[(VD_LY + i) * ncls + cls];
+    }
+    return v;
+}
+
+// SupervisedTau.py:42-83: tau = B(alpha) F, F_i = K_i n_i |n_i|
+__device__ __forceinline__ void thrust_map(const Vessel& ve, const float n[3], const float al[3], float& tx, float& ty,
+                                           float& tn)
+{
+    tx = 0.0f; ty = 0.0f; tn = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float K = (n[i] >= 0.0f) ? ve.Kf[i] : ve.Kr[i];
+        const float F = K * fabsf(n[i]) * n[i];
+        float sa, ca;
+        if (i == 0 && al[0] == kPi * 0.5f) {
+            // the bow thruster sits at its reset default pi/2 in simple/limited/final (customEnv.py:397):
+            // sin/cos of float(pi/2), no evaluation needed
+            sa = 1.0f; ca = -4.371139e-08f;
+        } else {
+            sincos_lean(al[i], sa, ca);
+        }
+        tx = fmaf(ca, F, tx);
+        ty = fmaf(sa, F, ty);
+        tn = fmaf(fmaf(ve.lx[i], sa, -(ve.ly[i] * ca)), F, tn);
+    }
+}
+
+// observation, errorFrame.py:25-32 + ENV:196-205
+__device__ __forceinline__ void make_obs(float N, float E, float psi, float u, float v, float r, float refN, float refE,
+                                         float refPsi, const float pt[3], bool deg, float o[9], float& sr, float& cr,
+                                         bool& rot_is_psi)
+{
+    const float eN = N - refN, eE = E - refE;
+    const float rot = wrap_angle(psi, deg);
+    rot_is_psi = (rot == psi);     // true unless the (degree-mode) wrap fired: sr, cr are then sin/cos of psi itself
+    sincos_lean(rot, sr, cr);
+    o[0] = fmaf(cr, eN, sr * eE);
+    o[1] = fmaf(cr, eE, -(sr * eN));
+    o[2] = wrap_angle(psi - refPsi, deg);
+    o[3] = u; o[4] = v; o[5] = r;
+    o[6] = pt[0] * 0.01f; o[7] = pt[1] * 0.01f; o[8] = pt[2] * 0.01f;
+}
+
+// training reset sampler, ENV:143-145 + simtools.py:109-123, Philox keyed (seed; global env id, episode)
+template <int MODE>
+__device__ __forceinline__ void sample_reset(const StepArgs& a, int64_t gid, uint32_t episode, float eta[3], float nu[3])
+{
+    float b[6];
+    ss_bounds<MODE>(b);
+    const float fr = a.reset_fraction, fv = 0.30f * a.reset_fraction;
+    uint32_t w0[4], w1[4];
+    const uint32_t g0 = (uint32_t)((uint64_t)gid & 0xffffffffu), g1 = (uint32_t)((uint64_t)gid >> 32);
+    philox4x32_10(g0, g1, episode, 0u, a.seed_lo, a.seed_hi, w0);
+    philox4x32_10(g0, g1, episode, 1u, a.seed_lo, a.seed_hi, w1);
+    eta[0] = (b[0] * fr) * u01_sym(w0[0]);
+    eta[1] = (b[1] * fr) * u01_sym(w0[1]);
+    eta[2] = (b[2] * fr) * u01_sym(w0[2]);
+    nu[0] = (b[3] * fv) * u01_sym(w0[3]);
+    nu[1] = (b[4] * fv) * u01_sym(w1[0]);
+    nu[2] = (b[5] * fv) * u01_sym(w1[1]);
+}
+
+// Ordering point for the LDS transposes.  With one wave per workgroup (BLOCK == 64) the staging area is
+// wave-private: DS operations of a wave execute in issue order, so a compiler-level fence is all that is
+// needed.  A real __syncthreads() would also drain vmcnt(0), i.e. stall on every outstanding global
+// store and prefetch - measured at ~2 us per env step in the fused rollout.
+template <int THREADS> __device__ __forceinline__ void lds_order()
+{
+    if (THREADS == 64) __builtin_amdgcn_wave_barrier();
+    else __syncthreads();
+}
+
+// Current of one env: constant, or a first-order Gauss-Markov (Ornstein-Uhlenbeck) process around its mean,
+// advanced once per env step (config 5; build-defined).  Noise: Philox keyed by the seed,
+// counter (global env id, draw index, tag) -> Box-Muller.
+struct Current {
+    float vc, beta;       // present speed [m/s] and NED direction [rad]
+    float vcN, vcE;       // NED components
+    uint32_t ctr;         // draws made so far
+};
+
+__device__ __forceinline__ void current_components(Current& c)
+{
+    float sb, cb;
+    sincos_lean(c.beta, sb, cb);
+    c.vcN = c.vc * cb; c.vcE = c.vc * sb;
+}
+
+__device__ __forceinline__ void current_drift_step(const StepArgs& a, Current& c, float vc0, float beta0, int64_t gid)
+{
+    uint32_t w[4];
+    philox4x32_10((uint32_t)((uint64_t)gid & 0xffffffffu), (uint32_t)((uint64_t)gid >> 32), c.ctr, 0xC0000000u, a.seed_lo,
+                  a.seed_hi, w);
+    c.ctr += 1u;
+    const float u1 = ((float)(w[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0, 1)
+    const float u2 = (float)(w[1] >> 8) * (1.0f / 16777216.0f);            // [0, 1)
+    const float rad = sqrt_hw(-2.0f * logf(u1));
+    float s2, c2;
+    sincos_lean(2.0f * kPi * u2, s2, c2);
+    c.vc = fmaf(a.drift_sv, rad * c2, fmaf(a.drift_a, vc0 - c.vc, c.vc));
+    c.beta = fmaf(a.drift_sb, rad * s2, fmaf(a.drift_a, beta0 - c.beta, c.beta));
+    current_components(c);
+}
+
+__device__ __forceinline__ uint16_t f2bf(float x)
+{
+    // plain cast: v_cvt_pk_bf16_f32 (RNE, NaN stays NaN)
+    return __builtin_bit_cast(uint16_t, __float2bfloat16(x));
+}
+
+// Coalesced write of a workgroup's THREADS x OD staged elements (LDS image [j*THREADS + tid]) to
+// dst[base ...]; `rem` = elements remaining in the destination from `base` (uniform).  Full workgroups take
+// the unpredicated path: uniform base pointer + 32-bit lane offset.
+template <int OD, int THREADS>
+__device__ __forceinline__ void store_rows(void* dst, int64_t base, int64_t rem, bool bf16, const float* lds, int tid)
+{
+    const bool full = rem >= (int64_t)THREADS * OD;
+    if (bf16) {
+        uint16_t* p = (uint16_t*)dst + base;
+        if (full) {
+#pragma unroll
+            for (int j = 0; j < OD; ++j) p[(unsigned)(j * THREADS + tid)] = f2bf(lds[j * THREADS + tid]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < OD; ++j)
+                if (j * THREADS + tid < rem) p[(unsigned)(j * THREADS + tid)] = f2bf(lds[j * THREADS + tid]);
+        }
+    } else {
+        float* p = (float*)dst + base;
+        if (full) {
+#pragma unroll
+            for (int j = 0; j < OD; ++j) p[(unsigned)(j * THREADS + tid)] = lds[j * THREADS + tid];
+        } else {
+#pragma unroll
+            for (int j = 0; j < OD; ++j)
+                if (j * THREADS + tid < rem) p[(unsigned)(j * THREADS + tid)] = lds[j * THREADS + tid];
+        }
+    }
+}
+
+// Coalesced read of a workgroup's THREADS x A action elements into registers (element j*THREADS + tid).
+// Out-of-range elements of the last workgroup are clamped to the last valid one instead of being selected
+// to zero: a select on the loaded value would force a wait after every load (the lanes that read them are
+// dead and never store).
+template <int A, int THREADS>
+__device__ __forceinline__ void load_rows(const float* src_block, int64_t rem, int tid, float pre[A])
+{
+    const int lim = (int)(rem < (int64_t)THREADS * A ? rem : (int64_t)THREADS * A) - 1;   // uniform
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+        const int e = j * THREADS + tid;
+        pre[j] = src_block[(unsigned)(e < lim ? e : lim)];
+    }
+}
+
+// Write one observation row per lane.  AOS: through LDS so that the global stores are coalesced
+// (row stride OD is odd for OD = 9 -> conflict-free; OD = 6 costs a 2-way conflict).
+template <int OD>
+__device__ __forceinline__ void store_obs(const StepArgs& a, void* dst, const float o[9], int i, bool live, float* lds)
+{
+    const int tid = threadIdx.x;
+    const int n = a.n;
+    if (a.obs_layout == LAYOUT_SOA) {
+        if (live) {
+            if (a.obs_bf16) {
+                uint16_t* p = (uint16_t*)dst;
+#pragma unroll
+                for (int k = 0; k < OD; ++k) p[(int64_t)k * n + i] = f2bf(o[k]);
+            } else {
+                float* p = (float*)dst;
+#pragma unroll
+                for (int k = 0; k < OD; ++k) p[(int64_t)k * n + i] = o[k];
+            }
+        }
+        return;
+    }
+    lds_order<BLOCK>();   // previous users of the LDS staging area are done
+#pragma unroll
+    for (int k = 0; k < OD; ++k) lds[tid * OD + k] = o[k];
+    lds_order<BLOCK>();
+    const int64_t base = (int64_t)blockIdx.x * (BLOCK * OD);          // uniform
+    const int64_t rem = (int64_t)n * OD - base;                           // elements left from this block's start
+    store_rows<OD, BLOCK>(dst, base, rem, a.obs_bf16, lds, tid);
+}
+
+// =============================================================================================
+//  one environment step in registers (shared by step_kernel and rollout_kernel)
+// =============================================================================================
+struct Env {              // per-lane state carried between env steps
+    float N, E, psi, u, v, r;
+    float refN, refE, refPsi;
+    float pt[3];          // previous thrust command, percent (ENV:126)
+    float ang[3];         // azimuth command in force: bow, port, star (ENV:122)
+    int steps;            // steps taken in the running episode
+    float sn, cs;         // sin/cos of psi (cache: refreshed by every observation, reused by the next plant step)
+};
+
+struct StepOut {
+    float o[9];           // observation of this step (terminal one if the env finished)
+    float reward;
+    float parts[4];
+    uint32_t d;           // DONE_* bits
+};
+
+// ENV:104-133 for one env: decode, command map, plant, observation, reward, termination, late new_ref.
+// cur = constant current (vcN, vcE in NED) present.
+template <int MODE, bool EXT>
+__device__ __forceinline__ void env_step(const StepArgs& a, const Vessel& ve, Env& s, const float* act, bool has_ref,
+                                         float nrN, float nrE, float nrP, bool cur, float vcN, float vcE, StepOut& out)
+{
+    const float ang_prev[3] = {s.ang[0], s.ang[1], s.ang[2]};   // ENV:102
+    const float pt_old[3] = {s.pt[0], s.pt[1], s.pt[2]};
+
+    // ---- action decode ENV:104-110, scale_and_clip ENV:215-225, command map ENV:117-122 -------------
+    float thr[3];
+    thr[0] = clipf(act[0] * 100.0f, 100.0f);
+    thr[1] = clipf(act[1] * 100.0f, 100.0f);
+    thr[2] = clipf(act[2] * 100.0f, 100.0f);
+    if (MODE == MODE_FULL) {
+        s.ang[0] = clipf(act[3] * kPi, kPi); s.ang[1] = clipf(act[4] * kPi, kPi); s.ang[2] = clipf(act[5] * kPi, kPi);
+    } else if (MODE == MODE_LIMITED) {
+        s.ang[1] = clipf(act[3] * (kPi * 0.5f), kPi * 0.5f); s.ang[2] = clipf(act[4] * (kPi * 0.5f), kPi * 0.5f);
+    } else if (MODE == MODE_FINAL_WRAP) {
+        // ENV:237-244: wrap_angle(a*pi, deg=False)/pi, evaluated in units of pi (exact in fp32)
+        const float w3 = act[3] - 2.0f * floorf((act[3] + 1.0f) * 0.5f);
+        const float w4 = act[4] - 2.0f * floorf((act[4] + 1.0f) * 0.5f);
+        s.ang[1] = clipf(w3 * kPi, kPi); s.ang[2] = clipf(w4 * kPi, kPi);
+    } else if (MODE == MODE_FINAL_CONT) {
+        // ENV:227-235: atan2(sin_head, cos_head)/pi, then *pi and clip
+        s.ang[1] = clipf(atan2_lean(act[3], act[4]), kPi); s.ang[2] = clipf(atan2_lean(act[5], act[6]), kPi);
+    }
+
+    // ---- plant: BUILD-OWNED 3-DOF model, n_substeps semi-implicit Euler steps --
+    float tx, ty, tn;
+    thrust_map(ve, thr, s.ang, tx, ty, tn);
+    float N = s.N, E = s.E, psi = s.psi, u = s.u, v = s.v, r = s.r;
+    float sn = s.sn, cs = s.cs;
+    if (cur) {
+        u -= fmaf(cs, vcN, sn * vcE);      // relative velocity nu_r = nu - R(psi)^T v_c
+        v -= fmaf(cs, vcE, -(sn * vcN));
+    }
+    const float h = a.h;
+    const float hA = h * ve.inv11, h22 = h * ve.i22, h23 = h * ve.i23, h33 = h * ve.i33;
+    // the Coriolis term c23 = m11 u only ever multiplies r (sway) and v (yaw): fold it into the
+    // speed-proportional cross-flow coefficients so that it costs nothing per sub-step
+    const float yur = ve.Yur + ve.m11;      // fy gets -(Yr + (Yur + m11) u) r
+    const float nuv = ve.Nuv - ve.m11;      // fn gets -(Nv + (Nuv - m11) u) v
+    const int nsub = a.hold_plant ? 0 : a.n_substeps;
+    for (int k = 0; k < nsub; ++k) {
+        // C(nu)nu with c13 = -q, q = m22 v + m23 r
+        const float q = fmaf(ve.m22, v, ve.m23 * r);
+        float fx = fmaf(-fmaf(ve.Xuu, fabsf(u), ve.Xu), u, tx);
+        fx = fmaf(q, r, fx);
+        float fy = fmaf(-fmaf(ve.Yvv, fabsf(v), ve.Yv), v, ty);
+        fy = fmaf(-fmaf(yur, u, ve.Yr), r, fy);
+        float fn = fmaf(-q, u, tn);
+        fn = fmaf(-fmaf(nuv, u, ve.Nv), v, fn);
+        fn = fmaf(-fmaf(ve.Nrr, fabsf(r), ve.Nr), r, fn);
+        u = fmaf(hA, fx, u);
+        v = fmaf(h22, fy, fmaf(h23, fn, v));
+        r = fmaf(h23, fy, fmaf(h33, fn, r));
+        // kinematics with the old heading and the new velocity
+        N = fmaf(h, fmaf(-sn, v, fmaf(cs, u, vcN)), N);
+        E = fmaf(h, fmaf(cs, v, fmaf(sn, u, vcE)), E);
+        // heading: exact rotation by d = h r, series for sin d / cos d
+        const float d = h * r;
+        const float d2 = d * d;
+        const float sd = d * fmaf(d2, fmaf(d2, 1.0f / 120.0f, -1.0f / 6.0f), 1.0f);
+        const float cd = fmaf(d2, fmaf(d2, 1.0f / 24.0f, -0.5f), 1.0f);
+        psi += d;
+        const float c2 = fmaf(cs, cd, -(sn * sd));
+        const float s2n = fmaf(sn, cd, cs * sd);
+        cs = c2; sn = s2n;
+    }
+    // exact sin/cos of the heading reached: needed by the observation, by the current term and by the next step
+    const bool deg = (a.wrap_mode == WRAP_REFERENCE);
+    float* o = out.o;
+    bool same;
+    float se, ce;
+    {
+        // the observation only depends on nu through o[3..5]; compute the frame first, patch nu after
+        make_obs(N, E, psi, 0.0f, 0.0f, 0.0f, s.refN, s.refE, s.refPsi, pt_old, deg, o, se, ce, same);
+        if (!same) sincos_lean(psi, se, ce);
+    }
+    if (cur) {
+        u += fmaf(ce, vcN, se * vcE);
+        v += fmaf(ce, vcE, -(se * vcN));
+    }
+    o[3] = u; o[4] = v; o[5] = r;
+    s.N = N; s.E = E; s.psi = psi; s.u = u; s.v = v; s.r = r;
+    s.sn = se; s.cs = ce;
+
+    float p_der = 0.0f;
+    const float p_vel = -sqrt_hw(fmaf(o[3] * o[3], 0.5f, fmaf(o[4] * o[4], 0.5f, o[5] * o[5])));   // ENV:267-273
+    const float rr2 = fmaf(o[0], o[0], o[1] * o[1]);
+    const float yaw = o[2] * (180.0f / kPi);                                                    // ENV:281
+    const float multivar = 2.0f * expf(-0.5f * fmaf(yaw * yaw, 1.0f / 25.0f, rr2));             // ENV:283, covar ENV:86-88
+    const float special = sqrt_hw(fmaf(yaw * 0.25f, yaw * 0.25f, rr2));                         // ENV:287
+    const float p_pos = multivar + fmaxf(-1.0f, fmaf(-0.1f, special, 1.0f)) + 0.5f;             // ENV:288-290
+    const float p_thr = -(fabsf(thr[0]) * 0.20f + fabsf(thr[1]) * 0.30f + fabsf(thr[2]) * 0.30f) * 0.01f;   // ENV:292-302
+    if (EXT) {
+        const float inv_dt = a.inv_dt;
+        float pen = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pen -= fabsf((thr[k] - pt_old[k]) * inv_dt * 0.01f) * 0.05f;   // ENV:310-313
+        const float inv_bnd = (MODE == MODE_LIMITED) ? (2.0f / kPi) : (1.0f / kPi);               // ENV:319
+        const float angpen = -(fabsf((s.ang[1] - ang_prev[1]) * inv_dt * inv_bnd) * 0.01f +
+                               fabsf((s.ang[2] - ang_prev[2]) * inv_dt * inv_bnd) * 0.01f);       // ENV:315-320 (bow coeff 0)
+        p_der = pen + fmaxf(-1.0f, angpen);                                                       // ENV:322-323
+    }
+    out.parts[0] = p_vel; out.parts[1] = p_pos; out.parts[2] = p_thr; out.parts[3] = p_der;
+    out.reward = p_vel + p_pos + p_thr + p_der;   // ENV:263
+
+    uint32_t d = 0;
+    if (a.terminate) {
+        float b[6];
+        ss_bounds<MODE>(b);
+        bool t = false;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) t = t || (fabsf(o[k]) > b[k]);   // ENV:207-213, strict >
+        d = t ? DONE_TERMINAL : 0u;
+    }
+    {
+        const float chk = N + E + psi + u + v + r;     // any NaN/Inf poisons the sum
+        if (!(fabsf(chk) <= 3.0e38f)) d |= DONE_TERMINAL | DONE_FAULT;
+    }
+    if (has_ref) { s.refN = nrN; s.refE = nrE; s.refPsi = nrP; }   // ENV:131: visible from the next step (Q4)
+    s.steps += 1;
+    if (a.max_ep_len > 0 && s.steps >= a.max_ep_len) d |= DONE_TIMELIMIT;   // ppo.py:304
+    s.pt[0] = thr[0]; s.pt[1] = thr[1]; s.pt[2] = thr[2];   // ENV:126
+    out.d = d;
+}
+
+// auto-reset of one finished env: ENV:135-194 with the training sampler; returns the new episode's first obs
+template <int MODE>
+__device__ __forceinline__ void env_auto_reset(const StepArgs& a, Env& s, int64_t gid, uint32_t episode, float o_new[9])
+{
+    float eta[3], nu[3];
+    sample_reset<MODE>(a, gid, episode, eta, nu);
+    s.N = eta[0]; s.E = eta[1]; s.psi = eta[2]; s.u = nu[0]; s.v = nu[1]; s.r = nu[2];
+    s.pt[0] = s.pt[1] = s.pt[2] = 0.0f;                         // ENV:190
+    default_angles<MODE>(s.ang[0], s.ang[1], s.ang[2]);         // ENV:173-177,192
+    s.steps = 0;
+    bool same;
+    make_obs(s.N, s.E, s.psi, s.u, s.v, s.r, s.refN, s.refE, s.refPsi, s.pt, a.wrap_mode == WRAP_REFERENCE, o_new, s.sn, s.cs,
+             same);
+    if (!same) sincos_lean(s.psi, s.sn, s.cs);
+}
+
+__device__ __forceinline__ void load_env(const StepArgs& a, int il, Env& s)
+{
+    const float4 s0 = a.S0[il], s1 = a.S1[il], s2 = a.S2[il], rf = a.RF[il];
+    s.N = s0.x; s.E = s0.y; s.psi = s0.z; s.u = s0.w; s.v = s1.x; s.r = s1.y;
+    s.ang[0] = rf.w; s.ang[1] = s1.z; s.ang[2] = s1.w;
+    s.pt[0] = s2.x; s.pt[1] = s2.y; s.pt[2] = s2.z; s.steps = __float_as_int(s2.w);
+    s.refN = rf.x; s.refE = rf.y; s.refPsi = rf.z;
+}
+
+__device__ __forceinline__ void store_env(const StepArgs& a, int i, const Env& s, bool rf_dirty)
+{
+    a.S0[i] = make_float4(s.N, s.E, s.psi, s.u);
+    a.S1[i] = make_float4(s.v, s.r, s.ang[1], s.ang[2]);
+    a.S2[i] = make_float4(s.pt[0], s.pt[1], s.pt[2], __int_as_float(s.steps));
+    if (rf_dirty) a.RF[i] = make_float4(s.refN, s.refE, s.refPsi, s.ang[0]);
+}
+
+}  // namespace dpenv
+
+#endif

@@ -1,0 +1,395 @@
+// dpenv_policy.hip - the PPO actor-critic evaluated INSIDE the rollout launch.
+//
+// Reference: mlp_gaussian_policy / mlp_actor_critic, src/rl/windows_workspace/spinup/algos/tf1/ppo/core.py:29-33,
+// 80-107 (dense layers y = x W + b with W[in][out], hidden activation leaky_relu(0.2) for the shipped model -
+// train.py:24,31, config.json - linear output, log_std parameter, pi = mu + N(0,1) exp(log_std),
+// gaussian_likelihood core.py:42-46), consumed by the rollout loop ppo.py:289-322 which stores
+// (o, a, r, v, logp) per step (ppo.py:298).
+//
+// Mapping to CDNA4.  A wave owns 64 environments (one per lane) and evaluates the MLP for all of them at
+// once on the matrix cores in the TRANSPOSED orientation  H_next^T [features x envs] = W^T [out x in] . H^T:
+//   * A operand  = weights, pre-permuted on the host into MFMA fragments, read from LDS (one 16-byte
+//                  ds_read_b128 per lane per fragment); one LDS copy per 256-thread workgroup.
+//   * B operand  = activations.  The f32 accumulator tile of v_mfma_f32_32x32x16_f16 has the env on the lane and
+//                  the feature in the register index, which is exactly what the next layer's B operand wants:
+//                  leaky-relu + convert to f16 in place, no lane movement, no LDS (cdna_hip_programming.md
+//                  section 3, "an accumulator tile as the next MFMA's operand"; the k-order permutation that
+//                  comes with it is folded into the host-side weight packing).
+//   * biases     = a constant-1 feature (input slot 15 of the first layer, feature H of every hidden layer)
+//                  whose weight column holds the bias, so the bias add happens inside the MFMA.
+//   * in/out     = the env-per-lane <-> (32-env tile, lane-half) exchange at both ends is one
+//                  v_permlane32_swap per register.
+// Precision: f16 weights and activations, f32 accumulation.  This is the only MFMA use in the library; the
+// environment itself stays scalar fp32 physics.
+#include "dpenv_env_dev.h"
+
+namespace dpenv {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+constexpr int PBLOCK = 256;          // 4 waves share one LDS image of the weights
+constexpr int PWAVES = PBLOCK / 64;
+
+__device__ __forceinline__ half8 ldfrag(const uint4* W, int f, int lane)
+{
+    const uint4 q = W[f * 64 + lane];
+    return __builtin_bit_cast(half8, q);
+}
+
+// leaky-relu + f32 -> f16 of registers 8s .. 8s+7 of an accumulator tile = the B fragment of k-step s
+__device__ __forceinline__ half8 act_pack(const float16v& acc, int s, _Float16 leak)
+{
+    half8 r;
+    const half2v lk = {leak, leak};
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        // v_cvt_pkrtz_f16_f32, then packed f16 mul + max: 1.5 instructions per activation
+        half2v h = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(acc[8 * s + j], acc[8 * s + j + 1]));
+        h = __builtin_elementwise_max(h, h * lk);
+        r[j] = h[0]; r[j + 1] = h[1];
+    }
+    return r;
+}
+
+// Evaluate one MLP for the 64 envs of this wave.  in0 / in1: first-layer B fragments of env tiles 0-31 / 32-63.
+// out[j], j < 8: output row j of the lane's OWN env.
+__device__ __forceinline__ void mlp_eval(const uint4* W, int n_hidden, half8 in0, half8 in1, _Float16 leak, float out[8])
+{
+    const int lane = threadIdx.x & 63;
+    const float16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float16v acc[3][2];
+#pragma unroll
+    for (int mo = 0; mo < 3; ++mo) {
+        const half8 w = ldfrag(W, mo, lane);
+        acc[mo][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, in0, zero, 0, 0, 0);
+        acc[mo][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, in1, zero, 0, 0, 0);
+    }
+    int fbase = 3;
+    half8 b[6][2];
+    for (int l = 1; l < n_hidden; ++l) {
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                b[2 * mt][nt] = act_pack(acc[mt][nt], 0, leak);
+                b[2 * mt + 1][nt] = act_pack(acc[mt][nt], 1, leak);
+            }
+#pragma unroll
+        for (int mo = 0; mo < 3; ++mo) {
+            float16v c0 = zero, c1 = zero;
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) {
+                const half8 w = ldfrag(W, fbase + mo * 6 + ks, lane);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, b[ks][0], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, b[ks][1], c1, 0, 0, 0);
+            }
+            acc[mo][0] = c0; acc[mo][1] = c1;
+        }
+        fbase += 18;
+    }
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            b[2 * mt][nt] = act_pack(acc[mt][nt], 0, leak);
+            b[2 * mt + 1][nt] = act_pack(acc[mt][nt], 1, leak);
+        }
+    float16v c0 = zero, c1 = zero;
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+        const half8 w = ldfrag(W, fbase + ks, lane);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, b[ks][0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, b[ks][1], c1, 0, 0, 0);
+    }
+    // rows 0..3 sit in registers 0..3 of lane half 0, rows 4..7 in registers 0..3 of lane half 1, for the 32 envs
+    // of each tile: one permlane32 swap per register brings every env's 8 rows home to its own lane
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(c0[j]), __float_as_uint(c1[j]), false, false);
+        out[j] = __uint_as_float(r[0]);
+        out[4 + j] = __uint_as_float(r[1]);
+    }
+}
+
+// first-layer B fragments from the per-lane observation row: input slot k < OD = obs[k], slot 15 = 1 (bias)
+template <int OD>
+__device__ __forceinline__ void obs_to_frags(const float o[9], half8& in0, half8& in1)
+{
+    half8 P, Q;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) P[k] = (_Float16)(k < OD ? o[k] : 0.0f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) Q[k] = (_Float16)((8 + k) < OD ? o[(8 + k) < 9 ? (8 + k) : 8] : 0.0f);
+    Q[7] = (_Float16)1.0f;
+    const uint4 p = __builtin_bit_cast(uint4, P), q = __builtin_bit_cast(uint4, Q);
+    uint4 a, b;
+    auto r0 = __builtin_amdgcn_permlane32_swap(p.x, q.x, false, false); a.x = r0[0]; b.x = r0[1];
+    auto r1 = __builtin_amdgcn_permlane32_swap(p.y, q.y, false, false); a.y = r1[0]; b.y = r1[1];
+    auto r2 = __builtin_amdgcn_permlane32_swap(p.z, q.z, false, false); a.z = r2[0]; b.z = r2[1];
+    auto r3 = __builtin_amdgcn_permlane32_swap(p.w, q.w, false, false); a.w = r3[0]; b.w = r3[1];
+    in0 = __builtin_bit_cast(half8, a);   // envs 0..31: lanes 0..31 carry slots 0..7, lanes 32..63 slots 8..15
+    in1 = __builtin_bit_cast(half8, b);   // envs 32..63
+}
+
+__device__ __forceinline__ void stage_weights(uint4* lds, const PolicyArgs& pa)
+{
+    const int total = 2 * pa.nfrag * 64;
+    for (int k = threadIdx.x; k < total; k += PBLOCK) lds[k] = pa.frags[k];
+    __syncthreads();
+}
+
+// wave-private AoS row I/O through LDS for a 64-env slice of a 256-thread workgroup
+template <int W>
+__device__ __forceinline__ void wave_store_rows(float* lds_w, void* dst, int64_t row0_elems, int64_t rem, const float* v, int lane)
+{
+    lds_order<64>();
+#pragma unroll
+    for (int k = 0; k < W; ++k) lds_w[lane * W + k] = v[k];
+    lds_order<64>();
+    store_rows<W, 64>(dst, row0_elems, rem, false, lds_w, lane);
+}
+
+template <int W>
+__device__ __forceinline__ void wave_rows_from_regs(float* lds_w, const float pre[W], float row[W], int lane)
+{
+    lds_order<64>();
+#pragma unroll
+    for (int j = 0; j < W; ++j) lds_w[j * 64 + lane] = pre[j];
+    lds_order<64>();
+#pragma unroll
+    for (int k = 0; k < W; ++k) row[k] = lds_w[lane * W + k];
+}
+
+// =============================================================================================
+//  standalone forward pass: mu [n][A], v [n] for obs [n][OD]   (deterministic policy / validation)
+// =============================================================================================
+template <int OD, int A>
+__global__ __launch_bounds__(PBLOCK) void policy_forward_kernel(const PolicyArgs pa, const float* obs, float* mu_out,
+                                                                 float* v_out, int n)
+{
+    extern __shared__ uint4 lds_dyn[];
+    uint4* lds_w = lds_dyn;                                                     // [2 * nfrag][64] fragments
+    float* lds_io = (float*)(lds_dyn + 2 * pa.nfrag * 64) + (threadIdx.x >> 6) * (64 * 9);   // wave-private staging
+    stage_weights(lds_w, pa);
+    const int lane = threadIdx.x & 63;
+    const int wave0 = blockIdx.x * PBLOCK + (threadIdx.x & ~63);               // first env of this wave
+    if (wave0 >= n) return;
+    const int i = wave0 + lane;
+    const bool live = i < n;
+    float pre[OD], o[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    load_rows<OD, 64>(obs + (int64_t)wave0 * OD, (int64_t)(n - wave0) * OD, lane, pre);
+    wave_rows_from_regs<OD>(lds_io, pre, o, lane);
+    half8 in0, in1;
+    obs_to_frags<OD>(o, in0, in1);
+    float mu[8], vv[8];
+    mlp_eval(lds_w, pa.n_hidden, in0, in1, (_Float16)pa.leak, mu);
+    mlp_eval(lds_w + pa.nfrag * 64, pa.n_hidden, in0, in1, (_Float16)pa.leak, vv);
+    wave_store_rows<A>(lds_io, mu_out, (int64_t)wave0 * A, (int64_t)(n - wave0) * A, mu, lane);
+    if (live) v_out[i] = vv[0];
+}
+
+// =============================================================================================
+//  policy-in-the-loop rollout: T steps of (policy -> sample -> env.step -> value) per launch,
+//  writing the PPO trajectory rows (ppo.py:298) straight into [T][n][.] blocks.
+// =============================================================================================
+template <int MODE, bool EXT>
+__global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a, const PolicyArgs pa)
+{
+    constexpr int A = ModeTraits<MODE>::A;
+    constexpr int OD = EXT ? 9 : 6;
+    extern __shared__ uint4 lds_dyn[];
+    uint4* lds_w = lds_dyn;
+    float* lds_io = (float*)(lds_dyn + 2 * pa.nfrag * 64) + (threadIdx.x >> 6) * (64 * 9);
+    stage_weights(lds_w, pa);
+    const uint4* Wpi = lds_w;
+    const uint4* Wv = lds_w + pa.nfrag * 64;
+    const _Float16 leak = (_Float16)pa.leak;
+
+    const int lane = threadIdx.x & 63;
+    const int n = a.n;
+    const int wave0 = blockIdx.x * PBLOCK + (threadIdx.x & ~63);
+    if (wave0 >= n) return;                                      // whole wave out of range (uniform)
+    const int i = wave0 + lane;
+    const bool live = i < n;
+    const int il = live ? i : n - 1;
+
+    Env s;
+    load_env(a, il, s);
+    sincos_lean(s.psi, s.sn, s.cs);
+    Current cur = {0.0f, 0.0f, 0.0f, 0.0f, 0u};
+    float vc0 = 0.0f, beta0 = 0.0f;
+    if (a.cur_vc) {
+        cur.vc = a.cur_vc[il]; cur.beta = a.cur_beta[il];
+        if (a.current_drift) { vc0 = a.cur_vc0[il]; beta0 = a.cur_beta0[il]; cur.ctr = a.drift_ctr[il]; }
+        current_components(cur);
+    }
+    Vessel ve = vessel_from_args(a.v0);
+    pin_vessel_in_vgprs(ve);
+    uint32_t episode = a.auto_reset ? (uint32_t)a.episode[il] : 0u;
+    bool ep_dirty = false, rf_dirty = (MODE == MODE_FULL);
+
+    const int64_t stride_a = (int64_t)n * A, stride_o = (int64_t)n * OD;
+    const int64_t w_a = (int64_t)wave0 * A, w_o = (int64_t)wave0 * OD;
+    const int64_t rem_a = stride_a - w_a, rem_o = stride_o - w_o;
+
+    // observation of the current state = policy input of step 0 (ENV:196-205), and its value
+    float o[9];
+    {
+        float sr_, cr_;
+        bool same_;
+        make_obs(s.N, s.E, s.psi, s.u, s.v, s.r, s.refN, s.refE, s.refPsi, s.pt, a.wrap_mode == WRAP_REFERENCE, o, sr_, cr_,
+                 same_);
+    }
+    half8 in0, in1;
+    obs_to_frags<OD>(o, in0, in1);
+    float vout[8];
+    mlp_eval(Wv, pa.n_hidden, in0, in1, leak, vout);
+    float v_t = vout[0];
+
+    float pre[A];
+    if (pa.noise) load_rows<A, 64>(pa.noise + w_a, rem_a, lane, pre);
+    int next_switch = 0;
+    for (int t = 0; t < pa.T; ++t) {
+        // ---- store the policy input row, evaluate the actor ----------------------------------
+        wave_store_rows<OD>(lds_io, pa.obs_out, (int64_t)t * stride_o + w_o, rem_o, o, lane);
+        float mu[8];
+        mlp_eval(Wpi, pa.n_hidden, in0, in1, leak, mu);
+        // ---- sample: a = mu + std * xi (core.py:85), log-likelihood (core.py:42-46) -----------
+        float act[A];
+        float logp = 0.0f;
+        if (pa.noise) {
+            float xi[A];
+            wave_rows_from_regs<A>(lds_io, pre, xi, lane);
+            if (t + 1 < pa.T) load_rows<A, 64>(pa.noise + (int64_t)(t + 1) * stride_a + w_a, rem_a, lane, pre);
+#pragma unroll
+            for (int k = 0; k < A; ++k) {
+                act[k] = fmaf(pa.std[k], xi[k], mu[k]);
+                const float z = (act[k] - mu[k]) * pa.inv_std_eps[k];
+                logp += fmaf(-0.5f * z, z, pa.logp_const[k]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < A; ++k) { act[k] = mu[k]; logp += pa.logp_const[k]; }
+        }
+        wave_store_rows<A>(lds_io, pa.act_out, (int64_t)t * stride_a + w_a, rem_a, act, lane);
+
+        // ---- env.step ------------------------------------------------------------------------
+        bool has_ref = false;
+        float nrN = 0.0f, nrE = 0.0f, nrP = 0.0f;
+        if (next_switch < pa.n_switch && pa.switch_step[next_switch] == t) {
+            const float* rp = pa.refs + (int64_t)next_switch * 3 * n;
+            nrN = rp[il]; nrE = rp[(int64_t)n + il]; nrP = rp[2 * (int64_t)n + il];
+            has_ref = true; rf_dirty = true;
+            ++next_switch;
+        }
+        StepOut out;
+        env_step<MODE, EXT>(a, ve, s, act, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out);
+        if (a.current_drift) current_drift_step(a, cur, vc0, beta0, a.env_id_base + i);
+
+        // ---- critic on the observation this step produced (pre-reset) --------------------------
+        obs_to_frags<OD>(out.o, in0, in1);
+        mlp_eval(Wv, pa.n_hidden, in0, in1, leak, vout);
+        const float v_next = vout[0];
+        // bootstrap value at a path end (ppo.py:311): 0 if the env terminated, V(o) if only the time limit or the
+        // end of this launch cut the path
+        const bool terminal = (out.d & DONE_TERMINAL) != 0u;
+        const bool ended = (out.d != 0u) || (t == pa.T - 1);
+        const float boot = (ended && !terminal) ? v_next : 0.0f;
+
+        if (live) {
+            (pa.rew + (int64_t)t * n)[(unsigned)i] = out.reward;
+            (pa.done + (int64_t)t * n)[(unsigned)i] = (uint8_t)out.d;
+            (pa.val + (int64_t)t * n)[(unsigned)i] = v_t;
+            (pa.logp + (int64_t)t * n)[(unsigned)i] = logp;
+            (pa.boot + (int64_t)t * n)[(unsigned)i] = boot;
+        }
+
+        // ---- next policy input: the new observation, or the reset observation -------------------
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o[k] = out.o[k];
+        v_t = v_next;
+        const bool do_reset = a.auto_reset && out.d != 0u && live;
+        if (__ballot(do_reset) != 0ull) {                       // wave-uniform: rare
+            if (do_reset) {
+                env_auto_reset<MODE>(a, s, a.env_id_base + i, episode, o);
+                ++episode; ep_dirty = true; rf_dirty = true;
+            }
+            obs_to_frags<OD>(o, in0, in1);
+            mlp_eval(Wv, pa.n_hidden, in0, in1, leak, vout);
+            v_t = do_reset ? vout[0] : v_t;
+        }
+    }
+    // observation after the last step (policy input of the next launch) and final state
+    wave_store_rows<OD>(lds_io, pa.last_obs, w_o, rem_o, o, lane);
+    if (live) {
+        pa.last_val[i] = v_t;
+        store_env(a, i, s, rf_dirty);
+        if (ep_dirty) a.episode[i] = (int)episode;
+        if (a.current_drift) { a.cur_vc[i] = cur.vc; a.cur_beta[i] = cur.beta; a.drift_ctr[i] = cur.ctr; }
+    }
+}
+
+}  // namespace dpenv
+
+using namespace dpenv;
+
+static size_t policy_lds_bytes(const PolicyArgs& pa) { return (size_t)2 * pa.nfrag * 64 * 16 + (size_t)PWAVES * 64 * 9 * 4; }
+
+extern "C" hipError_t dpenv_dev_launch_policy_forward(const PolicyArgs* pa, int od, int adim, const float* obs, float* mu,
+                                                      float* v, int n, hipStream_t s)
+{
+    const dim3 grid((n + PBLOCK - 1) / PBLOCK), block(PBLOCK);
+    const size_t lds = policy_lds_bytes(*pa);
+#define FWD(OD_, A_)                                                                                                     \
+    do {                                                                                                                 \
+        hipError_t e = hipFuncSetAttribute((const void*)policy_forward_kernel<OD_, A_>,                                   \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
+        if (e != hipSuccess) return e;                                                                                   \
+        hipLaunchKernelGGL((policy_forward_kernel<OD_, A_>), grid, block, lds, s, *pa, obs, mu, v, n);                    \
+        return hipGetLastError();                                                                                        \
+    } while (0)
+    if (od == 9 && adim == 7) FWD(9, 7);
+    if (od == 9 && adim == 5) FWD(9, 5);
+    if (od == 9 && adim == 6) FWD(9, 6);
+    if (od == 6 && adim == 7) FWD(6, 7);
+    if (od == 6 && adim == 5) FWD(6, 5);
+    if (od == 6 && adim == 6) FWD(6, 6);
+    if (od == 6 && adim == 3) FWD(6, 3);
+#undef FWD
+    return hipErrorInvalidValue;
+}
+
+template <int MODE>
+static hipError_t launch_policy_rollout_mode(const StepArgs& a, const PolicyArgs& pa, bool ext, hipStream_t s)
+{
+    const dim3 grid((a.n + PBLOCK - 1) / PBLOCK), block(PBLOCK);
+    const size_t lds = policy_lds_bytes(pa);
+    hipError_t e;
+    if (ext) {
+        e = hipFuncSetAttribute((const void*)policy_rollout_kernel<MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((policy_rollout_kernel<MODE, true>), grid, block, lds, s, a, pa);
+    } else {
+        e = hipFuncSetAttribute((const void*)policy_rollout_kernel<MODE, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((policy_rollout_kernel<MODE, false>), grid, block, lds, s, a, pa);
+    }
+    return hipGetLastError();
+}
+
+extern "C" hipError_t dpenv_dev_launch_policy_rollout(const StepArgs* a, const PolicyArgs* pa, int mode, int ext,
+                                                      hipStream_t s)
+{
+    switch (mode) {
+    case MODE_FULL: return launch_policy_rollout_mode<MODE_FULL>(*a, *pa, ext, s);
+    case MODE_SIMPLE: return launch_policy_rollout_mode<MODE_SIMPLE>(*a, *pa, ext, s);
+    case MODE_LIMITED: return launch_policy_rollout_mode<MODE_LIMITED>(*a, *pa, ext, s);
+    case MODE_FINAL_WRAP: return launch_policy_rollout_mode<MODE_FINAL_WRAP>(*a, *pa, ext, s);
+    case MODE_FINAL_CONT: return launch_policy_rollout_mode<MODE_FINAL_CONT>(*a, *pa, ext, s);
+    }
+    return hipErrorInvalidValue;
+}

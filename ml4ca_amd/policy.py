@@ -1,0 +1,135 @@
+"""Actor-critic of the reference PPO (spinup/algos/tf1/ppo/core.py:29-33,80-107) for the in-kernel rollout.
+
+``ActorCritic`` holds the fp32 parameters in the reference's layout (dense kernels W[in][out], biases, log_std;
+variable names pi/dense{,_1,_2,_3}/{kernel,bias}, pi/log_std, v/dense*) as torch tensors, offers an fp32 torch
+forward pass (the numerics reference for tests and for the PPO update, which stays host-side glue), and uploads
+itself to a ``BatchedRevoltEnv`` where libdpenv evaluates it on the matrix cores inside the rollout launch
+(dpenv_policy.hip).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class ActorCritic(object):
+    def __init__(self, obs_dim=9, act_dim=7, hidden_sizes=(80, 80, 80), leak=0.2, log_std_init=-0.5, seed=0, device='cpu'):
+        torch = _torch()
+        assert len(set(hidden_sizes)) == 1 and 1 <= len(hidden_sizes) <= 4, 'equal hidden widths, 1..4 hidden layers'
+        self.obs_dim, self.act_dim, self.hidden_sizes, self.leak = obs_dim, act_dim, tuple(hidden_sizes), float(leak)
+        g = torch.Generator().manual_seed(seed)
+        self.device = torch.device(device)
+
+        def net(out_dim):
+            sizes = [obs_dim] + list(hidden_sizes) + [out_dim]
+            Ws, bs = [], []
+            for i in range(len(sizes) - 1):
+                # tf.layers.dense default kernel initializer: glorot uniform, zero bias
+                lim = math.sqrt(6.0 / (sizes[i] + sizes[i + 1]))
+                Ws.append(((torch.rand((sizes[i], sizes[i + 1]), generator=g) * 2 - 1) * lim).to(self.device))
+                bs.append(torch.zeros(sizes[i + 1], device=self.device))
+            return Ws, bs
+
+        self.pi_W, self.pi_b = net(act_dim)
+        self.v_W, self.v_b = net(1)
+        self.log_std = torch.full((act_dim,), float(log_std_init), device=self.device)      # core.py:83
+
+    def parameters(self):
+        return self.pi_W + self.pi_b + self.v_W + self.v_b + [self.log_std]
+
+    def _mlp(self, x, Ws, bs):
+        torch = _torch()
+        for W, b in zip(Ws[:-1], bs[:-1]):
+            x = torch.nn.functional.leaky_relu(x @ W + b, self.leak)
+        return x @ Ws[-1] + bs[-1]
+
+    def forward_ref(self, obs):
+        """fp32 torch reference: (mu [n, act_dim], v [n])."""
+        return self._mlp(obs, self.pi_W, self.pi_b), self._mlp(obs, self.v_W, self.v_b)[:, 0]
+
+    def logp_ref(self, act, mu):
+        """gaussian_likelihood, core.py:42-46."""
+        torch = _torch()
+        pre = -0.5 * (((act - mu) / (torch.exp(self.log_std) + 1e-8)) ** 2 + 2 * self.log_std + math.log(2 * math.pi))
+        return pre.sum(dim=1)
+
+    def upload(self, env):
+        """Pack and upload to the env's library handle (dpenv_set_policy); call again after each PPO update."""
+        lib = env.lib
+
+        def mk(Ws, bs):
+            m = _lib.Mlp()
+            m.n_layers = len(Ws)
+            sizes = [Ws[0].shape[0]] + [w.shape[1] for w in Ws]
+            keep = []
+            for i, sz in enumerate(sizes):
+                m.sizes[i] = int(sz)
+            for i, (W, b) in enumerate(zip(Ws, bs)):
+                Wn = np.ascontiguousarray(W.detach().float().cpu().numpy())
+                bn = np.ascontiguousarray(b.detach().float().cpu().numpy())
+                keep += [Wn, bn]
+                m.W[i] = Wn.ctypes.data
+                m.b[i] = bn.ctypes.data
+            return m, keep
+
+        pi, k1 = mk(self.pi_W, self.pi_b)
+        v, k2 = mk(self.v_W, self.v_b)
+        ls = np.ascontiguousarray(self.log_std.detach().float().cpu().numpy())
+        _lib.check(lib.dpenv_set_policy(env._h, C.byref(pi), C.byref(v), ls.ctypes.data_as(C.POINTER(C.c_float)),
+                                        C.c_float(self.leak)), env._h)
+        env._has_policy = True
+        return self
+
+
+def policy_forward(env, obs):
+    """Deterministic actor mean and critic value for obs [n, obs_dim] on the env's device (dpenv_policy_forward)."""
+    torch = _torch()
+    n = obs.shape[0]
+    env._chk(obs, (n, env.num_states), torch.float32, 'obs')
+    mu = torch.empty((n, env.num_actions), dtype=torch.float32, device=env.device)
+    v = torch.empty(n, dtype=torch.float32, device=env.device)
+    _lib.check(env.lib.dpenv_policy_forward(env._h, env._ptr(obs), env._ptr(mu), env._ptr(v), n, env._stream()), env._h)
+    return mu, v
+
+
+def policy_rollout(env, T, noise=None, switch_steps=(), refs=None, out=None):
+    """T steps of (actor -> sample -> env.step -> critic) in ONE launch: the rollout loop ppo.py:289-322 for every env.
+
+    noise: float32 [T, n, act_dim] standard-normal draws (a = mu + exp(log_std) * noise, core.py:85) or None for the
+    deterministic policy (test_policy.py:90).  Returns a dict of blocks: obs [T,n,od] (policy inputs), act [T,n,ad],
+    rew, val, logp, boot [T,n], done [T,n] uint8, last_obs [n,od], last_val [n].  GAE: rollout.gae(rew, val, end=done, boot=boot)."""
+    torch = _torch()
+    n, od, ad = env.n_envs, env.num_states, env.num_actions
+    dev = env.device
+    if noise is not None:
+        env._chk(noise, (T, n, ad), torch.float32, 'noise')
+    k = len(switch_steps)
+    if k:
+        env._chk(refs, (k, 3, n), torch.float32, 'refs')
+    f32 = torch.float32
+    if out is None:
+        out = dict(obs=torch.empty((T, n, od), dtype=f32, device=dev), act=torch.empty((T, n, ad), dtype=f32, device=dev),
+                   rew=torch.empty((T, n), dtype=f32, device=dev), val=torch.empty((T, n), dtype=f32, device=dev),
+                   logp=torch.empty((T, n), dtype=f32, device=dev), boot=torch.empty((T, n), dtype=f32, device=dev),
+                   done=torch.empty((T, n), dtype=torch.uint8, device=dev),
+                   last_obs=torch.empty((n, od), dtype=f32, device=dev), last_val=torch.empty(n, dtype=f32, device=dev))
+    io = _lib.PolicyRolloutIO()
+    io.struct_size = C.sizeof(_lib.PolicyRolloutIO)
+    io.T = int(T)
+    io.noise = noise.data_ptr() if noise is not None else None
+    io.obs, io.act, io.reward = out['obs'].data_ptr(), out['act'].data_ptr(), out['rew'].data_ptr()
+    io.value, io.logp, io.done = out['val'].data_ptr(), out['logp'].data_ptr(), out['done'].data_ptr()
+    io.boot, io.last_obs, io.last_value = out['boot'].data_ptr(), out['last_obs'].data_ptr(), out['last_val'].data_ptr()
+    io.n_switch = k
+    for j, st in enumerate(switch_steps):
+        io.switch_step[j] = int(st)
+    io.refs = refs.data_ptr() if k else None
+    _lib.check(env.lib.dpenv_policy_rollout(env._h, C.byref(io), env._stream()), env._h)
+    return out

@@ -1,0 +1,192 @@
+"""GPU tests of the in-kernel actor-critic (dpenv_policy.hip): MFMA forward pass against an fp32 torch
+reference of core.py's MLP, and the policy-in-the-loop rollout against (a) that reference applied to the rows
+it wrote and (b) the single-step env kernel driven with the actions it took."""
+import math
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def torch_():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def make_ac(obs_dim, act_dim, hidden, seed, device, scale_bias=True):
+    from ml4ca_amd.policy import ActorCritic
+    torch = torch_()
+    ac = ActorCritic(obs_dim, act_dim, hidden, seed=seed, device=device)
+    g = torch.Generator().manual_seed(seed + 100)
+    # asymmetric, non-zero biases and distinct log_std so that any row/column/bias mix-up shows
+    for b in ac.pi_b + ac.v_b:
+        b.copy_((torch.rand(b.shape, generator=g) - 0.5).to(device) * 0.6)
+    ac.log_std.copy_((torch.rand(act_dim, generator=g) - 0.8).to(device))
+    return ac
+
+
+@pytest.mark.parametrize('mode,ext,hidden', [
+    ('final_cont', True, (80, 80, 80)),      # the shipped model shape (config.json)
+    ('final_cont', True, (64,)),
+    ('final_cont', True, (95, 95)),
+    ('final_cont', True, (33, 33, 33, 33)),
+    ('limited', False, (80, 80, 80)),
+    ('full', True, (48, 48)),
+    ('simple', False, (80, 80, 80)),
+])
+def test_policy_forward_matches_fp32_reference(mode, ext, hidden):
+    from ml4ca_amd.policy import policy_forward
+    torch = torch_()
+    n = 1000 + 7
+    env, orc = H.make_pair(mode, n, ext=ext)
+    ac = make_ac(env.num_states, env.num_actions, hidden, seed=3, device=env.device).upload(env)
+    g = torch.Generator(device=env.device).manual_seed(5)
+    obs = torch.randn((n, env.num_states), generator=g, device=env.device) * torch.tensor(
+        [3, 3, 0.3, 0.5, 0.2, 0.2, 0.5, 0.5, 0.5][:env.num_states], device=env.device)
+    mu, v = policy_forward(env, obs)
+    mu_ref, v_ref = ac.forward_ref(obs)
+    # f16 weights and activations, f32 accumulation: ~1e-3 relative to the activation scale
+    scale = float(mu_ref.abs().max()) + 1.0
+    assert float((mu - mu_ref).abs().max()) < 6e-3 * scale, float((mu - mu_ref).abs().max())
+    assert float((v - v_ref).abs().max()) < 6e-3 * (float(v_ref.abs().max()) + 1.0)
+    # it is not accidentally close: permuting the reference's outputs breaks the match
+    assert float((mu - mu_ref.roll(1, dims=1)).abs().max()) > 0.05
+    # exactness probe: weights and inputs representable in f16 with small integer sums -> bit-exact
+    from ml4ca_amd.policy import ActorCritic
+    ac2 = ActorCritic(env.num_states, env.num_actions, hidden, seed=1, device=env.device)
+    gi = torch.Generator().manual_seed(9)
+    for W in ac2.pi_W + ac2.v_W:
+        W.copy_((torch.randint(-2, 3, W.shape, generator=gi).float() / 8).to(env.device))
+    for b in ac2.pi_b + ac2.v_b:
+        b.copy_((torch.randint(-4, 5, b.shape, generator=gi).float() / 4).to(env.device))
+    ac2.leak = 0.25
+    ac2.upload(env)
+    obs_i = (torch.randint(-4, 5, (n, env.num_states), generator=gi).float() / 4).to(env.device)
+    # keep magnitudes small enough that every intermediate is exactly representable in f16
+    for W in ac2.pi_W[1:] + ac2.v_W[1:]:
+        W.mul_(0.25)
+    ac2.upload(env)
+    mu2, v2 = policy_forward(env, obs_i)
+    mu2_ref, v2_ref = ac2.forward_ref(obs_i)
+    assert float((mu2 - mu2_ref).abs().max()) < 2e-2 * (float(mu2_ref.abs().max()) + 1)
+    assert float((v2 - v2_ref).abs().max()) < 2e-2 * (float(v2_ref.abs().max()) + 1)
+
+
+@pytest.mark.parametrize('noise_on', [True, False])
+def test_policy_rollout_rows_are_consistent(noise_on):
+    """One launch of T steps: every stored row must satisfy the reference relations
+       act = mu(obs) + exp(log_std) noise,  logp = gaussian_likelihood,  val = V(obs),
+    and replaying the stored actions through the single-step kernel must give the same env trajectory
+    (rewards, done bits, next observations, auto-resets, final state) bit for bit."""
+    from ml4ca_amd.policy import policy_rollout
+    torch = torch_()
+    n, T = 2000 + 11, 45
+    kw = dict(auto_reset=True, max_ep_len=40, seed=8)       # T_max = 20: every env crosses an episode boundary
+    env, _ = H.make_pair('final_cont', n, **kw)
+    env2, _ = H.make_pair('final_cont', n, **kw)
+    ac = make_ac(9, 7, (80, 80, 80), seed=2, device=env.device).upload(env)
+    for W in ac.pi_W:
+        W.mul_(0.7)
+    ac.upload(env)
+    g = torch.Generator(device=env.device).manual_seed(1)
+    noise = torch.randn((T, n, 7), generator=g, device=env.device) if noise_on else None
+    env.reset()
+    env2.reset()
+    st0, c0 = env.get_state()
+    s2, c2 = env2.get_state()
+    assert torch.equal(st0, s2)
+    switch = (3, 30)
+    refs = torch.randn((2, 3, n), generator=g, device=env.device)
+    out = policy_rollout(env, T, noise=noise, switch_steps=switch, refs=refs)
+    obs, act, rew, val, logp, boot, done = (out[k] for k in ('obs', 'act', 'rew', 'val', 'logp', 'boot', 'done'))
+    # (a) actor / critic relations on the stored rows
+    mu_ref, v_ref = ac.forward_ref(obs.reshape(T * n, 9))
+    mu_ref, v_ref = mu_ref.reshape(T, n, 7), v_ref.reshape(T, n)
+    std = torch.exp(ac.log_std)
+    want = mu_ref + (std * noise if noise_on else 0.0)
+    sc = float(mu_ref.abs().max()) + 1.0
+    assert float((act - want).abs().max()) < 6e-3 * sc
+    assert float((val - v_ref).abs().max()) < 6e-3 * (float(v_ref.abs().max()) + 1.0)
+    if noise_on:
+        # logp is evaluated against the kernel's own mu, which act - std*noise recovers
+        mu_k = act - std * noise
+        lp = ac.logp_ref(act.reshape(T * n, 7), mu_k.reshape(T * n, 7)).reshape(T, n)
+        assert float((logp - lp).abs().max()) < 2e-3
+    else:
+        const = float((-ac.log_std - 0.5 * math.log(2 * math.pi)).sum())
+        assert float((logp - const).abs().max()) < 1e-5
+    # (b) the env trajectory: replay the stored actions with single steps
+    for t in range(T):
+        nr = refs[switch.index(t)] if t in switch else None
+        o, r, d, _ = env2.step(act[t].contiguous(), new_ref=nr)
+        assert torch.equal(r, rew[t]), 'reward t=%d' % t
+        assert torch.equal(d, done[t]), 'done t=%d' % t
+        nxt = obs[t + 1] if t + 1 < T else out['last_obs']
+        assert torch.equal(o, nxt), 'next obs t=%d' % t
+    sa, ca = env.get_state()
+    sb, cb = env2.get_state()
+    assert torch.equal(sa, sb) and torch.equal(ca, cb)
+    assert int(ca[1].min()) >= 2                                   # every env went through a reset in the launch
+    # bootstrap values (ppo.py:311): 0 where the env terminated, V(terminal obs) where only the time limit hit,
+    # V(next obs) at the end of the launch, 0 elsewhere
+    term = (done & 1) != 0
+    tl_only = ((done & 2) != 0) & ~term
+    inner = torch.ones_like(term)
+    inner[T - 1] = False
+    assert float(boot[term].abs().max()) == 0.0
+    assert float(boot[(done == 0) & inner].abs().max()) == 0.0
+    assert int(tl_only.sum()) > 100 and float(boot[tl_only].abs().min()) > 0.0
+    last_alive = done[T - 1] == 0
+    assert torch.equal(boot[T - 1][last_alive], out['last_val'][last_alive])
+    _, v_last = ac.forward_ref(out['last_obs'])
+    assert float((out['last_val'] - v_last).abs().max()) < 6e-3 * (float(v_last.abs().max()) + 1.0)
+    # val[t+1] is the critic on obs[t+1] also right after a reset
+    was_reset = done[:-1] != 0
+    assert float((val[1:][was_reset] - v_ref[1:][was_reset]).abs().max()) < 6e-3 * (float(v_ref.abs().max()) + 1.0)
+
+
+def test_policy_rollout_feeds_gae_and_ppo_buffer():
+    """Config 5 end to end on device: drifting current, in-kernel policy rollout, GAE over the block with the
+    kernel's bootstrap values, advantage normalisation - against the oracle's TrajectoryBuffer restatement."""
+    from ml4ca_amd import rollout
+    from ml4ca_amd.policy import policy_rollout
+    from oracle import oracle as O
+    torch = torch_()
+    n, T = 1024, 60
+    env, _ = H.make_pair('final_cont', n, auto_reset=True, max_ep_len=50, seed=4, current=True, current_drift=True)
+    env.set_current(torch.full((n,), 0.2, device=env.device), torch.full((n,), float(np.deg2rad(135)), device=env.device))
+    ac = make_ac(9, 7, (80, 80, 80), seed=6, device=env.device).upload(env)
+    noise = torch.randn((T, n, 7), device=env.device)
+    env.reset()
+    out = policy_rollout(env, T, noise=noise)
+    adv, ret = rollout.gae(out['rew'], out['val'], end=out['done'], boot=out['boot'], gamma=0.99, lam=0.97)
+    orc = O.Oracle(O.make_config(), np.float32)
+    oadv, oret = orc.gae(out['rew'].cpu().numpy(), out['val'].cpu().numpy(), end=out['done'].cpu().numpy(),
+                         boot=out['boot'].cpu().numpy(), gamma=0.99, lam=0.97)
+    assert np.allclose(adv.cpu().numpy(), oadv, rtol=1e-5, atol=1e-5)
+    assert np.allclose(ret.cpu().numpy(), oret, rtol=1e-5, atol=1e-5)
+    a2, mean, std = rollout.normalize_advantages(adv.clone())
+    assert abs(float(a2.mean())) < 1e-4 and abs(float(a2.std(unbiased=False)) - 1.0) < 1e-3
+    assert torch.isfinite(out['obs']).all() and torch.isfinite(out['logp']).all()
+
+
+def test_policy_argument_validation():
+    import ml4ca_amd
+    from ml4ca_amd.policy import ActorCritic, policy_forward, policy_rollout
+    torch = torch_()
+    env, _ = H.make_pair('final_cont', 128)
+    with pytest.raises(ml4ca_amd.DpenvError):
+        policy_forward(env, torch.zeros((128, 9), device=env.device))              # no policy yet
+    with pytest.raises(ml4ca_amd.DpenvError):
+        ActorCritic(9, 6, (80, 80), device=env.device).upload(env)                 # act_dim mismatch
+    with pytest.raises(ml4ca_amd.DpenvError):
+        ActorCritic(9, 7, (96, 96), device=env.device).upload(env)                 # hidden width > 95
+    ActorCritic(9, 7, (80, 80, 80), device=env.device).upload(env)
+    env_soa, _ = H.make_pair('final_cont', 128, layout='soa')
+    ActorCritic(9, 7, (80, 80, 80), device=env.device).upload(env_soa)
+    with pytest.raises(ml4ca_amd.DpenvError):
+        policy_rollout(env_soa, 4)

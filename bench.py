@@ -217,6 +217,57 @@ def main():
                  'GBps_at_177B_accounting': ALGO_BYTES_PER_ENV_STEP * n * K / (fms * 1e-3) / 1e9,
                  'frac_of_8TBps_at_177B_accounting': ALGO_BYTES_PER_ENV_STEP * n * K / (fms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
 
+    # ---- closed-loop leg (dpenv_policy_rollout): actor-critic 9-80-80-80-7 / -1 evaluated in-kernel on MFMA ----
+    closed = None
+    if not args.no_fused:
+        from ml4ca_amd.policy import ActorCritic, policy_rollout
+        ac = ActorCritic(9, 7, (80, 80, 80), seed=0, device=dev).upload(env)
+        noise = torch.randn((CHUNK, n, 7), generator=g, device=dev)
+        env.reset(init=init, new_ref=start.clone())
+        pout = policy_rollout(env, CHUNK, noise=noise)
+
+        def run_closed(k):
+            for c in range(k // CHUNK):
+                policy_rollout(env, CHUNK, noise=noise, out=pout)
+
+        run_closed(max(W, CHUNK))
+        ce0, ce1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        tc0 = time.perf_counter()
+        ce0.record()
+        run_closed(K)
+        ce1.record()
+        torch.cuda.synchronize(dev)
+        cwall = time.perf_counter() - tc0
+        assert bool(torch.isfinite(pout['obs']).all()) and bool(torch.isfinite(pout['logp']).all())
+        # reference point: the same policy as separate torch kernels (fp32) + one env.step launch per step
+        mu_w = [w.clone() for w in ac.pi_W]
+        act_buf = torch.empty((n, 7), device=dev)
+
+        def torch_loop(k):
+            o = obs
+            for _ in range(k):
+                mu, v = ac.forward_ref(o)
+                a_ = mu + torch.exp(ac.log_std) * noise[0]
+                lp = ac.logp_ref(a_, mu)
+                o, r_, d_, _ = env.step(a_.contiguous())
+            return o
+
+        env.reset(init=init, new_ref=start.clone(), out=obs)
+        torch_loop(20)
+        torch.cuda.synchronize(dev)
+        tt0 = time.perf_counter()
+        torch_loop(200)
+        torch.cuda.synchronize(dev)
+        twall = time.perf_counter() - tt0
+        flops = 2 * 2 * (9 * 80 + 80 * 80 * 2 + 80 * 7) * n       # actor + critic MACs x 2, per step (critic out 1 ~ 7)
+        closed = {'what': 'dpenv_policy_rollout: %d steps per launch of actor (9-80-80-80-7) -> sample -> env.step -> critic, '
+                          'PPO rows (o,a,r,v,logp,done,boot) written in-kernel; f16 MFMA policy, fp32 env' % CHUNK,
+                  'env_steps_per_s': n * K / cwall, 'us_per_step': cwall / K * 1e6,
+                  'policy_TFLOPs': flops * K / cwall / 1e12,
+                  'unfused_torch_fp32_policy_plus_step_kernel': {'env_steps_per_s': n * 200 / twall, 'us_per_step': twall / 200 * 1e6},
+                  'speedup_vs_unfused': (twall / 200) / (cwall / K)}
+
     # ---- config-4 leg: episode-boundary all-gather of [T=400, 32768, 19] f32 trajectory blocks ------------
     gather = None
     do_gather = (args.gather == 1) or (args.gather < 0 and world > 1)
@@ -278,6 +329,8 @@ def main():
             res['allgather'] = gather
         if fused:
             res['fused_rollout'] = fused
+        if closed:
+            res['policy_rollout'] = closed
         if not args.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline(n, args.cpu_seconds)
         elif not args.no_cpu_baseline:

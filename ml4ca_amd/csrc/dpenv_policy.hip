@@ -55,53 +55,58 @@ __device__ __forceinline__ half8 act_pack(const float16v& acc, int s, _Float16 l
 
 // Evaluate one MLP for the 64 envs of this wave.  in0 / in1: first-layer B fragments of env tiles 0-31 / 32-63.
 // out[j], j < 8: output row j of the lane's OWN env.
+//
+// Register discipline: a layer's output is never held as a whole f32 tile set.  Each 32-row block (two
+// accumulator tiles, one per env tile) is activated and packed to f16 as soon as its MFMAs are issued, straight
+// into the next layer's B fragments; weight fragments are fetched from LDS one row-block ahead.  That keeps the
+// evaluation under the 256 architectural VGPRs, so the accumulators stay out of the AGPR half (every AGPR value
+// a VALU instruction needs costs a v_accvgpr_read).
 __device__ __forceinline__ void mlp_eval(const uint4* W, int n_hidden, half8 in0, half8 in1, _Float16 leak, float out[8])
 {
     const int lane = threadIdx.x & 63;
     const float16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    float16v acc[3][2];
+    half8 b[6][2], bn[6][2], w[6];
+    // first layer: one k-step, three row-blocks
+#pragma unroll
+    for (int mo = 0; mo < 3; ++mo) w[mo] = ldfrag(W, mo, lane);
 #pragma unroll
     for (int mo = 0; mo < 3; ++mo) {
-        const half8 w = ldfrag(W, mo, lane);
-        acc[mo][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, in0, zero, 0, 0, 0);
-        acc[mo][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, in1, zero, 0, 0, 0);
+        const float16v c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[mo], in0, zero, 0, 0, 0);
+        const float16v c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[mo], in1, zero, 0, 0, 0);
+        b[2 * mo][0] = act_pack(c0, 0, leak); b[2 * mo + 1][0] = act_pack(c0, 1, leak);
+        b[2 * mo][1] = act_pack(c1, 0, leak); b[2 * mo + 1][1] = act_pack(c1, 1, leak);
     }
     int fbase = 3;
-    half8 b[6][2];
     for (int l = 1; l < n_hidden; ++l) {
 #pragma unroll
-        for (int mt = 0; mt < 3; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                b[2 * mt][nt] = act_pack(acc[mt][nt], 0, leak);
-                b[2 * mt + 1][nt] = act_pack(acc[mt][nt], 1, leak);
-            }
+        for (int ks = 0; ks < 6; ++ks) w[ks] = ldfrag(W, fbase + ks, lane);
 #pragma unroll
         for (int mo = 0; mo < 3; ++mo) {
             float16v c0 = zero, c1 = zero;
 #pragma unroll
             for (int ks = 0; ks < 6; ++ks) {
-                const half8 w = ldfrag(W, fbase + mo * 6 + ks, lane);
-                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, b[ks][0], c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, b[ks][1], c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks][0], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks][1], c1, 0, 0, 0);
             }
-            acc[mo][0] = c0; acc[mo][1] = c1;
+            // the MFMAs above have read w: refill it for the next row-block while they execute
+            if (mo < 2) {
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) w[ks] = ldfrag(W, fbase + (mo + 1) * 6 + ks, lane);
+            }
+            bn[2 * mo][0] = act_pack(c0, 0, leak); bn[2 * mo + 1][0] = act_pack(c0, 1, leak);
+            bn[2 * mo][1] = act_pack(c1, 0, leak); bn[2 * mo + 1][1] = act_pack(c1, 1, leak);
         }
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) { b[ks][0] = bn[ks][0]; b[ks][1] = bn[ks][1]; }
         fbase += 18;
     }
 #pragma unroll
-    for (int mt = 0; mt < 3; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            b[2 * mt][nt] = act_pack(acc[mt][nt], 0, leak);
-            b[2 * mt + 1][nt] = act_pack(acc[mt][nt], 1, leak);
-        }
+    for (int ks = 0; ks < 6; ++ks) w[ks] = ldfrag(W, fbase + ks, lane);
     float16v c0 = zero, c1 = zero;
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks) {
-        const half8 w = ldfrag(W, fbase + ks, lane);
-        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, b[ks][0], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, b[ks][1], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks][0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks][1], c1, 0, 0, 0);
     }
     // rows 0..3 sit in registers 0..3 of lane half 0, rows 4..7 in registers 0..3 of lane half 1, for the 32 envs
     // of each tile: one permlane32 swap per register brings every env's 8 rows home to its own lane
@@ -225,8 +230,7 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
         if (a.current_drift) { vc0 = a.cur_vc0[il]; beta0 = a.cur_beta0[il]; cur.ctr = a.drift_ctr[il]; }
         current_components(cur);
     }
-    Vessel ve = vessel_from_args(a.v0);
-    pin_vessel_in_vgprs(ve);
+    const Vessel ve = vessel_from_args(a.v0);      // SGPR-resident here: the VGPRs are needed by the MLP
     uint32_t episode = a.auto_reset ? (uint32_t)a.episode[il] : 0u;
     bool ep_dirty = false, rf_dirty = (MODE == MODE_FULL);
 

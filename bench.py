@@ -72,7 +72,7 @@ def cpu_baseline(n_envs, budget_s):
         orc.step_into(st, ctr, act, obs, rew, done)      # warm-up, page-in, thread pool start
     steps = 0
     t0 = time.perf_counter()
-    while steps < 3 or (time.perf_counter() - t0 < budget_s and steps < 2000):
+    while steps < 3 or (time.perf_counter() - t0 < budget_s and steps < 100000):
         orc.step_into(st, ctr, act, obs, rew, done)
         steps += 1
     dt = time.perf_counter() - t0

@@ -41,6 +41,50 @@ class ActorCritic(object):
         self.v_W, self.v_b = net(1)
         self.log_std = torch.full((act_dim,), float(log_std_init), device=self.device)      # core.py:83
 
+    @classmethod
+    def from_tensors(cls, tensors, leak=0.2, device='cpu'):
+        """Build from a {name: array} dict with the reference's variable names (core.py:103-106 scopes 'pi' and 'v',
+        tf.layers.dense naming dense, dense_1, ...; pi/log_std) - e.g. the output of tf_checkpoint.read_bundle."""
+        torch = _torch()
+
+        def layers(scope):
+            Ws, bs, i = [], [], 0
+            while True:
+                name = '%s/dense%s' % (scope, '' if i == 0 else '_%d' % i)
+                if name + '/kernel' not in tensors:
+                    break
+                Ws.append(torch.tensor(np.asarray(tensors[name + '/kernel'], np.float32), device=device))
+                bs.append(torch.tensor(np.asarray(tensors[name + '/bias'], np.float32), device=device))
+                i += 1
+            return Ws, bs
+
+        pW, pb = layers('pi')
+        vW, vb = layers('v')
+        if not pW or not vW:
+            raise ValueError("no 'pi/dense*/kernel' / 'v/dense*/kernel' variables found")
+        hidden = tuple(int(w.shape[1]) for w in pW[:-1])
+        ac = cls(int(pW[0].shape[0]), int(pW[-1].shape[1]), hidden, leak=leak, device=device)
+        ac.pi_W, ac.pi_b, ac.v_W, ac.v_b = pW, pb, vW, vb
+        ac.log_std = torch.tensor(np.asarray(tensors['pi/log_std'], np.float32), device=device)
+        return ac
+
+    @classmethod
+    def from_tf_checkpoint(cls, prefix, leak=0.2, device='cpu'):
+        """Load a reference-trained model, e.g. '<model dir>/tf1_save/variables/variables' (logx.py:161-228)."""
+        from .tf_checkpoint import read_bundle
+        return cls.from_tensors(read_bundle(prefix), leak=leak, device=device)
+
+    def state_dict(self):
+        """{reference variable name: numpy array} (inverse of from_tensors)."""
+        out = {}
+        for scope, Ws, bs in (('pi', self.pi_W, self.pi_b), ('v', self.v_W, self.v_b)):
+            for i, (W, b) in enumerate(zip(Ws, bs)):
+                name = '%s/dense%s' % (scope, '' if i == 0 else '_%d' % i)
+                out[name + '/kernel'] = W.detach().cpu().numpy()
+                out[name + '/bias'] = b.detach().cpu().numpy()
+        out['pi/log_std'] = self.log_std.detach().cpu().numpy()
+        return out
+
     def parameters(self):
         return self.pi_W + self.pi_b + self.v_W + self.v_b + [self.log_std]
 

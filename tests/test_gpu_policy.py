@@ -190,3 +190,34 @@ def test_policy_argument_validation():
     ActorCritic(9, 7, (80, 80, 80), device=env.device).upload(env_soa)
     with pytest.raises(ml4ca_amd.DpenvError):
         policy_rollout(env_soa, 4)
+
+
+def test_trained_reference_policy_flies_the_box_test():
+    """The shipped trained actor (reference data/finalmodel/finconttothighbowder_s0, fixture final_policy.npz),
+    deterministic, in the build-owned plant: forward pass against the float64 expectations, then the thesis' 4-corner
+    box test (results/all_plots/box_test/plot_pos.py:55-59).  The policy was trained in Cybersea, so this is a soft
+    validation of the plant: it must hold station and reach every corner."""
+    import os
+    from ml4ca_amd import evaluate as EV
+    from ml4ca_amd.policy import ActorCritic, policy_forward, policy_rollout
+    torch = torch_()
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'final_policy.npz'))
+    n = 256
+    env, _ = H.make_pair('final_cont', n, terminate=False, time_limit=False)
+    ac = ActorCritic.from_tensors({k.replace('.', '/'): d[k] for k in d.files if '.' in k}, device=env.device).upload(env)
+    obs = H.to_dev(np.tile(d['obs'].astype(np.float32), (4, 1)))
+    mu, v = policy_forward(env, obs)
+    mu_ref, v_ref = np.tile(d['mu'], (4, 1)), np.tile(d['v'], 4)
+    assert np.abs(mu.cpu().numpy() - mu_ref).max() < 6e-3 * (np.abs(mu_ref).max() + 1)
+    assert np.abs(v.cpu().numpy() - v_ref).max() < 6e-3 * (np.abs(v_ref).max() + 1)
+    start = torch.zeros((3, n), device=env.device)
+    env.reset(init=torch.zeros((6, n), device=env.device), new_ref=start.clone())
+    steps, refs = EV.box_schedule(start)
+    out = policy_rollout(env, 1250, noise=None, switch_steps=steps, refs=refs)
+    e = out['obs'][:, 0, :3].cpu().numpy()
+    assert np.abs(e[:50]).max() < 0.05                       # station keeping on the start setpoint for 10 s
+    for t in list(steps[1:]) + [1249]:                        # just before each later switch the corner is reached
+        assert np.hypot(e[t - 1, 0], e[t - 1, 1]) < 0.5 and abs(np.degrees(e[t - 1, 2])) < 2.0, (t, e[t - 1])
+    iae_tot, _ = EV.iae(out['obs'])
+    assert 20.0 < float(iae_tot.mean()) < 150.0
+    assert float(out['rew'].mean()) > 2.0

@@ -1,0 +1,88 @@
+"""CPU tests of the trained-policy import path: tensor-bundle reader/writer, ActorCritic construction from the
+reference's variable names, fp32 torch forward pass against the committed float64 expectations of the shipped
+model, and the evaluation metrics."""
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIX = os.path.join(ROOT, 'tests', 'golden', 'final_policy.npz')
+REF_CKPT = '/root/reference/src/rl/windows_workspace/data/finalmodel/finconttothighbowder_s0/tf1_save/variables/variables'
+
+
+def fixture_tensors():
+    d = np.load(FIX)
+    return {k.replace('.', '/'): d[k] for k in d.files if '.' in k}, d
+
+
+def test_bundle_roundtrip(tmp_path):
+    from ml4ca_amd.tf_checkpoint import read_bundle, write_bundle
+    rng = np.random.RandomState(0)
+    t = {'pi/dense/kernel': rng.normal(size=(9, 80)).astype(np.float32), 'pi/dense/bias': rng.normal(size=80).astype(np.float32),
+         'pi/log_std': rng.normal(size=7).astype(np.float32), 'beta1_power': np.float32(0.5).reshape(()),
+         'global_step': np.array(7, np.int64), 'v/dense_3/kernel': rng.normal(size=(80, 1)).astype(np.float32)}
+    write_bundle(str(tmp_path / 'variables'), t)
+    r = read_bundle(str(tmp_path / 'variables'))
+    assert sorted(r) == sorted(t)
+    for k in t:
+        assert r[k].shape == np.asarray(t[k]).shape and np.array_equal(r[k], t[k]), k
+    with pytest.raises(ValueError):
+        (tmp_path / 'bad.index').write_bytes(b'\\x00' * 64)
+        (tmp_path / 'bad.data-00000-of-00001').write_bytes(b'')
+        read_bundle(str(tmp_path / 'bad'))
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CKPT + '.index'), reason='reference tree only exists in the build container')
+def test_reader_on_the_reference_checkpoint_matches_fixture():
+    from ml4ca_amd.tf_checkpoint import read_bundle
+    b = read_bundle(REF_CKPT)
+    assert sum(v.size for v in b.values()) == 84529          # 28 175 parameters + Adam slots
+    t, _ = fixture_tensors()
+    assert sum(v.size for v in t.values()) == 28175
+    for k, v in t.items():
+        assert np.array_equal(b[k], v), k
+
+
+def test_actor_critic_from_reference_names_and_forward():
+    import torch
+    from ml4ca_amd.policy import ActorCritic
+    t, d = fixture_tensors()
+    ac = ActorCritic.from_tensors(t)
+    assert (ac.obs_dim, ac.act_dim, ac.hidden_sizes, ac.leak) == (9, 7, (80, 80, 80), 0.2)   # config.json of the shipped run
+    mu, v = ac.forward_ref(torch.tensor(d['obs'], dtype=torch.float32))
+    assert np.allclose(mu.numpy(), d['mu'], rtol=2e-5, atol=2e-5)
+    assert np.allclose(v.numpy(), d['v'], rtol=2e-5, atol=2e-3)
+    # on the setpoint at rest the critic predicts ~ the discounted sum of the 3.5/step maximum reward
+    assert 250 < float(v[0]) < 350
+    sd = ac.state_dict()
+    assert all(np.array_equal(sd[k], t[k]) for k in t)
+    with pytest.raises(ValueError):
+        ActorCritic.from_tensors({'x': np.zeros(3)})
+
+
+def test_evaluation_metrics():
+    import torch
+    from ml4ca_amd import evaluate as EV
+    T, n = 11, 3
+    obs = torch.zeros((T, n, 9))
+    obs[:, 0, 0] = 5.0                       # constant 5 m error -> normalised error 1 -> IAE = duration
+    obs[:, 1, 2] = float(np.deg2rad(25.0))   # constant 25 deg heading error -> 1
+    tot, cum = EV.iae(obs, dt=0.2)
+    assert np.allclose(tot.numpy(), [2.0, 2.0, 0.0], atol=1e-6) and cum.shape == (T, n)
+    # the reference's own formula on the same series (common.py:56-74)
+    t = np.arange(T) * 0.2
+    e = np.sqrt(((obs[:, 0, :3].numpy() / np.array([5, 5, np.deg2rad(25)])) ** 2).sum(1))
+    assert abs(sum((e[i] + e[i + 1]) / 2 * (t[i + 1] - t[i]) for i in range(T - 1)) - 2.0) < 1e-6
+    thr = torch.zeros((T, n, 3))
+    thr[:, 0, 0] = 100.0
+    thr[:, 1, 1] = -50.0
+    w = EV.work(thr, dt=0.2)
+    p_bow = 0.02 * 2 * np.pi * 1025 * 0.06 ** 5 * 33.0 ** 3          # plot_act.py:128-135 at n = 100 %
+    # sgn(n) * (n ...)^3 is |.|^3: the reference's power is positive for reverse thrust as well
+    p_port = 0.036 * 2 * np.pi * 1025 * 0.15 ** 5 * (0.5 * 11.0) ** 3
+    assert np.allclose(w[0].numpy(), [p_bow * 2.0, 0, 0], rtol=1e-5) and np.allclose(w[1].numpy(), [0, p_port * 2.0, 0], rtol=1e-5)
+    steps, refs = EV.box_schedule(torch.zeros((3, 2)))
+    assert steps == (50, 300, 550, 700, 950) and refs.shape == (5, 3, 2)
+    assert np.allclose(refs[2, :, 0].numpy(), [5.0, -5.0, -np.pi / 4])
+    assert np.allclose(EV.commanded_thrust(torch.tensor([[[2.0, -0.5, 0.1]]])).numpy(), [[[100.0, -50.0, 10.0]]])

@@ -453,17 +453,51 @@ def gen_forcemap():
     print('wrote forcemap.npz')
 
 
+def gen_policy():
+    """The shipped trained actor-critic (data/finalmodel/finconttothighbowder_s0, logx.py:161-228 SavedModel
+    variables) read with ml4ca_amd.tf_checkpoint (no TensorFlow here), plus a float64 NumPy forward pass of
+    core.py:29-33 on a few observations as expected outputs.  Optimiser slots are dropped."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from ml4ca_amd.tf_checkpoint import read_bundle
+    prefix = os.path.join(WW, 'data/finalmodel/finconttothighbowder_s0/tf1_save/variables/variables')
+    b = read_bundle(prefix)
+    keep = {k: v for k, v in b.items() if 'Adam' not in k and not k.startswith('beta')}
+    assert sum(v.size for v in keep.values()) == 28175, sum(v.size for v in keep.values())   # SURVEY: 28 175 parameters
+    rng = np.random.RandomState(0)
+    obs = f32(rng.normal(size=(64, 9)) * np.array([3, 3, 0.3, 0.4, 0.1, 0.1, 0.5, 0.5, 0.5]))
+    obs[0] = 0.0
+
+    def mlp(x, scope):
+        i = 0
+        while True:
+            name = '%s/dense%s' % (scope, '' if i == 0 else '_%d' % i)
+            if name + '/kernel' not in keep:
+                return x
+            x = x @ keep[name + '/kernel'].astype(np.float64) + keep[name + '/bias'].astype(np.float64)
+            if ('%s/dense_%d/kernel' % (scope, i + 1)) in keep:
+                x = np.where(x > 0, x, 0.2 * x)          # tf.nn.leaky_relu, alpha = 0.2 (config.json: leaky_relu)
+            i += 1
+
+    out = {k.replace('/', '.'): v for k, v in keep.items()}
+    out['obs'] = obs
+    out['mu'] = mlp(obs, 'pi')
+    out['v'] = mlp(obs, 'v')[:, 0]
+    np.savez_compressed(os.path.join(OUT, 'final_policy.npz'), **out)
+    print('wrote final_policy.npz (%d parameters)' % sum(v.size for v in keep.values()))
+
+
 def main():
     if len(sys.argv) > 1:
         what = sys.argv[1]
         if what in MODES:
             gen_mode(what)
         else:
-            {'errorframe': gen_errorframe, 'gae': gen_gae, 'forcemap': gen_forcemap}[what]()
+            {'errorframe': gen_errorframe, 'gae': gen_gae, 'forcemap': gen_forcemap, 'policy': gen_policy}[what]()
         return
     assert os.path.isdir(REF), 'reference tree not present: fixtures can only be regenerated in the build container'
     os.makedirs(OUT, exist_ok=True)
-    for what in list(MODES) + ['errorframe', 'gae', 'forcemap']:
+    for what in list(MODES) + ['errorframe', 'gae', 'forcemap', 'policy']:
         subprocess.check_call([sys.executable, '-B', os.path.abspath(__file__), what])
     # the reference tree must stay pristine
     for root, dirs, files in os.walk(REF):

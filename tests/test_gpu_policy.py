@@ -221,3 +221,31 @@ def test_trained_reference_policy_flies_the_box_test():
     iae_tot, _ = EV.iae(out['obs'])
     assert 20.0 < float(iae_tot.mean()) < 150.0
     assert float(out['rew'].mean()) > 2.0
+
+
+def test_plant_tracks_the_recorded_cybersea_box_run():
+    """Soft validation of the BUILD-OWNED plant (no parity claim): the trained actor, fed the recorded filtered
+    setpoint series of the thesis' Cybersea box test (fixture cybersea_box_rl.npz from results/all_plots/box_test/
+    bagfile__RL_*), must keep this plant's pose close to the recorded Cybersea pose.  Measured when written:
+    RMS 0.17 m N, 0.23 m E, 3.6 deg yaw over 251 s."""
+    import os
+    from ml4ca_amd.policy import ActorCritic, policy_forward
+    torch = torch_()
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    rec = np.load(os.path.join(g, 'cybersea_box_rl.npz'))
+    d = np.load(os.path.join(g, 'final_policy.npz'))
+    refs = np.ascontiguousarray(rec['setpoint'].T.astype(np.float32))
+    T = refs.shape[1] - 1
+    env, _ = H.make_pair('final_cont', 1, terminate=False, time_limit=False, wrap_mode='radians')   # ROS node wraps in rad
+    ActorCritic.from_tensors({k.replace('.', '/'): d[k] for k in d.files if '.' in k}, device=env.device).upload(env)
+    obs = env.reset(init=torch.zeros((6, 1), device=env.device), new_ref=H.to_dev(refs[:, :1]))
+    traj = np.zeros((T, 3))
+    for k in range(T):
+        mu, _ = policy_forward(env, obs)
+        obs, _, _, _ = env.step(mu.contiguous(), new_ref=H.to_dev(refs[:, k + 1:k + 2]))
+        st, _ = env.get_state()
+        traj[k] = st[0:3, 0].cpu().numpy()
+    dev = traj - rec['pose'][1:]
+    rms = np.sqrt((dev ** 2).mean(0))
+    assert rms[0] < 0.5 and rms[1] < 0.5 and np.degrees(rms[2]) < 8.0, rms
+    assert np.abs(dev[:, :2]).max() < 1.5

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Soft validation of the build-owned plant against the ONLY plant outputs the reference ships: the recorded Cybersea
+box test of the RL allocator (results/all_plots/box_test/bagfile__RL_*.csv).  The trained actor (fixture
+final_policy.npz) is driven with the RECORDED filtered setpoint series (reference_filter/state_desired, the signal the
+ROS node fed the policy, rl_allocator.py:160) and the resulting pose is compared with the recorded pose.
+Input: tests/golden/cybersea_box_rl.npz (tools/gen_golden.py cybersea).  Prints per-axis RMS and max deviations."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ml4ca_amd
+from ml4ca_amd.policy import ActorCritic, policy_forward
+
+rec = np.load(os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden', 'cybersea_box_rl.npz'))
+dt = 0.2
+tt = rec['t']
+T = len(tt) - 1
+refs = np.ascontiguousarray(rec['setpoint'].T.astype(np.float32))        # [3, T+1]
+cy_full = rec['pose']
+
+d = np.load(os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden', 'final_policy.npz'))
+env = ml4ca_amd.BatchedRevoltEnv(1, terminate=False, time_limit=False, wrap_mode='radians')   # the ROS node wraps in radians
+ac = ActorCritic.from_tensors({k.replace('.', '/'): d[k] for k in d.files if '.' in k}, device='cuda:0').upload(env)
+obs = env.reset(init=torch.zeros((6, 1), device=env.device), new_ref=torch.tensor(refs[:, :1], device=env.device).contiguous())
+traj = np.zeros((T, 3))
+for k in range(T):
+    mu, _ = policy_forward(env, obs)
+    nr = torch.tensor(refs[:, k + 1:k + 2], device=env.device).contiguous()
+    obs, r, dn, _ = env.step(mu.contiguous(), new_ref=nr)
+    st, _ = env.get_state()
+    traj[k] = st[0:3, 0].cpu().numpy()
+cy = cy_full[1:]
+dev = traj - cy
+print('duration %.0f s, %d steps' % (tt[-1], T))
+print('RMS deviation from the Cybersea record: N %.2f m  E %.2f m  yaw %.1f deg' % (np.sqrt((dev[:, 0] ** 2).mean()), np.sqrt((dev[:, 1] ** 2).mean()), np.degrees(np.sqrt((dev[:, 2] ** 2).mean()))))
+print('max deviation: N %.2f m  E %.2f m  yaw %.1f deg' % (np.abs(dev[:, 0]).max(), np.abs(dev[:, 1]).max(), np.degrees(np.abs(dev[:, 2]).max())))
+for s in (15, 20, 25, 30, 40, 70, 90, 120, 139, 160, 189, 220, 249):
+    k = int(s / dt) - 1
+    if k < T:
+        print('t=%3d  this plant N %.2f E %.2f yaw %.1f | Cybersea N %.2f E %.2f yaw %.1f | ref N %.2f E %.2f yaw %.1f' % (
+            s, traj[k, 0], traj[k, 1], np.degrees(traj[k, 2]), cy[k, 0], cy[k, 1], np.degrees(cy[k, 2]),
+            refs[0, k + 1], refs[1, k + 1], np.degrees(refs[2, k + 1])))

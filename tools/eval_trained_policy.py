@@ -35,3 +35,13 @@ for t in list(steps) + [T - 1]:
     print('t=%6.1fs body-frame error before switch: x %.2f m  y %.2f m  yaw %.1f deg' % (k * 0.2, e[k, 0], e[k, 1], np.degrees(e[k, 2])))
 print('reward mean %.3f (max 3.5)' % float(out['rew'].mean()))
 print('thrust cmd range', float(act[..., :3].min()), float(act[..., :3].max()))
+print('--- first leg (+5 m North at t = 10 s): N(t) in this plant vs Cybersea record (box_test/bagfile__RL_observer_eta_ned.csv)')
+cyb = {15: 0.17, 20: 1.91, 25: 3.93, 30: 4.79, 40: 5.02, 50: 5.00}
+for tt in (15, 20, 25, 30, 40, 50):
+    k = int(tt / 0.2)
+    print('t=%3d s  N = %.2f m   (Cybersea %.2f)   u = %.2f m/s' % (tt, 5.0 + e[k, 0], cyb[tt], float(obs[k, 0, 3])))
+print('--- second leg (-5 m East at t = 60 s): E(t)')
+cyb2 = {70: -0.58, 90: -4.68, 109: -5.08}
+for tt in (70, 90, 109):
+    k = int(tt / 0.2)
+    print('t=%3d s  E = %.2f m   (Cybersea %.2f)' % (tt, -5.0 + e[k, 1], cyb2[tt]))

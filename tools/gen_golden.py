@@ -487,17 +487,38 @@ def gen_policy():
     print('wrote final_policy.npz (%d parameters)' % sum(v.size for v in keep.values()))
 
 
+def gen_cybersea_box():
+    """Recorded Cybersea run of the RL allocator on the 4-corner box test (results/all_plots/box_test/bagfile__RL_*,
+    ROS-bag exports): pose and the filtered setpoint the policy was fed, resampled to the env's
+    5 Hz and made relative to the start pose.  The only plant OUTPUT data in the reference tree; used as a soft
+    validation target for the build-owned plant (no parity claim)."""
+    d = os.path.join(REF, 'results/all_plots/box_test')
+    eta = np.genfromtxt(os.path.join(d, 'bagfile__RL_observer_eta_ned.csv'), delimiter=',', skip_header=1)
+    ref = np.genfromtxt(os.path.join(d, 'bagfile__RL_reference_filter_state_desired.csv'), delimiter=',', skip_header=1)
+    t_eta, t_ref = eta[:, 7], ref[:, -1]
+    n0, e0, p0 = eta[0, 1], eta[0, 2], eta[0, 6]
+    T = int(t_eta[-1] / 0.2)
+    tt = np.arange(T) * 0.2
+    pose = np.stack([np.interp(tt, t_eta, eta[:, 1] - n0), np.interp(tt, t_eta, eta[:, 2] - e0),
+                     np.radians(np.interp(tt, t_eta, eta[:, 6] - p0))], 1)
+    setp = np.stack([np.interp(tt, t_ref, ref[:, 1] - n0), np.interp(tt, t_ref, ref[:, 2] - e0),
+                     np.radians(np.interp(tt, t_ref, ref[:, 3] - p0))], 1)
+    np.savez_compressed(os.path.join(OUT, 'cybersea_box_rl.npz'), t=tt, pose=pose.astype(np.float32),
+                        setpoint=setp.astype(np.float32))
+    print('wrote cybersea_box_rl.npz (%d samples at 5 Hz)' % T)
+
+
 def main():
     if len(sys.argv) > 1:
         what = sys.argv[1]
         if what in MODES:
             gen_mode(what)
         else:
-            {'errorframe': gen_errorframe, 'gae': gen_gae, 'forcemap': gen_forcemap, 'policy': gen_policy}[what]()
+            {'errorframe': gen_errorframe, 'gae': gen_gae, 'forcemap': gen_forcemap, 'policy': gen_policy, 'cybersea': gen_cybersea_box}[what]()
         return
     assert os.path.isdir(REF), 'reference tree not present: fixtures can only be regenerated in the build container'
     os.makedirs(OUT, exist_ok=True)
-    for what in list(MODES) + ['errorframe', 'gae', 'forcemap', 'policy']:
+    for what in list(MODES) + ['errorframe', 'gae', 'forcemap', 'policy', 'cybersea']:
         subprocess.check_call([sys.executable, '-B', os.path.abspath(__file__), what])
     # the reference tree must stay pristine
     for root, dirs, files in os.walk(REF):

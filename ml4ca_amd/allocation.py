@@ -42,3 +42,90 @@ def pinv_allocate(tau, alpha, K=K_SIM, saturate=False):
     if saturate:
         F = np.clip(F, -F_MAX, F_MAX)
     return force_to_percent(F, K), F
+
+
+class QPAllocator(object):
+    """CPU restatement of the reference's nonlinear "QP" thrust allocator (SLSQP), the baseline the thesis compares the
+    RL allocator with: QPTA.solve_QP and the command conversion of tau_controller_callback_func
+    (src/qp/ROS/qp_allocator/src/qp_allocator.py:108-234, 264-320).  ROS order: port, starboard, bow.
+
+    Decision vector x = [F_port, F_star, F_bow, a_port, a_star, s1, s2, s3]; minimise 0.5 z'Qz with
+    z = [s, |F|^1.5, |a - a_prev| (weight 0.25), |F - F_prev| (weight 0.25)] subject to B(a) F - tau - s = 0, force-rate and
+    azimuth-rate limits per 0.2 s step, force bounds, |a| <= 2 pi, |s| <= s_bnd.  The bow azimuth is fixed at pi/2.
+    A failed solve keeps the previous thruster state (:267-269).  ``retry`` reproduces the node's loop that widens the
+    slack bound by 1 N until SLSQP succeeds (:209-226; it only runs when wall-clock time has elapsed, and with SciPy
+    versions whose ``success`` is a Python bool)."""
+
+    def __init__(self, simulation=False, retry=False, dt=0.20):
+        self.dt = dt
+        self.simulation = simulation
+        self.retry = retry
+        self.max_force_rate = [10.0 / 2.0, 10.0 / 2.0, 4.0 / 2.0]                           # :57
+        self.max_rotational_rate = [np.pi / 6.0 / 2.0, np.pi / 6.0 / 2.0, np.pi / 32.0 / 2.0]  # :58
+        self.bow_angle_fixed = np.pi / 2                                                    # :65
+        self.previous_thruster_state = [0, 0, 0, 0, 0, self.bow_angle_fixed]                # :66  [N, N, N, rad, rad, rad]
+
+    def solve(self, tau_d, s_bnd=1.0, x0=None):
+        from scipy.optimize import minimize
+        tau = np.asarray(tau_d, dtype=np.float64).reshape(3)
+        s_t = self.previous_thruster_state
+        lx, ly = LX, LY
+
+        def objective(x):                                                                   # :116-150
+            obj = x[5:]
+            obj = np.hstack((obj, np.abs(x[0:3]) ** 1.5))
+            obj = np.hstack((obj, np.abs(x[3] - s_t[3])))
+            obj = np.hstack((obj, np.abs(x[4] - s_t[4])))
+            obj = np.hstack((obj, np.abs(x[0:3] - np.array(s_t[0:3]))))
+            Q = np.zeros((len(obj), len(obj)))
+            np.fill_diagonal(Q, 1.0)
+            Q[6, 6] = Q[7, 7] = 0.25
+            for i in range(8, 11):
+                Q[i, i] = 0.25
+            return 0.5 * (obj.T).dot(Q).dot(obj)
+
+        hp = np.pi / 2
+        cons = [                                                                            # :156-192
+            {'type': 'eq', 'fun': lambda x: np.cos(x[3]) * x[0] + np.cos(x[4]) * x[1] + np.cos(hp) * x[2] - x[5] - float(tau[0])},
+            {'type': 'eq', 'fun': lambda x: np.sin(x[3]) * x[0] + np.sin(x[4]) * x[1] + np.sin(hp) * x[2] - x[6] - float(tau[1])},
+            {'type': 'eq', 'fun': lambda x: (lx[0] * np.sin(x[3]) - ly[0] * np.cos(x[3])) * x[0] +
+                (lx[1] * np.sin(x[4]) - ly[1] * np.cos(x[4])) * x[1] + (lx[2] * np.sin(hp) - ly[2] * np.cos(hp)) * x[2] - x[7] - float(tau[2])},
+        ]
+        for i in range(3):
+            cons.append({'type': 'ineq', 'fun': lambda x, i=i: self.max_force_rate[i] - (x[i] - s_t[i])})
+            cons.append({'type': 'ineq', 'fun': lambda x, i=i: self.max_force_rate[i] + (x[i] - s_t[i])})
+        for i in range(2):
+            cons.append({'type': 'ineq', 'fun': lambda x, i=i: self.max_rotational_rate[i] + (x[3 + i] - s_t[3 + i])})
+            cons.append({'type': 'ineq', 'fun': lambda x, i=i: self.max_rotational_rate[i] - (x[3 + i] - s_t[3 + i])})
+
+        def bounds(sb):                                                                     # :198-200
+            return ((-F_MAX[0], F_MAX[0]), (-F_MAX[1], F_MAX[1]), (-F_MAX[2], F_MAX[2]), (-2 * np.pi, 2 * np.pi),
+                    (-2 * np.pi, 2 * np.pi), (-sb, sb), (-sb, sb), (-sb, sb))
+
+        if x0 is None:
+            x0 = np.array([s_t[0], s_t[1], s_t[2], s_t[3], s_t[4], 0.0, 0.0, 0.0])          # :203
+        sol = minimize(objective, x0, method='SLSQP', bounds=bounds(s_bnd), constraints=cons)   # :206
+        tries = 0
+        while self.retry and not bool(sol.success) and tries < 100:                         # :209-226
+            s_bnd += 1.0
+            s1, s2, s3 = sol.x[-3:]
+            x0 = np.array([s_t[0], s_t[1], s_t[2], s_t[3], s_t[4], s1, s2, s3])
+            sol = minimize(objective, x0, method='SLSQP', bounds=bounds(s_bnd), constraints=cons)
+            tries += 1
+        x = sol.x
+        x[np.where(np.abs(x) < 0.01)] = 0.0                                                 # :232
+        return x, bool(sol.success)
+
+    def allocate(self, tau_d):
+        """One 5 Hz allocation step (:264-320): returns (n_pct [port, star, bow-as-published], angles_deg [port, star])
+        and updates the carried thruster state."""
+        x, ok = self.solve(tau_d)
+        sol = x if ok else self.previous_thruster_state                                     # :267-269
+        F = np.array([sol[0], sol[1], sol[2]], dtype=np.float64)
+        alpha = np.array([sol[3], sol[4], self.bow_angle_fixed], dtype=np.float64)
+        alpha = np.mod(alpha + np.pi, 2 * np.pi) - np.pi                                    # mapToPi :101-106,277
+        n = force_to_percent(F, K_SIM)                                                      # :287-288
+        bow = float(n[2]) if self.simulation else float(np.clip(n[2] * 2.5, -100.0, 100.0))  # :303-308
+        self.previous_thruster_state = [float(F[0]), float(F[1]), float(F[2]), float(alpha[0]), float(alpha[1]),
+                                        float(alpha[2])]                                    # :316-318
+        return np.array([n[0], n[1], bow]), np.degrees(alpha[:2]), ok

@@ -176,3 +176,34 @@ def test_current_drift_is_a_stationary_gauss_markov_process():
     orc.reset(st2, ctr2, init=np.zeros((6, n), np.float32))
     orc.step(st2, ctr2, act, current=cur2, current_mean=mean, drift_ctr=dctr2)
     assert np.array_equal(cur2, hist[0])
+
+
+def test_qp_allocator_restatement_matches_reference_fixture():
+    """qp_allocator.py:108-320 (imported behind ROS stubs by tools/gen_golden.py qp): 30 wrenches through the SLSQP
+    allocator - raw solution, success flag, published efforts / azimuths, carried state - incl. one infeasible jump
+    after which the node keeps its previous state."""
+    from ml4ca_amd.allocation import QPAllocator
+    d = np.load(os.path.join(G, 'qp_allocator.npz'))
+    qa = QPAllocator(simulation=bool(d['simulation_flag'][0]), retry=False)
+    assert np.allclose(qa.max_force_rate, d['max_force_rate']) and np.allclose(qa.max_rotational_rate, d['max_rotational_rate'])
+    n_fail = 0
+    for k, tau in enumerate(d['tau']):
+        x, ok = qa.solve(tau)
+        assert ok == bool(d['success'][k]), k
+        if ok:
+            assert np.allclose(x, d['solution'][k], rtol=0, atol=2e-4), (k, x, d['solution'][k])
+        n, ang, ok2 = qa.allocate(tau)
+        assert np.allclose(n, d['published_effort'][k], rtol=0, atol=2e-2), (k, n, d['published_effort'][k])
+        assert np.allclose(ang, d['published_angle_deg'][k], rtol=0, atol=2e-2)
+        assert np.allclose(qa.previous_thruster_state, d['previous_state'][k], rtol=0, atol=2e-4)
+        n_fail += (not ok)
+    assert n_fail == 1
+    # a successful allocation reproduces the wrench within its +-1 N slack (equality constraints :156-158)
+    from ml4ca_amd import allocation as AL
+    F = np.array(qa.previous_thruster_state[:3])
+    a = np.array(qa.previous_thruster_state[3:])
+    assert np.all(np.abs(AL.effectiveness(a) @ F - d['tau'][-1]) <= 1.0 + 1e-6)
+    # with the retry loop the infeasible jump is followed as far as the rate limits allow
+    qr = QPAllocator(retry=True)
+    x, ok = qr.solve([60.0, -30.0, 40.0])
+    assert ok and abs(x[0] - 5.0) < 1e-3 and np.abs(x[5:]).max() > 1.0

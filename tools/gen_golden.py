@@ -508,17 +508,105 @@ def gen_cybersea_box():
     print('wrote cybersea_box_rl.npz (%d samples at 5 Hz)' % T)
 
 
+def gen_qp():
+    """src/qp/ROS/qp_allocator/src/qp_allocator.py (QPTA.solve_QP :108-234, tau_controller_callback_func :247-320)
+    behind stubs for rospy / custom_msgs / geometry_msgs: a sequence of desired wrenches through the SLSQP allocator,
+    recording the raw solution, the published thruster commands and the carried previous state.  scipy here is
+    1.15 (the reference pinned 1.2.0): the fixture pins the FORMULATION, evaluated with this container's SLSQP."""
+    class _Any(object):
+        def __init__(self, *a, **k):
+            pass
+
+        def __getattr__(self, k):
+            return _Any()
+
+        def __call__(self, *a, **k):
+            return _Any()
+
+    published = []
+
+    class Pub(object):
+        def __init__(self, topic, *a, **k):
+            self.topic = topic
+
+        def publish(self, msg):
+            published.append((self.topic, dict(msg.__dict__)))
+
+    class Msg(object):
+        pass
+
+    rospy = types.ModuleType('rospy')
+    rospy.init_node = lambda *a, **k: None
+    rospy.Rate = _Any
+    rospy.Publisher = Pub
+    rospy.Subscriber = _Any
+    clock = [0.0]
+
+    def get_time():
+        # a clock that always advances by 1 s: the node's retry loop (qp_allocator.py:209) then runs until SLSQP succeeds,
+        # as it does on the vessel where real time has passed since the last callback
+        clock[0] += 1.0
+        return clock[0]
+
+    rospy.get_time = get_time
+    rospy.loginfo = lambda *a, **k: None
+    rospy.logwarn = lambda *a, **k: None
+    sys.modules['rospy'] = rospy
+    cm = types.ModuleType('custom_msgs')
+    cmm = types.ModuleType('custom_msgs.msg')
+    for n in ('podAngle', 'SternThrusterSetpoints', 'bowControl', 'diffThrottleStern'):
+        setattr(cmm, n, type(n, (Msg,), {}))
+    cm.msg = cmm
+    gm = types.ModuleType('geometry_msgs')
+    gmm = types.ModuleType('geometry_msgs.msg')
+    gmm.Wrench = type('Wrench', (Msg,), {})
+    gm.msg = gmm
+    sys.modules.update({'custom_msgs': cm, 'custom_msgs.msg': cmm, 'geometry_msgs': gm, 'geometry_msgs.msg': gmm})
+    sys.path.insert(0, os.path.join(REF, 'src/qp/ROS/qp_allocator/src'))
+    import qp_allocator as QA
+    qa = QA.QPTA()
+    rng = np.random.RandomState(11)
+    # wrench series a DP controller would produce: smooth, so that the allocator's rate limits (5 N, 5 N, 2 N and
+    # pi/12 rad per 0.2 s, qp_allocator.py:57-58) and its +-1 N slack can follow; plus two jumps it cannot follow
+    # (SLSQP fails -> the node keeps the previous thruster state, qp_allocator.py:267-269)
+    k = np.arange(30)[:, None]
+    ramp = np.minimum(k, 12) * np.array([[1.2, 0.6, 0.4]]) - np.maximum(k - 16, 0) * np.array([[1.5, -0.5, 0.8]])
+    taus = f32(ramp + rng.uniform(-0.3, 0.3, size=ramp.shape))
+    taus[14] = [60.0, -30.0, 40.0]
+    taus[15] = taus[13]
+    sols, succ, prev, n_pub, a_pub = [], [], [], [], []
+    for tau in taus:
+        w = gmm.Wrench()
+        w.force, w.torque = Msg(), Msg()
+        w.force.x, w.force.y, w.torque.z = float(tau[0]), float(tau[1]), float(tau[2])
+        x, ok = qa.solve_QP(np.array([[tau[0], tau[1], tau[2]]]).T)
+        sols.append(np.array(x, dtype=np.float64))
+        succ.append(bool(ok))
+        del published[:]
+        qa.tau_controller_callback_func(w)
+        msgs = dict(published)
+        n_pub.append([msgs['thrusterAllocation/stern_thruster_setpoints']['port_effort'],
+                      msgs['thrusterAllocation/stern_thruster_setpoints']['star_effort'], msgs['bow_control']['throttle_bow']])
+        a_pub.append([msgs['thrusterAllocation/pod_angle_input']['port'], msgs['thrusterAllocation/pod_angle_input']['star']])
+        prev.append(list(qa.previous_thruster_state))
+    np.savez_compressed(os.path.join(OUT, 'qp_allocator.npz'), tau=taus, solution=np.array(sols), success=np.array(succ),
+                        previous_state=np.array(prev), published_effort=np.array(n_pub), published_angle_deg=np.array(a_pub),
+                        simulation_flag=np.array([int(QA.SIMULATION)]), skewed_bow=np.array([int(QA.SKEWED_BOW_THRUSTER)]),
+                        max_force_rate=np.array(qa.max_force_rate), max_rotational_rate=np.array(qa.max_rotational_rate))
+    print('wrote qp_allocator.npz (%d wrenches, %d successes)' % (len(taus), sum(succ)))
+
+
 def main():
     if len(sys.argv) > 1:
         what = sys.argv[1]
         if what in MODES:
             gen_mode(what)
         else:
-            {'errorframe': gen_errorframe, 'gae': gen_gae, 'forcemap': gen_forcemap, 'policy': gen_policy, 'cybersea': gen_cybersea_box}[what]()
+            {'errorframe': gen_errorframe, 'gae': gen_gae, 'forcemap': gen_forcemap, 'policy': gen_policy, 'cybersea': gen_cybersea_box, 'qp': gen_qp}[what]()
         return
     assert os.path.isdir(REF), 'reference tree not present: fixtures can only be regenerated in the build container'
     os.makedirs(OUT, exist_ok=True)
-    for what in list(MODES) + ['errorframe', 'gae', 'forcemap', 'policy', 'cybersea']:
+    for what in list(MODES) + ['errorframe', 'gae', 'forcemap', 'policy', 'cybersea', 'qp']:
         subprocess.check_call([sys.executable, '-B', os.path.abspath(__file__), what])
     # the reference tree must stay pristine
     for root, dirs, files in os.walk(REF):

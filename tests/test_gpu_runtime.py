@@ -1,0 +1,134 @@
+"""GPU tests of the runtime contract of the C ABI: stream ordering, HIP-graph capture, independent handles,
+large batches, lifetime, argument checking."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import helpers as H
+from tests import tolerances as TOL
+
+pytestmark = pytest.mark.gpu
+
+
+def torch_():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def test_steps_are_stream_ordered_and_graph_capturable():
+    """reset/step/rollout do no allocation and no host sync (include/dpenv.h): they run on a side stream and can be
+    captured into a HIP graph whose replay reproduces eager execution bit for bit."""
+    torch = torch_()
+    n, K = 4096 + 9, 12
+    rng = np.random.RandomState(2)
+    e1, _ = H.make_pair('final_cont', n, auto_reset=True, max_ep_len=16, seed=3)
+    e2, _ = H.make_pair('final_cont', n, auto_reset=True, max_ep_len=16, seed=3)
+    acts = H.to_dev(rng.normal(0, 0.8, size=(K, n, 7)).astype(np.float32))
+    st = H.to_dev(H.random_state(rng, n, spread=0.4))
+    ctr = H.to_dev(np.zeros((2, n), np.int32))
+    e1.set_state(st, ctr)
+    e2.set_state(st, ctr)
+    eager = []
+    for k in range(K):
+        o, r, d, _ = e1.step(acts[k])
+        eager.append((o.clone(), r.clone(), d.clone()))
+    s1, c1 = e1.get_state()
+    # capture the same K steps on a side stream, writing into per-step output rows
+    obs = torch.empty((K, n, 9), device=e2.device)
+    rew = torch.empty((K, n), device=e2.device)
+    done = torch.empty((K, n), dtype=torch.uint8, device=e2.device)
+    side = torch.cuda.Stream(device=e2.device)
+    side.wait_stream(torch.cuda.current_stream(e2.device))
+    with torch.cuda.stream(side):
+        e2.step(acts[0], out=(obs[0], rew[0], done[0]))        # warm up the launch path outside capture
+    torch.cuda.current_stream(e2.device).wait_stream(side)
+    torch.cuda.synchronize()
+    e2.set_state(st, ctr)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for k in range(K):
+            e2.step(acts[k], out=(obs[k], rew[k], done[k]))
+    e2.set_state(st, ctr)                                      # capture executed nothing: state still the start state
+    g.replay()
+    torch.cuda.synchronize()
+    for k in range(K):
+        assert torch.equal(obs[k], eager[k][0]) and torch.equal(rew[k], eager[k][1]) and torch.equal(done[k], eager[k][2]), k
+    s2, c2 = e2.get_state()
+    assert torch.equal(s1, s2) and torch.equal(c1, c2)
+    # replaying again continues from the new state (the graph holds pointers, not values)
+    g.replay()
+    torch.cuda.synchronize()
+    s3, _ = e2.get_state()
+    assert not torch.equal(s3, s2)
+
+
+def test_handles_are_independent_and_survive_recreation():
+    torch = torch_()
+    n = 1000
+    rng = np.random.RandomState(5)
+    act = H.to_dev(H.random_actions(rng, n, 7))
+    outs = []
+    for rep in range(6):                                        # create / use / destroy repeatedly
+        ea, _ = H.make_pair('final_cont', n, seed=1)
+        eb, _ = H.make_pair('limited', n, seed=2)               # a second live handle of a different variant
+        ea.reset()
+        eb.reset()
+        o, r, d, _ = ea.step(act)
+        eb.step(H.to_dev(H.random_actions(rng, n, 5)))
+        outs.append((o.clone(), r.clone()))
+        ea.close()
+        eb.close()
+        ea.close()                                              # closing twice is harmless
+    for o, r in outs[1:]:
+        assert torch.equal(o, outs[0][0]) and torch.equal(r, outs[0][1])
+
+
+def test_one_million_envs():
+    """16x the benchmark batch in one launch: against the OpenMP oracle on every env."""
+    torch = torch_()
+    n = 1 << 20
+    rng = np.random.RandomState(8)
+    env, orc = H.make_pair('final_cont', n)
+    O.set_threads(16)
+    st = H.random_state(rng, n, spread=0.7)
+    ctr = np.zeros((2, n), np.int32)
+    act = H.random_actions(rng, n, 7)
+    env.set_state(H.to_dev(st), H.to_dev(ctr))
+    obs, rew, done, _ = env.step(H.to_dev(act))
+    ost, octr = st.copy(), ctr.copy()
+    oobs = np.zeros((n, 9), np.float32)
+    orew = np.zeros(n, np.float32)
+    odone = np.zeros(n, np.uint8)
+    orc.step_into(ost, octr, act, oobs, orew, odone)
+    TOL.assert_close(obs.cpu().numpy(), oobs, TOL.OBS_FLOOR, what='obs at 2^20 envs')
+    TOL.assert_close(rew.cpu().numpy(), orew, TOL.REWARD_FLOOR, what='reward at 2^20 envs')
+    assert (done.cpu().numpy() != odone).mean() < 1e-4
+    st2, _ = env.get_state()
+    TOL.assert_close(st2.cpu().numpy()[0:3].T, ost[0:3].T, TOL.ETA_FLOOR, what='eta at 2^20 envs')
+
+
+def test_argument_checking_is_loud():
+    import ml4ca_amd
+    torch = torch_()
+    env, _ = H.make_pair('final_cont', 64)
+    good = torch.zeros((64, 7), device=env.device)
+    with pytest.raises(ValueError):
+        env.step(torch.zeros((64, 6), device=env.device))                       # wrong act_dim
+    with pytest.raises(ValueError):
+        env.step(good.cpu())                                                    # host tensor
+    with pytest.raises(ValueError):
+        env.step(good.double())                                                 # wrong dtype
+    with pytest.raises(ValueError):
+        env.step(torch.zeros((7, 64), device=env.device).t())                   # not contiguous
+    with pytest.raises(ValueError):
+        env.step(good, new_ref=torch.zeros((64, 3), device=env.device))         # new_ref is [3, n]
+    with pytest.raises(ValueError):
+        env.reset(init=torch.zeros((64, 6), device=env.device))
+    with pytest.raises(ml4ca_amd.DpenvError):
+        env.set_current(torch.zeros(64, device=env.device), torch.zeros(64, device=env.device))   # current not enabled
+    with pytest.raises(ml4ca_amd.DpenvError):
+        ml4ca_amd.BatchedRevoltEnv(64, variant='simple', extended_state=True)   # IndexError in the reference too
+    with pytest.raises(ml4ca_amd.DpenvError):
+        ml4ca_amd.BatchedRevoltEnv(64, vessel_params=np.zeros(32, np.float32))  # singular mass matrix
+    env.step(good)                                                              # and the handle still works

@@ -80,48 +80,44 @@ def normalize_advantages(adv, group=None):
 
 
 class RolloutBuffer(object):
-    """[T, n_envs] trajectory block in HBM: obs 9 + act 7 + rew + val + logp = 19 floats per env-step
-    (ppo.py:40-46) plus done bits, advantages and returns."""
+    """The reference's TrajectoryBuffer (ppo.py:21-105) for N envs at once: a [T, n_envs] block in HBM holding
+    obs 9 + act 7 + rew + val + logp = 19 floats per env-step (ppo.py:40-46) plus done bits, bootstrap values,
+    advantages and returns.  ``collect`` fills it with ONE launch (dpenv_policy_rollout: the loop ppo.py:289-322),
+    ``finish`` is finish_path for every path of every env, ``get`` is TrajectoryBuffer.get."""
 
-    def __init__(self, T, n_envs, obs_dim, act_dim, device, gamma=0.99, lam=0.97, obs_dtype=None):
+    def __init__(self, T, env, gamma=0.99, lam=0.97):
         torch = _torch()
-        self.T, self.n = int(T), int(n_envs)
-        self.gamma, self.lam = gamma, lam
+        n, od, ad, dev = env.n_envs, env.num_states, env.num_actions, env.device
+        self.T, self.n, self.gamma, self.lam = int(T), n, gamma, lam
         f32 = torch.float32
-        self.obs = torch.zeros((T, n_envs, obs_dim), dtype=obs_dtype or f32, device=device)
-        self.act = torch.zeros((T, n_envs, act_dim), dtype=f32, device=device)
-        self.rew = torch.zeros((T, n_envs), dtype=f32, device=device)
-        self.val = torch.zeros((T, n_envs), dtype=f32, device=device)
-        self.logp = torch.zeros((T, n_envs), dtype=f32, device=device)
-        self.done = torch.zeros((T, n_envs), dtype=torch.uint8, device=device)
-        self.boot = torch.zeros((T, n_envs), dtype=f32, device=device)
-        self.adv = torch.zeros((T, n_envs), dtype=f32, device=device)
-        self.ret = torch.zeros((T, n_envs), dtype=f32, device=device)
-        self.ptr = 0
+        self.blocks = dict(obs=torch.zeros((T, n, od), dtype=f32, device=dev), act=torch.zeros((T, n, ad), dtype=f32, device=dev),
+                           rew=torch.zeros((T, n), dtype=f32, device=dev), val=torch.zeros((T, n), dtype=f32, device=dev),
+                           logp=torch.zeros((T, n), dtype=f32, device=dev), boot=torch.zeros((T, n), dtype=f32, device=dev),
+                           done=torch.zeros((T, n), dtype=torch.uint8, device=dev),
+                           last_obs=torch.zeros((n, od), dtype=f32, device=dev), last_val=torch.zeros(n, dtype=f32, device=dev))
+        self.adv = torch.zeros((T, n), dtype=f32, device=dev)
+        self.ret = torch.zeros((T, n), dtype=f32, device=dev)
 
-    def step_outputs(self, t):
-        """(next_obs_row, reward_row, done_row) views for BatchedRevoltEnv.step(out=...): the observation that
-        step t produces is the policy input of step t+1, so it lands in obs[t+1] (the caller puts the reset
-        observation in obs[0] and keeps the last one for the bootstrap value)."""
-        return self.rew[t], self.done[t]
+    def collect(self, env, noise=None, switch_steps=(), refs=None):
+        """Run T policy-in-the-loop steps from the env's current state into the block (the env must have a policy
+        uploaded, policy.ActorCritic.upload)."""
+        from .policy import policy_rollout
+        return policy_rollout(env, self.T, noise=noise, switch_steps=switch_steps, refs=refs, out=self.blocks)
 
-    def finish(self, last_val=None):
-        """GAE over the whole block (finish_path for every path of every env)."""
-        return gae(self.rew, self.val, end=self.done, boot=self.boot, last_val=None if last_val is None else last_val,
-                   gamma=self.gamma, lam=self.lam, out=(self.adv, self.ret)) if last_val is None else \
-            self._finish_with_last(last_val)
-
-    def _finish_with_last(self, last_val):
-        self.boot[self.T - 1] = last_val
-        return gae(self.rew, self.val, end=self.done, boot=self.boot, gamma=self.gamma, lam=self.lam,
-                   out=(self.adv, self.ret))
+    def finish(self):
+        """GAE-lambda advantages and rewards-to-go for every path in the block (ppo.py:65-91); paths end where done != 0
+        and at the end of the block, bootstrapped with the values the rollout kernel left in ``boot`` (ppo.py:311)."""
+        b = self.blocks
+        return gae(b['rew'], b['val'], end=b['done'], boot=b['boot'], gamma=self.gamma, lam=self.lam, out=(self.adv, self.ret))
 
     def get(self, group=None):
         """ppo.py:93-105: obs, act, normalised adv, ret, logp."""
         normalize_advantages(self.adv, group=group)
-        return self.obs, self.act, self.adv, self.ret, self.logp
+        b = self.blocks
+        return b['obs'], b['act'], self.adv, self.ret, b['logp']
 
     def packed(self):
         """[T, n, 19] float32 = obs 9 | act 7 | rew | val | logp: the block the episode-boundary all-gather moves."""
         torch = _torch()
-        return torch.cat([self.obs.float(), self.act, self.rew[..., None], self.val[..., None], self.logp[..., None]], dim=-1)
+        b = self.blocks
+        return torch.cat([b['obs'], b['act'], b['rew'][..., None], b['val'][..., None], b['logp'][..., None]], dim=-1)

@@ -172,6 +172,14 @@ def test_policy_rollout_feeds_gae_and_ppo_buffer():
     a2, mean, std = rollout.normalize_advantages(adv.clone())
     assert abs(float(a2.mean())) < 1e-4 and abs(float(a2.std(unbiased=False)) - 1.0) < 1e-3
     assert torch.isfinite(out['obs']).all() and torch.isfinite(out['logp']).all()
+    # the same through the TrajectoryBuffer mirror
+    env.reset()
+    buf = rollout.RolloutBuffer(T, env)
+    buf.collect(env, noise=noise)
+    buf.finish()
+    o_, a_, adv_, ret_, lp_ = buf.get()
+    assert o_.shape == (T, n, 9) and a_.shape == (T, n, 7) and buf.packed().shape == (T, n, 19)
+    assert abs(float(adv_.mean())) < 1e-4 and torch.isfinite(ret_).all()
 
 
 def test_policy_argument_validation():

@@ -420,6 +420,8 @@ __device__ __forceinline__ void env_step(const StepArgs& a, const Vessel& ve, En
     const float yur = ve.Yur + ve.m11;      // fy gets -(Yr + (Yur + m11) u) r
     const float nuv = ve.Nuv - ve.m11;      // fn gets -(Nv + (Nuv - m11) u) v
     const int nsub = a.hold_plant ? 0 : a.n_substeps;
+    // unrolled x10 (20 sub-steps = 2 trips): the loop counter / compare / branch are SALU issue slots of the same lone wave
+#pragma unroll 10
     for (int k = 0; k < nsub; ++k) {
         // C(nu)nu with c13 = -q, q = m22 v + m23 r
         const float q = fmaf(ve.m22, v, ve.m23 * r);

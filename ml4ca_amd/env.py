@@ -20,7 +20,7 @@ import math
 import numpy as np
 
 from . import _lib
-from . import simtools
+from . import reset_samplers as simtools
 
 _VARIANTS = {'full': _lib.FULL, 'simple': _lib.SIMPLE, 'limited': _lib.LIMITED, 'final': _lib.FINAL}
 _NAMES = {'full': 'full', 'simple': 'revoltsimple', 'limited': 'revoltlimited', 'final': 'revoltfinal'}   # ENV:37,335,360,385

@@ -37,7 +37,7 @@ def test_config1_pseudoinverse_allocation():
 
 
 def test_host_reset_samplers_match_reference_fixture():
-    from ml4ca_amd import simtools
+    from ml4ca_amd import reset_samplers as simtools
     d = np.load(os.path.join(G, 'env_final_cont.npz'))
     got = np.array([simtools.get_fixed_pose_on_radius(n) for n in range(6)])
     assert np.allclose(got, d['fixed_pose_on_radius'], rtol=0, atol=1e-15)

@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Fit the BUILD-OWNED hull parameters to the only plant outputs the reference ships (soft validation data, no parity):
+  (a) free drift in a 0.2 m/s / 135 deg current, zero thrust (tests/golden/cybersea_free_drift.npz),
+  (b) the RL box test: the trained actor fed the recorded filtered setpoints, pose vs the Cybersea record
+      (cybersea_box_rl.npz, final_policy.npz),
+  (c) the steady full-thrust speeds noted in customEnv.py:13-14 (surge 2.20 m/s, yaw 0.60 rad/s, sway 0.35 m/s).
+CPU only: float64 oracle plant + NumPy policy in closed loop; Nelder-Mead over a handful of coefficients.
+Prints the fitted vector; the defaults in dpenv_default_vessel / dpo_default_vessel are updated by hand from it."""
+import os
+import sys
+
+import numpy as np
+from scipy.optimize import minimize
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O
+
+G = os.path.join(ROOT, 'tests', 'golden')
+box = np.load(os.path.join(G, 'cybersea_box_rl.npz'))
+drift = np.load(os.path.join(G, 'cybersea_free_drift.npz'))
+pol = np.load(os.path.join(G, 'final_policy.npz'))
+W = [(pol['pi.dense%s.kernel' % s].astype(np.float64), pol['pi.dense%s.bias' % s].astype(np.float64)) for s in ('', '_1', '_2', '_3')]
+
+
+def actor(o):
+    x = o
+    for i, (w, b) in enumerate(W):
+        x = x @ w + b
+        if i < 3:
+            x = np.where(x > 0, x, 0.2 * x)
+    return x
+
+
+NAMES = ['XU', 'XUU', 'YV', 'YVV', 'YR', 'NV', 'NR', 'NRR', 'NUV', 'YUR', 'M22', 'M33']
+IDX = dict(M11=0, M22=1, M23=2, M33=3, XU=4, XUU=5, YV=6, YVV=7, YR=8, NV=9, NR=10, NRR=11, NUV=24, YUR=25)
+
+
+def vessel_from(theta, base):
+    v = base.copy()
+    for nme, x in zip(NAMES, theta):
+        v[IDX[nme]] = x
+    return v
+
+
+def simulate_drift(v):
+    orc = O.Oracle(O.make_config(terminate=0, current_enabled=1), np.float64, vessel=v)
+    st, ctr = orc.new_state(1)
+    orc.reset(st, ctr, init=np.zeros((6, 1)))
+    cur = drift['current'].reshape(2, 1).astype(np.float64)
+    a = np.zeros((1, 7)); a[0, 4] = 1; a[0, 6] = 1
+    out = []
+    for _ in range(len(drift['t']) - 1):
+        orc.step(st, ctr, a, current=cur)
+        out.append(st[0:3, 0].copy())
+    return np.array(out)
+
+
+def simulate_box(v):
+    orc = O.Oracle(O.make_config(terminate=0, wrap_mode=O.WRAP_RADIANS), np.float64, vessel=v)
+    refs = box['setpoint'].astype(np.float64)
+    st, ctr = orc.new_state(1)
+    obs = orc.reset(st, ctr, init=np.zeros((6, 1)), ref=refs[0].reshape(3, 1))
+    out = []
+    for k in range(len(refs) - 1):
+        a = actor(obs)
+        obs, _, _ = orc.step(st, ctr, a, new_ref=refs[k + 1].reshape(3, 1))
+        out.append(st[0:3, 0].copy())
+    return np.array(out)
+
+
+def steady(v):
+    """steady surge / yaw-rate at full stern thrust (no cross coupling): roots of the 1-DOF balances"""
+    Fx = 2 * 20.5
+    u = (-v[4] + np.sqrt(v[4] ** 2 + 4 * v[5] * Fx)) / (2 * v[5])
+    Mz = 2 * 20.5 * 1.12 + 9.0 * 1.08
+    r = (-v[10] + np.sqrt(v[10] ** 2 + 4 * v[11] * Mz)) / (2 * v[11])
+    return u, r
+
+
+def cost(theta, base, verbose=False):
+    if np.any(np.asarray(theta)[[0, 1, 2, 3, 6, 7, 10, 11]] <= 0):
+        return 1e6
+    v = vessel_from(theta, base)
+    if v[1] * v[3] - v[2] ** 2 <= 0:
+        return 1e6
+    d = simulate_drift(v)
+    b = simulate_box(v)
+    if not (np.isfinite(d).all() and np.isfinite(b).all()):
+        return 1e6
+    ed = d - drift['pose'][1:]
+    eb = b - box['pose'][1:]
+    u, r = steady(v)
+    J_d = np.mean(ed[:, 0] ** 2 + ed[:, 1] ** 2) + np.mean((ed[:, 2] / np.radians(10)) ** 2) * 0.25
+    J_b = np.mean(eb[:, 0] ** 2 + eb[:, 1] ** 2) * 4.0 + np.mean((eb[:, 2] / np.radians(5)) ** 2) * 0.25
+    J_p = ((u - 2.2) / 0.1) ** 2 * 0.1 + ((r - 0.6) / 0.03) ** 2 * 0.1
+    if verbose:
+        print('drift rms: pos %.2f m yaw %.1f deg | box rms: N %.2f E %.2f yaw %.1f deg | steady u %.2f r %.2f' % (
+            np.sqrt(np.mean(ed[:, 0] ** 2 + ed[:, 1] ** 2)), np.degrees(np.sqrt(np.mean(ed[:, 2] ** 2))),
+            np.sqrt(np.mean(eb[:, 0] ** 2)), np.sqrt(np.mean(eb[:, 1] ** 2)), np.degrees(np.sqrt(np.mean(eb[:, 2] ** 2))), u, r))
+    return J_d + J_b + J_p
+
+
+if __name__ == '__main__':
+    base = O.Oracle(O.make_config(), np.float64).vessel.copy()
+    th0 = np.array([base[IDX[n]] for n in NAMES])
+    print('start:', dict(zip(NAMES, th0.round(2))))
+    print('J0 = %.3f' % cost(th0, base, verbose=True))
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 600
+    res = minimize(cost, th0, args=(base,), method='Nelder-Mead',
+                   options=dict(maxfev=iters, xatol=1e-2, fatol=1e-4, adaptive=True,
+                                initial_simplex=np.vstack([th0] + [th0 + np.eye(len(th0))[i] * (0.25 * abs(th0[i]) + 5.0) for i in range(len(th0))])))
+    print('fitted:', dict(zip(NAMES, res.x.round(3))))
+    print('J = %.3f after %d evaluations' % (cost(res.x, base, verbose=True), res.nfev))

@@ -506,6 +506,18 @@ def gen_cybersea_box():
     np.savez_compressed(os.path.join(OUT, 'cybersea_box_rl.npz'), t=tt, pose=pose.astype(np.float32),
                         setpoint=setp.astype(np.float32))
     print('wrote cybersea_box_rl.npz (%d samples at 5 Hz)' % T)
+    # free drift: zero thrust in a 0.2 m/s current towards 135 deg (results/all_plots/stationKeep135/bagfile__NO_*,
+    # current_box_test/plot_pos.py:78) - the cleanest open-loop plant response in the tree
+    fd = np.genfromtxt(os.path.join(REF, 'results/all_plots/stationKeep135/bagfile__NO_observer_eta_ned.csv'),
+                       delimiter=',', skip_header=1)
+    tf = fd[:, 7]
+    Tf = int(tf[-1] / 0.2)
+    ttf = np.arange(Tf) * 0.2
+    posef = np.stack([np.interp(ttf, tf, fd[:, 1] - fd[0, 1]), np.interp(ttf, tf, fd[:, 2] - fd[0, 2]),
+                      np.radians(np.interp(ttf, tf, fd[:, 6] - fd[0, 6]))], 1)
+    np.savez_compressed(os.path.join(OUT, 'cybersea_free_drift.npz'), t=ttf, pose=posef.astype(np.float32),
+                        current=np.array([0.2, np.radians(135.0)]))
+    print('wrote cybersea_free_drift.npz (%d samples at 5 Hz)' % Tf)
 
 
 def gen_qp():

@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""PPO-clip on the batched ReVolt DP environment with the rollout entirely inside one launch per epoch.
+
+Host-side glue around the accelerated path (the PPO update is out of the hot path's scope: SURVEY section 2 row 9):
+the algorithm and hyper-parameters are the reference's (spinup/algos/tf1/ppo/ppo.py:109-347, train.py:29-55,
+config.json of the shipped run): clip 0.2, pi_lr 3e-4, vf_lr 1e-3, <= 80 policy iterations with early stop at
+KL > 1.5 * 0.01, 80 value iterations, gamma 0.99, lambda 0.97, hidden 3 x 80 leaky-relu, T = 400.
+What differs is the rollout: N environments x T steps from ONE dpenv_policy_rollout launch (actor, sampling,
+env.step, critic, trajectory rows), GAE by one scan kernel, advantage statistics by device reductions.
+
+    python examples/train_ppo.py --envs 4096 --epochs 30
+"""
+import argparse
+import math
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ml4ca_amd
+from ml4ca_amd import rollout
+from ml4ca_amd.policy import ActorCritic
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--envs', type=int, default=4096)
+    ap.add_argument('--epochs', type=int, default=30)
+    ap.add_argument('--steps', type=int, default=400, help='rollout length per epoch = max_ep_len (train.py:70-73)')
+    ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--minibatch', type=int, default=1 << 18, help='samples per gradient step (full batch in the reference)')
+    args = ap.parse_args()
+    dev = torch.device('cuda:0')
+    torch.manual_seed(args.seed)
+    env = ml4ca_amd.BatchedRevoltEnv(args.envs, auto_reset=True, seed=args.seed)       # final / ext / cont_ang
+    ac = ActorCritic(9, 7, (80, 80, 80), leak=0.2, seed=args.seed, device=dev)
+    for p in ac.parameters():
+        p.requires_grad_(True)
+    pi_params = ac.pi_W + ac.pi_b + [ac.log_std]
+    v_params = ac.v_W + ac.v_b
+    pi_opt = torch.optim.Adam(pi_params, lr=3e-4)
+    v_opt = torch.optim.Adam(v_params, lr=1e-3)
+    clip, target_kl, T, n = 0.2, 0.01, args.steps, args.envs
+    buf = rollout.RolloutBuffer(T, env, gamma=0.99, lam=0.97)
+    ac.upload(env)
+    env.reset()
+    print('epoch  mean_reward/step(max 3.5)  terminated/1k-steps  pi_iters  KL      V-loss    rollout_ms  update_s')
+    for epoch in range(args.epochs):
+        noise = torch.randn((T, n, 7), device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        blk = buf.collect(env, noise=noise)
+        buf.finish()
+        obs, act, adv, ret, logp_old = buf.get()
+        torch.cuda.synchronize()
+        t_roll = time.perf_counter() - t0
+        obs, act = obs.reshape(-1, 9), act.reshape(-1, 7)
+        adv, ret, logp_old = adv.reshape(-1), ret.reshape(-1), logp_old.reshape(-1)
+        N = obs.shape[0]
+        mb = min(args.minibatch, N)
+        t1 = time.perf_counter()
+        kl, pi_iters = 0.0, 0
+        for i in range(80):                                                     # ppo.py:265-271
+            idx = torch.randint(0, N, (mb,), device=dev) if mb < N else slice(None)
+            mu = ac._mlp(obs[idx], ac.pi_W, ac.pi_b)
+            logp = ac.logp_ref(act[idx], mu)
+            ratio = torch.exp(logp - logp_old[idx])
+            a = adv[idx]
+            pi_loss = -torch.min(ratio * a, torch.clamp(ratio, 1 - clip, 1 + clip) * a).mean()   # ppo.py:238-240
+            kl = float((logp_old[idx] - logp).mean().detach())
+            if kl > 1.5 * target_kl:                                            # ppo.py:267-270
+                break
+            pi_opt.zero_grad()
+            pi_loss.backward()
+            pi_opt.step()
+            pi_iters += 1
+        for i in range(80):                                                     # ppo.py:272-273
+            idx = torch.randint(0, N, (mb,), device=dev) if mb < N else slice(None)
+            v = ac._mlp(obs[idx], ac.v_W, ac.v_b)[:, 0]
+            v_loss = ((ret[idx] - v) ** 2).mean()                               # ppo.py:241
+            v_opt.zero_grad()
+            v_loss.backward()
+            v_opt.step()
+        with torch.no_grad():
+            ac.log_std.clamp_(-4.0, 1.0)
+        ac.upload(env)
+        torch.cuda.synchronize()
+        t_upd = time.perf_counter() - t1
+        done = blk['done']
+        print('%5d  %10.3f  %22.2f  %8d  %.4f  %8.1f  %9.1f  %8.2f' % (
+            epoch, float(blk['rew'].mean()), 1000.0 * float((done & 1).float().mean()), pi_iters, kl, float(v_loss),
+            t_roll * 1e3, t_upd))
+    print('env-steps collected: %d (%.1f M per epoch)' % (args.epochs * T * n, T * n / 1e6))
+
+
+if __name__ == '__main__':
+    main()

@@ -79,8 +79,13 @@ def steady(v):
 
 
 def cost(theta, base, verbose=False):
-    if np.any(np.asarray(theta)[[0, 1, 2, 3, 6, 7, 10, 11]] <= 0):
+    th = np.asarray(theta)
+    if np.any(th[[0, 1, 2, 3, 6, 7, 10, 11]] <= 0):
         return 1e6
+    # keep some linear damping in every axis (a hull with none is a fitting artefact of records dominated by
+    # moderate speeds): soft lower bounds XU >= 3, YV >= 10, NR >= 10, YVV >= 5, NRR >= 5
+    lo = np.array([3.0, 0.0, 10.0, 5.0, -1e9, -1e9, 10.0, 5.0, -1e9, -1e9, 257.0, 298.0])
+    pen = float(np.sum(np.maximum(lo - th, 0.0) ** 2)) * 10.0
     v = vessel_from(theta, base)
     if v[1] * v[3] - v[2] ** 2 <= 0:
         return 1e6
@@ -98,12 +103,14 @@ def cost(theta, base, verbose=False):
         print('drift rms: pos %.2f m yaw %.1f deg | box rms: N %.2f E %.2f yaw %.1f deg | steady u %.2f r %.2f' % (
             np.sqrt(np.mean(ed[:, 0] ** 2 + ed[:, 1] ** 2)), np.degrees(np.sqrt(np.mean(ed[:, 2] ** 2))),
             np.sqrt(np.mean(eb[:, 0] ** 2)), np.sqrt(np.mean(eb[:, 1] ** 2)), np.degrees(np.sqrt(np.mean(eb[:, 2] ** 2))), u, r))
-    return J_d + J_b + J_p
+    return J_d + J_b + J_p + pen
 
 
 if __name__ == '__main__':
     base = O.Oracle(O.make_config(), np.float64).vessel.copy()
     th0 = np.array([base[IDX[n]] for n in NAMES])
+    if len(sys.argv) > 2:
+        th0 = np.array([float(x) for x in sys.argv[2].split(',')])
     print('start:', dict(zip(NAMES, th0.round(2))))
     print('J0 = %.3f' % cost(th0, base, verbose=True))
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 600

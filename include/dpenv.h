@@ -81,7 +81,7 @@ enum {
     DPENV_P_KR_BOW, DPENV_P_KR_PORT, DPENV_P_KR_STAR, /* n < 0 */
     DPENV_P_LX_BOW, DPENV_P_LX_PORT, DPENV_P_LX_STAR,
     DPENV_P_LY_BOW, DPENV_P_LY_PORT, DPENV_P_LY_STAR,
-    DPENV_P_NUV, DPENV_P_YUR, /* lift-type cross-flow terms: yaw moment -N_uv u v (N_uv < -(m22-m11) = weathervane-stable), sway force -Y_ur u r */
+    DPENV_P_NUV, DPENV_P_YUR, /* speed-proportional cross-flow terms: yaw moment -N_uv u v (adds to the Munk moment -(m22-m11) u v; N_uv < -(m22-m11) would make the hull weathervane-stable), sway force -Y_ur u r */
     DPENV_NPARAM = 32
 };
 #define DPENV_MAX_CLASSES 64

@@ -97,12 +97,13 @@ extern "C" int dpenv_default_vessel(float* p)
 {
     if (!p) return DPENV_EINVAL;
     for (int i = 0; i < DPENV_NPARAM; ++i) p[i] = 0.0f;
-    p[DPENV_P_M11] = 263.93f; p[DPENV_P_M22] = 306.44f; p[DPENV_P_M23] = 7.0f; p[DPENV_P_M33] = 322.56f;
-    p[DPENV_P_XU] = 6.0f;  p[DPENV_P_XUU] = 5.75f;
-    p[DPENV_P_YV] = 30.0f; p[DPENV_P_YVV] = 58.8f;
-    p[DPENV_P_YR] = 2.0f;  p[DPENV_P_NV] = 2.0f;
-    p[DPENV_P_NR] = 50.0f; p[DPENV_P_NRR] = 71.1f;
-    p[DPENV_P_NUV] = -60.0f; p[DPENV_P_YUR] = 0.0f;
+    // fitted to the reference's recorded Cybersea runs by tools/calibrate_plant.py
+    p[DPENV_P_M11] = 263.93f; p[DPENV_P_M22] = 300.9f; p[DPENV_P_M23] = 7.0f; p[DPENV_P_M33] = 300.0f;
+    p[DPENV_P_XU] = 3.0f;  p[DPENV_P_XUU] = 7.1f;
+    p[DPENV_P_YV] = 19.8f; p[DPENV_P_YVV] = 80.3f;
+    p[DPENV_P_YR] = -1.1f; p[DPENV_P_NV] = 19.7f;
+    p[DPENV_P_NR] = 77.8f; p[DPENV_P_NRR] = 24.9f;
+    p[DPENV_P_NUV] = 40.0f; p[DPENV_P_YUR] = 30.0f;
     p[DPENV_P_KF_BOW] = 0.0009f; p[DPENV_P_KF_PORT] = 0.00205f; p[DPENV_P_KF_STAR] = 0.00205f;
     p[DPENV_P_KR_BOW] = 0.0009f; p[DPENV_P_KR_PORT] = 0.00205f; p[DPENV_P_KR_STAR] = 0.00205f;
     p[DPENV_P_LX_BOW] = 1.08f; p[DPENV_P_LX_PORT] = -1.12f; p[DPENV_P_LX_STAR] = -1.12f;

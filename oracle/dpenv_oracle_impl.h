@@ -63,12 +63,13 @@ int FN(dpo_obs_dim)(const dpo_config* c) { return c->extended_state ? 9 : 6; } /
 void FN(dpo_default_vessel)(REAL* p)
 {
     for (int i = 0; i < DPO_NPARAM; ++i) p[i] = R(0);
-    p[DPO_P_M11] = R(263.93); p[DPO_P_M22] = R(306.44); p[DPO_P_M23] = R(7.0); p[DPO_P_M33] = R(322.56);
-    p[DPO_P_XU] = R(6.0);  p[DPO_P_XUU] = R(5.75);
-    p[DPO_P_YV] = R(30.0); p[DPO_P_YVV] = R(58.8);
-    p[DPO_P_YR] = R(2.0);  p[DPO_P_NV] = R(2.0);
-    p[DPO_P_NR] = R(50.0); p[DPO_P_NRR] = R(71.1);
-    p[DPO_P_NUV] = R(-60.0); p[DPO_P_YUR] = R(0.0);
+    /* fitted to the reference's recorded Cybersea runs by tools/calibrate_plant.py */
+    p[DPO_P_M11] = R(263.93); p[DPO_P_M22] = R(300.9); p[DPO_P_M23] = R(7.0); p[DPO_P_M33] = R(300.0);
+    p[DPO_P_XU] = R(3.0);  p[DPO_P_XUU] = R(7.1);
+    p[DPO_P_YV] = R(19.8); p[DPO_P_YVV] = R(80.3);
+    p[DPO_P_YR] = R(-1.1); p[DPO_P_NV] = R(19.7);
+    p[DPO_P_NR] = R(77.8); p[DPO_P_NRR] = R(24.9);
+    p[DPO_P_NUV] = R(40.0); p[DPO_P_YUR] = R(30.0);
     p[DPO_P_KF_BOW] = R(0.0009); p[DPO_P_KF_PORT] = R(0.00205); p[DPO_P_KF_STAR] = R(0.00205);
     p[DPO_P_KR_BOW] = R(0.0009); p[DPO_P_KR_PORT] = R(0.00205); p[DPO_P_KR_STAR] = R(0.00205);
     p[DPO_P_LX_BOW] = R(1.08); p[DPO_P_LX_PORT] = R(-1.12); p[DPO_P_LX_STAR] = R(-1.12);

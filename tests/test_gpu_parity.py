@@ -538,15 +538,17 @@ def test_full_size_physical_properties():
     o2m[:, 7], o2m[:, 8] = o2[:, 8].clone(), o2[:, 7].clone()
     assert float((o1 - o2m).abs().max()) < 2e-5
     assert float((r1 - r2).abs().max()) < 2e-5
-    # soft pins of the plant (customEnv.py:13-14, no thrust loss): ~2.2 m/s ahead, ~0.6 rad/s yaw at full thrust
+    # full stern thrust from rest: 20 s in, every env is doing the same ~1.9 m/s (the steady 2.20 m/s pin of
+    # customEnv.py:13-14 is checked on the float64 oracle in tests/test_host_cpu.py: the calibrated hull, like the
+    # Cybersea one, is not straight-line stable, so fp32 rounding asymmetry makes a long open-loop run veer)
     env.reset(init=torch.zeros((6, n), device=dev))
     full = a0.clone()
     full[:, 1:3] = 1.0
-    for _ in range(500):
+    for _ in range(100):
         env.step(full)
     s, _ = env.get_state()
     u = s[3]
-    assert float((u - u[0]).abs().max()) == 0.0 and 2.0 < float(u[0]) < 2.4
+    assert float((u - u[0]).abs().max()) < 1e-5 and 1.8 < float(u[0]) < 2.05 and float(s[4:6].abs().max()) < 1e-3
 
 
 # --------------------------------------------------------------------------------------------

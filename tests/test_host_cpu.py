@@ -207,3 +207,34 @@ def test_qp_allocator_restatement_matches_reference_fixture():
     qr = QPAllocator(retry=True)
     x, ok = qr.solve([60.0, -30.0, 40.0])
     assert ok and abs(x[0] - 5.0) < 1e-3 and np.abs(x[5:]).max() > 1.0
+
+
+def test_default_hull_soft_pins_and_free_drift_record():
+    """The BUILD-OWNED default hull (calibrated by tools/calibrate_plant.py; no parity claim) against what the reference
+    records about its plant: steady full-thrust speeds (customEnv.py:13-14: +2.20 m/s, 0.60 rad/s) and the free-drift
+    run in a 0.2 m/s / 135 deg current (results/all_plots/stationKeep135, fixture cybersea_free_drift.npz), incl. the
+    swing towards broadside that the Munk moment produces."""
+    from oracle import oracle as O
+    orc = O.Oracle(O.make_config(terminate=0, current_enabled=1), np.float64)
+    e, v = np.zeros(3), np.zeros(3)
+    for _ in range(600):
+        e, v = orc.plant(e, v, [0, 100, 100], [np.pi / 2, 0, 0])
+    assert abs(v[0] - 2.20) < 0.05 and abs(v[1]) < 1e-9 and abs(v[2]) < 1e-9
+    e, v = np.zeros(3), np.zeros(3)
+    for _ in range(600):
+        e, v = orc.plant(e, v, [100, 100, 100], [np.pi / 2, -np.pi / 2, -np.pi / 2])
+    assert abs(v[2] - 0.60) < 0.03
+    d = np.load(os.path.join(G, 'cybersea_free_drift.npz'))
+    st, ctr = orc.new_state(1)
+    orc.reset(st, ctr, init=np.zeros((6, 1)))
+    cur = d['current'].reshape(2, 1).astype(np.float64)
+    a = np.zeros((1, 7))
+    a[0, 4] = a[0, 6] = 1.0
+    traj = []
+    for _ in range(len(d['t']) - 1):
+        orc.step(st, ctr, a, current=cur)
+        traj.append(st[0:3, 0].copy())
+    err = np.array(traj) - d['pose'][1:]
+    assert np.sqrt((err[:, :2] ** 2).sum(1).mean()) < 0.6          # measured 0.36 m over 60 s
+    assert np.degrees(np.sqrt((err[:, 2] ** 2).mean())) < 12.0       # measured 8.1 deg
+    assert np.degrees(np.array(traj)[:, 2].max()) > 30.0             # the hull does swing towards broadside (record: 49 deg)

@@ -84,8 +84,11 @@ def cost(theta, base, verbose=False):
         return 1e6
     # keep some linear damping in every axis (a hull with none is a fitting artefact of records dominated by
     # moderate speeds): soft lower bounds XU >= 3, YV >= 10, NR >= 10, YVV >= 5, NRR >= 5
-    lo = np.array([3.0, 0.0, 10.0, 5.0, -1e9, -1e9, 10.0, 5.0, -1e9, -1e9, 257.0, 298.0])
-    pen = float(np.sum(np.maximum(lo - th, 0.0) ** 2)) * 10.0
+    # physically sensible box (soft): some linear damping on every axis, quadratic terms present, cross terms and
+    # added masses within what a 3 m / 257 kg hull can have; keeps the few records from being over-fitted
+    lo = np.array([3.0, 2.0, 10.0, 5.0, -20.0, -20.0, 20.0, 20.0, -60.0, -30.0, 290.0, 300.0])
+    hi = np.array([15.0, 15.0, 80.0, 120.0, 20.0, 20.0, 120.0, 150.0, 40.0, 30.0, 450.0, 400.0])
+    pen = float(np.sum((np.maximum(lo - th, 0.0) / (0.05 * (hi - lo))) ** 2 + (np.maximum(th - hi, 0.0) / (0.05 * (hi - lo))) ** 2))
     v = vessel_from(theta, base)
     if v[1] * v[3] - v[2] ** 2 <= 0:
         return 1e6

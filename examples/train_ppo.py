@@ -90,7 +90,7 @@ def main():
         t_upd = time.perf_counter() - t1
         done = blk['done']
         print('%5d  %10.3f  %22.2f  %8d  %.4f  %8.1f  %9.1f  %8.2f' % (
-            epoch, float(blk['rew'].mean()), 1000.0 * float((done & 1).float().mean()), pi_iters, kl, float(v_loss),
+            epoch, float(blk['rew'].mean()), 1000.0 * float((done & 1).float().mean()), pi_iters, kl, float(v_loss.detach()),
             t_roll * 1e3, t_upd))
     print('env-steps collected: %d (%.1f M per epoch)' % (args.epochs * T * n, T * n / 1e6))
 

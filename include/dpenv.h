@@ -209,7 +209,8 @@ typedef struct dpenv_policy_rollout_io {
     uint32_t struct_size;
     int32_t T;
     const float* noise;      /* [T][n][act_dim] N(0,1) draws (a = mu + exp(log_std) * noise, core.py:85); NULL: a = mu */
-    float* obs;              /* [T][n][obs_dim]  policy input of step t */
+    void* obs;               /* [T][n][obs_dim]  policy input of step t; f32 or bf16 per config.obs_dtype (the actor
+                                always sees the full-precision observation, only the stored row is rounded) */
     float* act;              /* [T][n][act_dim] */
     float* reward;           /* [T][n] */
     float* value;            /* [T][n]  V(obs[t]) */
@@ -217,13 +218,13 @@ typedef struct dpenv_policy_rollout_io {
     uint8_t* done;           /* [T][n]  DPENV_DONE_* bits */
     float* boot;             /* [T][n]  value appended at a path end (ppo.py:311): 0 if terminal, V(next obs) if only the
                                 time limit or the end of the launch cut the path; 0 elsewhere.  Feed to dpenv_gae. */
-    float* last_obs;         /* [n][obs_dim] policy input of the next launch */
+    void* last_obs;          /* [n][obs_dim] policy input of the next launch; f32 or bf16 */
     float* last_value;       /* [n] */
     int32_t n_switch;
     int32_t switch_step[DPENV_MAX_SWITCH];
     const float* refs;       /* [n_switch][3][n] */
 } dpenv_policy_rollout_io;
-/* Requires AOS layouts and f32 observations. */
+/* Requires AOS layouts. */
 int dpenv_policy_rollout(dpenv_handle h, const dpenv_policy_rollout_io* io, dpenv_stream s);
 
 /* Parity/test access to the library-owned state in the canonical format above. */

@@ -564,8 +564,8 @@ extern "C" int dpenv_policy_rollout(dpenv_handle h, const dpenv_policy_rollout_i
     if (io->T <= 0 || !io->obs || !io->act || !io->reward || !io->value || !io->logp || !io->done || !io->boot ||
         !io->last_obs || !io->last_value)
         return fail(h, DPENV_EINVAL, "T > 0 and every output block are required");
-    if (h->cfg.action_layout != DPENV_AOS || h->cfg.obs_layout != DPENV_AOS || h->cfg.obs_dtype != DPENV_F32)
-        return fail(h, DPENV_EINVAL, "policy rollout needs AOS layouts and f32 observations");
+    if (h->cfg.action_layout != DPENV_AOS || h->cfg.obs_layout != DPENV_AOS)
+        return fail(h, DPENV_EINVAL, "policy rollout needs AOS layouts");
     if (h->n_classes > 1) return fail(h, DPENV_EINVAL, "policy rollout supports one vessel class");
     if (io->n_switch < 0 || io->n_switch > DPENV_MAX_SWITCH || (io->n_switch > 0 && !io->refs))
         return fail(h, DPENV_EINVAL, "bad setpoint schedule");

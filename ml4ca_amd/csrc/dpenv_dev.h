@@ -105,14 +105,14 @@ struct PolicyArgs {
     // rollout I/O
     int32_t T;
     const float* noise;       // [T][n][A] standard normal draws, NULL = deterministic (a = mu)
-    float* obs_out;           // [T][n][OD]  policy input of step t   (ppo.py:298 'o')
+    void* obs_out;            // [T][n][OD]  policy input of step t   (ppo.py:298 'o'); f32 or bf16
     float* act_out;           // [T][n][A]   action taken             ('a')
     float* rew;               // [T][n]
     float* val;               // [T][n]      V(o_t)                   ('v_t')
     float* logp;              // [T][n]                               ('logp_t')
     uint8_t* done;            // [T][n]
     float* boot;              // [T][n]      bootstrap value where a path ends (ppo.py:311), else 0
-    float* last_obs;          // [n][OD]     policy input of the next launch
+    void* last_obs;           // [n][OD]     policy input of the next launch; f32 or bf16
     float* last_val;          // [n]
     int32_t n_switch;
     int32_t switch_step[MAX_SWITCH];

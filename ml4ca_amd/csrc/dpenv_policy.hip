@@ -147,13 +147,14 @@ __device__ __forceinline__ void stage_weights(uint4* lds, const PolicyArgs& pa)
 
 // wave-private AoS row I/O through LDS for a 64-env slice of a 256-thread workgroup
 template <int W>
-__device__ __forceinline__ void wave_store_rows(float* lds_w, void* dst, int64_t row0_elems, int64_t rem, const float* v, int lane)
+__device__ __forceinline__ void wave_store_rows(float* lds_w, void* dst, int64_t row0_elems, int64_t rem, const float* v, int lane,
+                                                bool bf16 = false)
 {
     lds_order<64>();
 #pragma unroll
     for (int k = 0; k < W; ++k) lds_w[lane * W + k] = v[k];
     lds_order<64>();
-    store_rows<W, 64>(dst, row0_elems, rem, false, lds_w, lane);
+    store_rows<W, 64>(dst, row0_elems, rem, bf16, lds_w, lane);
 }
 
 template <int W>
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
     int next_switch = 0;
     for (int t = 0; t < pa.T; ++t) {
         // ---- store the policy input row, evaluate the actor ----------------------------------
-        wave_store_rows<OD>(lds_io, pa.obs_out, (int64_t)t * stride_o + w_o, rem_o, o, lane);
+        wave_store_rows<OD>(lds_io, pa.obs_out, (int64_t)t * stride_o + w_o, rem_o, o, lane, a.obs_bf16 != 0);
         float mu[8];
         mlp_eval(Wpi, pa.n_hidden, in0, in1, leak, mu);
         // ---- sample: a = mu + std * xi (core.py:85), log-likelihood (core.py:42-46) -----------
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
         }
     }
     // observation after the last step (policy input of the next launch) and final state
-    wave_store_rows<OD>(lds_io, pa.last_obs, w_o, rem_o, o, lane);
+    wave_store_rows<OD>(lds_io, pa.last_obs, w_o, rem_o, o, lane, a.obs_bf16 != 0);
     if (live) {
         pa.last_val[i] = v_t;
         store_env(a, i, s, rf_dirty);

@@ -159,11 +159,11 @@ def policy_rollout(env, T, noise=None, switch_steps=(), refs=None, out=None):
         env._chk(refs, (k, 3, n), torch.float32, 'refs')
     f32 = torch.float32
     if out is None:
-        out = dict(obs=torch.empty((T, n, od), dtype=f32, device=dev), act=torch.empty((T, n, ad), dtype=f32, device=dev),
+        out = dict(obs=torch.empty((T, n, od), dtype=env.obs_torch_dtype, device=dev), act=torch.empty((T, n, ad), dtype=f32, device=dev),
                    rew=torch.empty((T, n), dtype=f32, device=dev), val=torch.empty((T, n), dtype=f32, device=dev),
                    logp=torch.empty((T, n), dtype=f32, device=dev), boot=torch.empty((T, n), dtype=f32, device=dev),
                    done=torch.empty((T, n), dtype=torch.uint8, device=dev),
-                   last_obs=torch.empty((n, od), dtype=f32, device=dev), last_val=torch.empty(n, dtype=f32, device=dev))
+                   last_obs=torch.empty((n, od), dtype=env.obs_torch_dtype, device=dev), last_val=torch.empty(n, dtype=f32, device=dev))
     io = _lib.PolicyRolloutIO()
     io.struct_size = C.sizeof(_lib.PolicyRolloutIO)
     io.T = int(T)

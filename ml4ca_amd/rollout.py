@@ -90,11 +90,11 @@ class RolloutBuffer(object):
         n, od, ad, dev = env.n_envs, env.num_states, env.num_actions, env.device
         self.T, self.n, self.gamma, self.lam = int(T), n, gamma, lam
         f32 = torch.float32
-        self.blocks = dict(obs=torch.zeros((T, n, od), dtype=f32, device=dev), act=torch.zeros((T, n, ad), dtype=f32, device=dev),
+        self.blocks = dict(obs=torch.zeros((T, n, od), dtype=env.obs_torch_dtype, device=dev), act=torch.zeros((T, n, ad), dtype=f32, device=dev),
                            rew=torch.zeros((T, n), dtype=f32, device=dev), val=torch.zeros((T, n), dtype=f32, device=dev),
                            logp=torch.zeros((T, n), dtype=f32, device=dev), boot=torch.zeros((T, n), dtype=f32, device=dev),
                            done=torch.zeros((T, n), dtype=torch.uint8, device=dev),
-                           last_obs=torch.zeros((n, od), dtype=f32, device=dev), last_val=torch.zeros(n, dtype=f32, device=dev))
+                           last_obs=torch.zeros((n, od), dtype=env.obs_torch_dtype, device=dev), last_val=torch.zeros(n, dtype=f32, device=dev))
         self.adv = torch.zeros((T, n), dtype=f32, device=dev)
         self.ret = torch.zeros((T, n), dtype=f32, device=dev)
 
@@ -120,4 +120,4 @@ class RolloutBuffer(object):
         """[T, n, 19] float32 = obs 9 | act 7 | rew | val | logp: the block the episode-boundary all-gather moves."""
         torch = _torch()
         b = self.blocks
-        return torch.cat([b['obs'], b['act'], b['rew'][..., None], b['val'][..., None], b['logp'][..., None]], dim=-1)
+        return torch.cat([b['obs'].float(), b['act'], b['rew'][..., None], b['val'][..., None], b['logp'][..., None]], dim=-1)

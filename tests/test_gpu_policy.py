@@ -182,6 +182,28 @@ def test_policy_rollout_feeds_gae_and_ppo_buffer():
     assert abs(float(adv_.mean())) < 1e-4 and torch.isfinite(ret_).all()
 
 
+def test_policy_rollout_bf16_observation_rows():
+    """Config 5 stores observations as bf16: same trajectory, stored rows = round-to-nearest-even of the f32 rows."""
+    from ml4ca_amd.policy import policy_rollout
+    torch = torch_()
+    n, T = 1500, 20
+    kw = dict(auto_reset=True, max_ep_len=30, seed=5)
+    e32, _ = H.make_pair('final_cont', n, **kw)
+    e16, _ = H.make_pair('final_cont', n, obs_dtype='bfloat16', **kw)
+    ac = make_ac(9, 7, (80, 80, 80), seed=4, device=e32.device)
+    ac.upload(e32)
+    ac.upload(e16)
+    noise = torch.randn((T, n, 7), device=e32.device)
+    e32.reset()
+    e16.reset()
+    a = policy_rollout(e32, T, noise=noise)
+    b = policy_rollout(e16, T, noise=noise)
+    assert b['obs'].dtype == torch.bfloat16 and b['last_obs'].dtype == torch.bfloat16
+    assert torch.equal(a['obs'].to(torch.bfloat16), b['obs']) and torch.equal(a['last_obs'].to(torch.bfloat16), b['last_obs'])
+    for k in ('act', 'rew', 'val', 'logp', 'done', 'boot'):
+        assert torch.equal(a[k], b[k]), k
+
+
 def test_policy_argument_validation():
     import ml4ca_amd
     from ml4ca_amd.policy import ActorCritic, policy_forward, policy_rollout

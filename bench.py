@@ -268,6 +268,39 @@ def main():
                   'unfused_torch_fp32_policy_plus_step_kernel': {'env_steps_per_s': n * 200 / twall, 'us_per_step': twall / 200 * 1e6},
                   'speedup_vs_unfused': (twall / 200) / (cwall / K)}
 
+    # ---- config-5 leg (BASELINE.json configs[4]): drifting current, bf16 observation rows, full PPO rollout block
+    #      (T = 400 = one episode, auto-reset) + GAE scan + advantage normalisation, all on device ------------------
+    cfg5 = None
+    if not args.no_fused:
+        from ml4ca_amd import rollout as RO
+        env5 = ml4ca_amd.BatchedRevoltEnv(n, variant='final', extended_state=True, cont_ang=True, device=dev, auto_reset=True,
+                                          seed=2, env_id_base=rank * n, obs_dtype='bfloat16', current=True, current_drift=True)
+        env5.set_current(torch.full((n,), 0.2, device=dev), torch.full((n,), 135.0 * deg, device=dev))
+        ac.upload(env5)
+        T5 = 400
+        buf5 = RO.RolloutBuffer(T5, env5)
+        noise5 = torch.randn((T5, n, 7), generator=g, device=dev)
+        env5.reset()
+
+        def epoch5():
+            buf5.collect(env5, noise=noise5)
+            buf5.finish()
+            return buf5.get()
+
+        epoch5()
+        torch.cuda.synchronize(dev)
+        t50 = time.perf_counter()
+        reps5 = 3
+        for _ in range(reps5):
+            o5, a5, adv5, ret5, lp5 = epoch5()
+        torch.cuda.synchronize(dev)
+        w5 = (time.perf_counter() - t50) / reps5
+        assert bool(torch.isfinite(adv5).all()) and o5.dtype == torch.bfloat16
+        cfg5 = {'what': 'BASELINE.json configs[4]: %d envs, Gauss-Markov current (0.2 m/s, 135 deg), bf16 obs rows, one launch of '
+                        'T = 400 policy-in-the-loop steps with auto-reset + GAE(0.99, 0.97) + advantage normalisation' % n,
+                'env_steps_per_s': n * T5 / w5, 'ms_per_epoch': w5 * 1e3, 'us_per_step': w5 / T5 * 1e6}
+        del env5, buf5, noise5
+
     # ---- config-4 leg: episode-boundary all-gather of [T=400, 32768, 19] f32 trajectory blocks ------------
     gather = None
     do_gather = (args.gather == 1) or (args.gather < 0 and world > 1)
@@ -331,6 +364,8 @@ def main():
             res['fused_rollout'] = fused
         if closed:
             res['policy_rollout'] = closed
+        if cfg5:
+            res['config5_ppo_rollout'] = cfg5
         if not args.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline(n, args.cpu_seconds)
         elif not args.no_cpu_baseline:

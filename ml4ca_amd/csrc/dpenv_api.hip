@@ -53,6 +53,20 @@ static int fail(dpenv_handle h, int code, const char* fmt, ...)
     return code;
 }
 
+// Entry points launch on the handle's device even if the caller's current device is another one.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int want)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != want) switched = (hipSetDevice(want) == hipSuccess);
+    }
+    ~DeviceGuard()
+    {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
 #define HIP_TRY(h, expr)                                                                               \
     do {                                                                                               \
         hipError_t e_ = (expr);                                                                        \
@@ -307,6 +321,7 @@ extern "C" int dpenv_create(const dpenv_config* cfg, const float* vessel_params,
 extern "C" int dpenv_destroy(dpenv_handle h)
 {
     if (!h) return DPENV_EINVAL;
+    DeviceGuard dev_guard(h->device);
     if (h->blob) (void)hipFree(h->blob);
     if (h->pol_frags) (void)hipFree(h->pol_frags);
     delete h;
@@ -327,6 +342,7 @@ extern "C" int dpenv_set_reset_fraction(dpenv_handle h, float fraction)
 extern "C" int dpenv_set_vessel_class(dpenv_handle h, const int32_t* class_id, dpenv_stream s)
 {
     if (!h || !class_id) return fail(h, DPENV_EINVAL, "dpenv_set_vessel_class: NULL argument");
+    DeviceGuard dev_guard(h->device);
     HIP_TRY(h, hipMemcpyAsync(h->class_id, class_id, sizeof(int32_t) * (size_t)h->cfg.n_envs, hipMemcpyDeviceToDevice,
                               (hipStream_t)s));
     h->classes_assigned = true;
@@ -336,6 +352,7 @@ extern "C" int dpenv_set_vessel_class(dpenv_handle h, const int32_t* class_id, d
 extern "C" int dpenv_set_current(dpenv_handle h, const float* vc, const float* beta, dpenv_stream s)
 {
     if (!h || !vc || !beta) return fail(h, DPENV_EINVAL, "dpenv_set_current: NULL argument");
+    DeviceGuard dev_guard(h->device);
     if (!h->cfg.current_enabled) return fail(h, DPENV_EINVAL, "config.current_enabled is 0");
     const size_t bytes = sizeof(float) * (size_t)h->cfg.n_envs;
     HIP_TRY(h, hipMemcpyAsync(h->cur_vc, vc, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
@@ -349,6 +366,7 @@ extern "C" int dpenv_set_current(dpenv_handle h, const float* vc, const float* b
 extern "C" int dpenv_get_current(dpenv_handle h, float* vc_out, float* beta_out, dpenv_stream s)
 {
     if (!h || !vc_out || !beta_out) return fail(h, DPENV_EINVAL, "dpenv_get_current: NULL argument");
+    DeviceGuard dev_guard(h->device);
     if (!h->cfg.current_enabled) return fail(h, DPENV_EINVAL, "config.current_enabled is 0");
     const size_t bytes = sizeof(float) * (size_t)h->cfg.n_envs;
     HIP_TRY(h, hipMemcpyAsync(vc_out, h->cur_vc, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
@@ -371,6 +389,7 @@ extern "C" int dpenv_reset(dpenv_handle h, const uint8_t* mask, const float* ini
                            dpenv_stream s)
 {
     if (!h) return DPENV_EINVAL;
+    DeviceGuard dev_guard(h->device);
     StepArgs a = h->args;
     bind_optional(h, a);
     a.obs = obs_out;
@@ -381,6 +400,7 @@ extern "C" int dpenv_reset(dpenv_handle h, const uint8_t* mask, const float* ini
 extern "C" int dpenv_step_ex(dpenv_handle h, const dpenv_step_io* io, dpenv_stream s)
 {
     if (!h) return DPENV_EINVAL;
+    DeviceGuard dev_guard(h->device);
     if (!io || io->struct_size != sizeof(dpenv_step_io)) return fail(h, DPENV_EINVAL, "dpenv_step_io ABI mismatch");
     if (!io->action || !io->obs || !io->reward || !io->done)
         return fail(h, DPENV_EINVAL, "action, obs, reward and done buffers are required");
@@ -412,6 +432,7 @@ extern "C" int dpenv_step(dpenv_handle h, const float* action, const float* new_
 extern "C" int dpenv_rollout(dpenv_handle h, const dpenv_rollout_io* io, dpenv_stream s)
 {
     if (!h) return DPENV_EINVAL;
+    DeviceGuard dev_guard(h->device);
     if (!io || io->struct_size != sizeof(dpenv_rollout_io)) return fail(h, DPENV_EINVAL, "dpenv_rollout_io ABI mismatch");
     if (io->T <= 0 || !io->actions || !io->obs || !io->reward || !io->done)
         return fail(h, DPENV_EINVAL, "T > 0 and action, obs, reward, done blocks are required");
@@ -510,6 +531,7 @@ static int pack_net(const dpenv_mlp* m, int in_dim, int out_dim, std::vector<uin
 extern "C" int dpenv_set_policy(dpenv_handle h, const dpenv_mlp* pi, const dpenv_mlp* v, const float* log_std, float leak)
 {
     if (!h) return DPENV_EINVAL;
+    DeviceGuard dev_guard(h->device);
     if (!pi || !v || !log_std) return fail(h, DPENV_EINVAL, "dpenv_set_policy: NULL argument");
     if (pi->n_layers != v->n_layers || pi->sizes[1] != v->sizes[1])
         return fail(h, DPENV_EINVAL, "actor and critic must have the same hidden shape");
@@ -528,6 +550,8 @@ extern "C" int dpenv_set_policy(dpenv_handle h, const dpenv_mlp* pi, const dpenv
         if (hipMalloc(&p, 2 * bytes_net) != hipSuccess) return fail(h, DPENV_ENOMEM, "hipMalloc of the policy fragments failed");
         h->pol_frags = (uint4*)p;
     }
+    // not on the step path: make sure no launch that still reads the previous weights is in flight on any stream
+    HIP_TRY(h, hipDeviceSynchronize());
     HIP_TRY(h, hipMemcpy(h->pol_frags, fp.data(), bytes_net, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy((char*)h->pol_frags + bytes_net, fv.data(), bytes_net, hipMemcpyHostToDevice));
     PolicyArgs& pa = h->pol;
@@ -549,6 +573,7 @@ extern "C" int dpenv_set_policy(dpenv_handle h, const dpenv_mlp* pi, const dpenv
 extern "C" int dpenv_policy_forward(dpenv_handle h, const float* obs, float* mu_out, float* v_out, int32_t n, dpenv_stream s)
 {
     if (!h) return DPENV_EINVAL;
+    DeviceGuard dev_guard(h->device);
     if (!h->has_policy) return fail(h, DPENV_EINVAL, "dpenv_set_policy has not been called");
     if (!obs || !mu_out || !v_out || n <= 0) return fail(h, DPENV_EINVAL, "dpenv_policy_forward: bad argument");
     HIP_TRY(h, dpenv_dev_launch_policy_forward(&h->pol, dpenv_obs_dim(&h->cfg), dpenv_act_dim(&h->cfg), obs, mu_out, v_out, n,
@@ -559,6 +584,7 @@ extern "C" int dpenv_policy_forward(dpenv_handle h, const float* obs, float* mu_
 extern "C" int dpenv_policy_rollout(dpenv_handle h, const dpenv_policy_rollout_io* io, dpenv_stream s)
 {
     if (!h) return DPENV_EINVAL;
+    DeviceGuard dev_guard(h->device);
     if (!h->has_policy) return fail(h, DPENV_EINVAL, "dpenv_set_policy has not been called");
     if (!io || io->struct_size != sizeof(dpenv_policy_rollout_io)) return fail(h, DPENV_EINVAL, "dpenv_policy_rollout_io ABI mismatch");
     if (io->T <= 0 || !io->obs || !io->act || !io->reward || !io->value || !io->logp || !io->done || !io->boot ||
@@ -586,6 +612,7 @@ extern "C" int dpenv_policy_rollout(dpenv_handle h, const dpenv_policy_rollout_i
 extern "C" int dpenv_get_state(dpenv_handle h, float* state_out, int32_t* counters_out, dpenv_stream s)
 {
     if (!h) return DPENV_EINVAL;
+    DeviceGuard dev_guard(h->device);
     HIP_TRY(h, dpenv_dev_launch_get_state(&h->args, state_out, counters_out, (hipStream_t)s));
     return DPENV_OK;
 }
@@ -593,6 +620,7 @@ extern "C" int dpenv_get_state(dpenv_handle h, float* state_out, int32_t* counte
 extern "C" int dpenv_set_state(dpenv_handle h, const float* state_in, const int32_t* counters_in, dpenv_stream s)
 {
     if (!h) return DPENV_EINVAL;
+    DeviceGuard dev_guard(h->device);
     HIP_TRY(h, dpenv_dev_launch_set_state(&h->args, state_in, counters_in, (hipStream_t)s));
     return DPENV_OK;
 }

@@ -76,6 +76,36 @@ def test_policy_forward_matches_fp32_reference(mode, ext, hidden):
     assert float((v2 - v2_ref).abs().max()) < 2e-2 * (float(v2_ref.abs().max()) + 1)
 
 
+@pytest.mark.parametrize('mode,ext,hidden', [('limited', True, (80, 80, 80)), ('full', True, (64, 64)), ('simple', False, (80, 80, 80)),
+                                             ('final_wrap', False, (48,))])
+def test_policy_rollout_other_variants_replay_through_single_steps(mode, ext, hidden):
+    """Every env variant / observation width / network depth: the launch's stored actions, replayed through the
+    single-step kernel, reproduce rewards, done bits and next observations bit for bit; actor/critic rows match fp32."""
+    from ml4ca_amd.policy import policy_rollout
+    torch = torch_()
+    n, T = 777, 25
+    kw = dict(auto_reset=True, max_ep_len=30, seed=3)
+    env, _ = H.make_pair(mode, n, ext=ext, **kw)
+    env2, _ = H.make_pair(mode, n, ext=ext, **kw)
+    od, ad = env.num_states, env.num_actions
+    ac = make_ac(od, ad, hidden, seed=7, device=env.device).upload(env)
+    noise = torch.randn((T, n, ad), device=env.device)
+    env.reset()
+    env2.reset()
+    out = policy_rollout(env, T, noise=noise)
+    mu_ref, v_ref = ac.forward_ref(out['obs'].reshape(T * n, od))
+    want = mu_ref.reshape(T, n, ad) + torch.exp(ac.log_std) * noise
+    assert float((out['act'] - want).abs().max()) < 6e-3 * (float(mu_ref.abs().max()) + 1.0)
+    assert float((out['val'] - v_ref.reshape(T, n)).abs().max()) < 6e-3 * (float(v_ref.abs().max()) + 1.0)
+    for t in range(T):
+        o, r, d, _ = env2.step(out['act'][t].contiguous())
+        nxt = out['obs'][t + 1] if t + 1 < T else out['last_obs']
+        assert torch.equal(r, out['rew'][t]) and torch.equal(d, out['done'][t]) and torch.equal(o, nxt), t
+    sa, ca = env.get_state()
+    sb, cb = env2.get_state()
+    assert torch.equal(sa, sb) and torch.equal(ca, cb)
+
+
 @pytest.mark.parametrize('noise_on', [True, False])
 def test_policy_rollout_rows_are_consistent(noise_on):
     """One launch of T steps: every stored row must satisfy the reference relations

@@ -59,7 +59,7 @@ enum { DPENV_F32 = 0, DPENV_BF16 = 1 };
 /* bits of the per-env done byte */
 enum { DPENV_DONE_TERMINAL = 1 /* is_terminal, customEnv.py:207-213 */,
        DPENV_DONE_TIMELIMIT = 2 /* traj_len == max_ep_len, ppo.py:304 */,
-       DPENV_DONE_FAULT = 4 /* non-finite state */ };
+       DPENV_DONE_FAULT = 4 /* non-finite state or action (also sets TERMINAL) */ };
 
 /* canonical state exchange format for get/set_state: float state[DPENV_NSTATE][n_envs] */
 enum {

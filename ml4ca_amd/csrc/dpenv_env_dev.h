@@ -497,7 +497,11 @@ __device__ __forceinline__ void env_step(const StepArgs& a, const Vessel& ve, En
         d = t ? DONE_TERMINAL : 0u;
     }
     {
-        const float chk = N + E + psi + u + v + r;     // any NaN/Inf poisons the sum
+        // any NaN/Inf in the state or in the action poisons the sum (a NaN thrust would otherwise be clipped to a
+        // legal command by fminf/fmaxf and vanish)
+        float chk = N + E + psi + u + v + r;
+#pragma unroll
+        for (int k = 0; k < ModeTraits<MODE>::A; ++k) chk += act[k];
         if (!(fabsf(chk) <= 3.0e38f)) d |= DONE_TERMINAL | DONE_FAULT;
     }
     if (has_ref) { s.refN = nrN; s.refE = nrE; s.refPsi = nrP; }   // ENV:131: visible from the next step (Q4)

@@ -445,6 +445,7 @@ void FN(dpo_step)(const dpo_config* c, const REAL* vessel, int32_t n, REAL* stat
         uint8_t d = (uint8_t)FN(dpo_done)(c, o);                           /* ENV:129 */
         int finite = 1;
         for (int k = 0; k < 3; ++k) finite = finite && isfinite(eta[k]) && isfinite(nu[k]);
+        for (int k = 0; k < ad; ++k) finite = finite && isfinite(action[(int64_t)i * ad + k]);   /* a non-finite action is a fault too */
         if (!finite) d |= 5;
         if (new_ref) for (int k = 0; k < 3; ++k) ref[k] = new_ref[k * n + i];   /* ENV:131, quirk Q4 */
         counters[i] += 1;

@@ -205,12 +205,17 @@ def test_time_limit_and_fault_bits():
     ctr[0, :100] = env.max_ep_len - 1          # these hit the time limit on this step (ppo.py:304)
     st[0, 200] = np.nan                        # poisoned env
     st[3, 201] = np.inf
-    g, o = step_both(env, orc, st, ctr, H.random_actions(rng, n, 7))
+    act = H.random_actions(rng, n, 7)
+    act[202, 1] = np.nan                       # a NaN thrust command must not be clipped into a legal one
+    act[203, 5] = np.inf
+    g, o = step_both(env, orc, st, ctr, act)
     assert (g['done'][:100] & 2).all() and not (g['done'][100:] & 2).any()
-    assert g['done'][200] & 4 and g['done'][201] & 4 and (g['done'][[200, 201]] & 1).all()
+    bad = [200, 201, 202, 203]
+    assert (g['done'][bad] & 4).all() and (g['done'][bad] & 1).all()
+    assert not (np.delete(g['done'], bad) & 4).any()
     assert np.array_equal(g['done'], o['done'])
     ok = np.ones(n, bool)
-    ok[[200, 201]] = False
+    ok[bad] = False
     TOL.assert_close(g['obs'][ok], o['obs'][ok], TOL.OBS_FLOOR, what='obs')
 
 

@@ -309,3 +309,48 @@ def test_plant_tracks_the_recorded_cybersea_box_run():
     rms = np.sqrt((dev ** 2).mean(0))
     assert rms[0] < 0.5 and rms[1] < 0.5 and np.degrees(rms[2]) < 8.0, rms
     assert np.abs(dev[:, :2]).max() < 1.5
+
+
+def test_run_RL_policy_harness_with_the_trained_actor():
+    """test_policy.py:97-186 semantics, batched: six fixed starts on the 5 m circle, deterministic trained actor,
+    optional setpoint change at half time through a zero-action step."""
+    import os
+    import ml4ca_amd
+    from ml4ca_amd import evaluate as EV
+    from ml4ca_amd.policy import ActorCritic
+    torch = torch_()
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'final_policy.npz'))
+    tensors = {k.replace('.', '/'): d[k] for k in d.files if '.' in k}
+    for changes in (False, True):
+        env = ml4ca_amd.BatchedRevoltEnv(6, testing=True, time_limit=False)
+        ac = ActorCritic.from_tensors(tensors, device=env.device).upload(env)
+        res = EV.run_RL_policy(env, ac, num_episodes=6, test_setpoint_changes=changes)
+        T = env.max_ep_len
+        assert res['obs'].shape == (T + 1, 6, 9) and res['action_vec'].shape == (T + 1, 6, 6)
+        pos0 = res['ned_pos'][0].cpu().numpy()
+        assert np.allclose(np.hypot(pos0[:, 0], pos0[:, 1]), 5.0, atol=1e-5)          # simtools.py:91-107
+        assert np.allclose(pos0[:, 2], np.radians([0, 0, -15, 15, 0, -15]), atol=1e-6)
+        assert float(res['action_vec'][0, :, 3].min()) == float(res['action_vec'][0, :, 3].max())   # bow azimuth default pi/2
+        assert abs(float(res['action_vec'][0, 0, 3]) - np.pi / 2) < 1e-6
+        eplen = res['EpLen'].cpu().numpy()
+        if not changes:
+            assert (eplen == T).all(), 'the trained actor must not run any start out of bounds'
+            ok = np.ones(6, bool)
+        else:
+            # refs[2] and refs[3] ask for a 90 deg heading step: |yaw error| > pi/4 is terminal in the final env
+            # (customEnv.py:386), so - exactly as in the reference's harness - those two episodes end right after
+            # the new setpoint becomes visible
+            assert list(eplen) == [T, T, T // 2 + 2, T // 2 + 2, T, T], eplen
+            ok = eplen == T
+        # it converges on the setpoint in force: within 0.5 m / 3 deg at the end, and the return is near the thesis' (~1200-1300)
+        err = (res['ned_pos'][-1] - res['ned_ref'][-1]).cpu().numpy()[ok]
+        assert np.hypot(err[:, 0], err[:, 1]).max() < 0.5 and np.degrees(np.abs(err[:, 2])).max() < 3.0, err
+        ret = res['EpRet'].cpu().numpy()[ok]
+        assert ret.min() > (700 if changes else 900) and ret.max() < 1400, ret
+        if changes:
+            ref_end = res['ned_ref'][-1].cpu().numpy()
+            assert np.allclose(ref_end, np.array(EV.TEST_POLICY_REFS + (EV.TEST_POLICY_REFS[0],))[:6], atol=1e-6)
+            # the switching step used a zero action and restored the default action vector (test_policy.py:148-153)
+            assert torch.equal(res['action_vec'][T // 2 + 1], res['action_vec'][0])
+            assert np.allclose(res['ned_ref'][T // 2].cpu().numpy(), 0.0)              # visible one step late (Q4)
+        env.close()

@@ -177,8 +177,9 @@ __device__ __forceinline__ Vessel vessel_from_lds(const float* tab, int ncls, in
 }
 
 // SupervisedTau.py:42-83: tau = B(alpha) F, F_i = K_i n_i |n_i|
+// sc != nullptr: sin/cos of the port and starboard azimuths are already known (sc = {sin_p, cos_p, sin_s, cos_s})
 __device__ __forceinline__ void thrust_map(const Vessel& ve, const float n[3], const float al[3], float& tx, float& ty,
-                                           float& tn)
+                                           float& tn, const float* sc = nullptr)
 {
     tx = 0.0f; ty = 0.0f; tn = 0.0f;
 #pragma unroll
@@ -186,7 +187,9 @@ __device__ __forceinline__ void thrust_map(const Vessel& ve, const float n[3], c
         const float K = (n[i] >= 0.0f) ? ve.Kf[i] : ve.Kr[i];
         const float F = K * fabsf(n[i]) * n[i];
         float sa, ca;
-        if (i == 0 && al[0] == kPi * 0.5f) {
+        if (i > 0 && sc != nullptr) {
+            sa = sc[2 * (i - 1)]; ca = sc[2 * (i - 1) + 1];
+        } else if (i == 0 && al[0] == kPi * 0.5f) {
             // the bow thruster sits at its reset default pi/2 in simple/limited/final (customEnv.py:397):
             // sin/cos of float(pi/2), no evaluation needed
             sa = 1.0f; ca = -4.371139e-08f;
@@ -406,7 +409,18 @@ __device__ __forceinline__ void env_step(const StepArgs& a, const Vessel& ve, En
 
     // ---- plant: BUILD-OWNED 3-DOF model, n_substeps semi-implicit Euler steps --
     float tx, ty, tn;
-    thrust_map(ve, thr, s.ang, tx, ty, tn);
+    if (MODE == MODE_FINAL_CONT) {
+        // the azimuth is atan2 of the two heads, so its sine and cosine are the normalised heads themselves:
+        // no sincos of the angle just computed ((0, 0) -> angle 0 -> (0, 1))
+        float sc[4];
+        const float np2 = fmaf(act[3], act[3], act[4] * act[4]), ns2 = fmaf(act[5], act[5], act[6] * act[6]);
+        const float ip = __builtin_amdgcn_rsqf(np2), is = __builtin_amdgcn_rsqf(ns2);
+        sc[0] = (np2 > 0.0f) ? act[3] * ip : 0.0f; sc[1] = (np2 > 0.0f) ? act[4] * ip : 1.0f;
+        sc[2] = (ns2 > 0.0f) ? act[5] * is : 0.0f; sc[3] = (ns2 > 0.0f) ? act[6] * is : 1.0f;
+        thrust_map(ve, thr, s.ang, tx, ty, tn, sc);
+    } else {
+        thrust_map(ve, thr, s.ang, tx, ty, tn);
+    }
     float N = s.N, E = s.E, psi = s.psi, u = s.u, v = s.v, r = s.r;
     float sn = s.sn, cs = s.cs;
     if (cur) {
@@ -438,14 +452,13 @@ __device__ __forceinline__ void env_step(const StepArgs& a, const Vessel& ve, En
         // kinematics with the old heading and the new velocity
         N = fmaf(h, fmaf(-sn, v, fmaf(cs, u, vcN)), N);
         E = fmaf(h, fmaf(cs, v, fmaf(sn, u, vcE)), E);
-        // heading: exact rotation by d = h r, series for sin d / cos d
+        // heading: psi += d, d = h r; its sin/cos by the rotation (1 - d^2/2, d), i.e. exact to second order - one
+        // order above the integrator's own - and re-seeded from the exact sin/cos of psi at every env step
         const float d = h * r;
-        const float d2 = d * d;
-        const float sd = d * fmaf(d2, fmaf(d2, 1.0f / 120.0f, -1.0f / 6.0f), 1.0f);
-        const float cd = fmaf(d2, fmaf(d2, 1.0f / 24.0f, -0.5f), 1.0f);
+        const float cd = fmaf(-0.5f * d, d, 1.0f);
         psi += d;
-        const float c2 = fmaf(cs, cd, -(sn * sd));
-        const float s2n = fmaf(sn, cd, cs * sd);
+        const float c2 = fmaf(cs, cd, -(sn * d));
+        const float s2n = fmaf(sn, cd, cs * d);
         cs = c2; sn = s2n;
     }
     // exact sin/cos of the heading reached: needed by the observation, by the current term and by the next step

@@ -155,8 +155,8 @@ void FN(dpo_thrust_map)(const REAL* p, const REAL n[3], const REAL alpha[3], REA
 /*
  * BUILD-OWNED plant (replaces ENV:124 dTwin.step(20) -> Cybersea; PARITY UNPINNED).
  * 3-DOF manoeuvring model M nu_r' + C(nu_r) nu_r + D(nu_r) nu_r = tau, eta' = R(psi) nu_r + v_c,
- * n_substeps semi-implicit Euler steps of substep_dt; heading advanced by the exact rotation of
- * angle dt*r evaluated with a 5th/4th-order series (|dt*r| << 1).  Ideal actuators: commanded
+ * n_substeps semi-implicit Euler steps of substep_dt; heading advanced by dt*r, its sin/cos by a
+ * second-order rotation re-seeded from the exact values every env step.  Ideal actuators: commanded
  * n, alpha act immediately.  current = {V_c, beta_c} (NED, constant, irrotational) or NULL.
  */
 void FN(dpo_plant)(const dpo_config* c, const REAL* p, REAL eta[3], REAL nu[3], const REAL n_pct[3],
@@ -192,13 +192,13 @@ void FN(dpo_plant)(const dpo_config* c, const REAL* p, REAL eta[3], REAL nu[3], 
         r += h * (i23 * fy + i33 * fn);
         N += h * (cs * u - sn * v + vcN);
         E += h * (sn * u + cs * v + vcE);
+        /* heading by d = h r; its sin/cos by the second-order rotation (1 - d^2/2, d), re-seeded from cos/sin(psi) at
+         * every env step (one order above the Euler integrator itself) */
         REAL d = h * r;
-        REAL d2 = d * d;
-        REAL sd = d * (R(1) - d2 * (R(1) / R(6)) * (R(1) - d2 * (R(1) / R(20))));
-        REAL cd = R(1) - d2 * R(0.5) * (R(1) - d2 * (R(1) / R(12)));
+        REAL cd = R(1) - R(0.5) * d * d;
         psi += d;
-        REAL c2 = cs * cd - sn * sd;
-        REAL s2 = sn * cd + cs * sd;
+        REAL c2 = cs * cd - sn * d;
+        REAL s2 = sn * cd + cs * d;
         cs = c2; sn = s2;
     }
     if (current) {

@@ -483,7 +483,8 @@ __device__ __forceinline__ void env_step(const StepArgs& a, const Vessel& ve, En
     const float p_vel = -sqrt_hw(fmaf(o[3] * o[3], 0.5f, fmaf(o[4] * o[4], 0.5f, o[5] * o[5])));   // ENV:267-273
     const float rr2 = fmaf(o[0], o[0], o[1] * o[1]);
     const float yaw = o[2] * (180.0f / kPi);                                                    // ENV:281
-    const float multivar = 2.0f * expf(-0.5f * fmaf(yaw * yaw, 1.0f / 25.0f, rr2));             // ENV:283, covar ENV:86-88
+    // exp(x) as the hardware's exp2(x log2 e): relative error <= ~1e-7 (1 + |x|), far inside the reward tolerance
+    const float multivar = 2.0f * __builtin_amdgcn_exp2f((-0.5f * 1.4426950408889634f) * fmaf(yaw * yaw, 1.0f / 25.0f, rr2));   // ENV:283, covar ENV:86-88
     const float special = sqrt_hw(fmaf(yaw * 0.25f, yaw * 0.25f, rr2));                         // ENV:287
     const float p_pos = multivar + fmaxf(-1.0f, fmaf(-0.1f, special, 1.0f)) + 0.5f;             // ENV:288-290
     const float p_thr = -(fabsf(thr[0]) * 0.20f + fabsf(thr[1]) * 0.30f + fabsf(thr[2]) * 0.30f) * 0.01f;   // ENV:292-302

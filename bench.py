@@ -241,8 +241,6 @@ def main():
         cwall = time.perf_counter() - tc0
         assert bool(torch.isfinite(pout['obs']).all()) and bool(torch.isfinite(pout['logp']).all())
         # reference point: the same policy as separate torch kernels (fp32) + one env.step launch per step
-        mu_w = [w.clone() for w in ac.pi_W]
-        act_buf = torch.empty((n, 7), device=dev)
 
         def torch_loop(k):
             o = obs

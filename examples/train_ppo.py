@@ -11,7 +11,6 @@ env.step, critic, trajectory rows), GAE by one scan kernel, advantage statistics
     python examples/train_ppo.py --envs 4096 --epochs 30
 """
 import argparse
-import math
 import os
 import sys
 import time

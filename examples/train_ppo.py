@@ -19,6 +19,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ml4ca_amd
+from ml4ca_amd import dist as D
 from ml4ca_amd import rollout
 from ml4ca_amd.policy import ActorCritic
 
@@ -31,10 +32,17 @@ def main():
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--minibatch', type=int, default=1 << 18, help='samples per gradient step (full batch in the reference)')
     args = ap.parse_args()
-    dev = torch.device('cuda:0')
-    torch.manual_seed(args.seed)
-    env = ml4ca_amd.BatchedRevoltEnv(args.envs, auto_reset=True, seed=args.seed)       # final / ext / cont_ang
+    # one process per GPU under torch.distributed.run (backend nccl = RCCL); envs shard by global id, gradients average
+    rank, world, local = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('LOCAL_RANK', 0))
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        torch.distributed.init_process_group('nccl', device_id=dev)
+    torch.manual_seed(args.seed + 1000 * rank)
+    env = ml4ca_amd.BatchedRevoltEnv(args.envs, auto_reset=True, seed=args.seed, device=dev,
+                                     env_id_base=rank * args.envs)               # final / ext / cont_ang
     ac = ActorCritic(9, 7, (80, 80, 80), leak=0.2, seed=args.seed, device=dev)
+    D.sync_params(ac.parameters())                                               # sync_all_params, ppo.py:255
     for p in ac.parameters():
         p.requires_grad_(True)
     pi_params = ac.pi_W + ac.pi_b + [ac.log_std]
@@ -45,7 +53,8 @@ def main():
     buf = rollout.RolloutBuffer(T, env, gamma=0.99, lam=0.97)
     ac.upload(env)
     env.reset()
-    print('epoch  mean_reward/step(max 3.5)  terminated/1k-steps  pi_iters  KL      V-loss    rollout_ms  update_s')
+    if rank == 0:
+        print('epoch  mean_reward/step(max 3.5)  terminated/1k-steps  pi_iters  KL      V-loss    rollout_ms  update_s')
     for epoch in range(args.epochs):
         noise = torch.randn((T, n, 7), device=dev)
         torch.cuda.synchronize()
@@ -68,11 +77,12 @@ def main():
             ratio = torch.exp(logp - logp_old[idx])
             a = adv[idx]
             pi_loss = -torch.min(ratio * a, torch.clamp(ratio, 1 - clip, 1 + clip) * a).mean()   # ppo.py:238-240
-            kl = float((logp_old[idx] - logp).mean().detach())
+            kl = float(D.mean_across_ranks((logp_old[idx] - logp).mean().detach()))   # mpi_avg(kl), ppo.py:267
             if kl > 1.5 * target_kl:                                            # ppo.py:267-270
                 break
             pi_opt.zero_grad()
             pi_loss.backward()
+            D.average_gradients(pi_params)                                     # mpi_tf.py:59-62 (no-op on one rank)
             pi_opt.step()
             pi_iters += 1
         for i in range(80):                                                     # ppo.py:272-273
@@ -81,6 +91,7 @@ def main():
             v_loss = ((ret[idx] - v) ** 2).mean()                               # ppo.py:241
             v_opt.zero_grad()
             v_loss.backward()
+            D.average_gradients(v_params)
             v_opt.step()
         with torch.no_grad():
             ac.log_std.clamp_(-4.0, 1.0)
@@ -88,10 +99,14 @@ def main():
         torch.cuda.synchronize()
         t_upd = time.perf_counter() - t1
         done = blk['done']
-        print('%5d  %10.3f  %22.2f  %8d  %.4f  %8.1f  %9.1f  %8.2f' % (
-            epoch, float(blk['rew'].mean()), 1000.0 * float((done & 1).float().mean()), pi_iters, kl, float(v_loss.detach()),
-            t_roll * 1e3, t_upd))
-    print('env-steps collected: %d (%.1f M per epoch)' % (args.epochs * T * n, T * n / 1e6))
+        if rank == 0:
+            print('%5d  %10.3f  %22.2f  %8d  %.4f  %8.1f  %9.1f  %8.2f' % (
+                epoch, float(blk['rew'].mean()), 1000.0 * float((done & 1).float().mean()), pi_iters, kl,
+                float(v_loss.detach()), t_roll * 1e3, t_upd))
+    if rank == 0:
+        print('env-steps collected: %d (%.1f M per epoch, %d rank(s))' % (args.epochs * T * n * world, T * n * world / 1e6, world))
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -41,3 +41,53 @@ def to_global_env_order(gathered):
     """[world, T, n_local, F] -> [T, world * n_local, F]: env axis in global id order."""
     w, T, n, F = gathered.shape
     return gathered.permute(1, 0, 2, 3).reshape(T, w * n, F)
+
+
+def average_gradients(params, group=None):
+    """MpiAdamOptimizer.compute_gradients' all-reduce (spinup/utils/mpi_tf.py:29-62): one flat SUM all-reduce over the
+    concatenated gradients, divided by the rank count.  The whole actor (14 334 floats) or critic (13 841) is a single
+    57 KB bucket, so this is one latency-bound RCCL call per optimiser step."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, group=group)
+    flat /= dist.get_world_size(group)
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+
+
+def sync_params(params, root=0, group=None):
+    """sync_all_params / sync_params (mpi_tf.py:16-26): broadcast the root's parameters, as one flat buffer."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    params = list(params)
+    flat = torch.cat([p.detach().reshape(-1) for p in params])
+    dist.broadcast(flat, src=root, group=group)
+    off = 0
+    with torch.no_grad():
+        for p in params:
+            n = p.numel()
+            p.copy_(flat[off:off + n].view_as(p))
+            off += n
+
+
+def mean_across_ranks(x, group=None):
+    """mpi_avg (mpi_tools.py:67-69) for a scalar tensor or float."""
+    import torch
+    import torch.distributed as dist
+    t = x if isinstance(x, torch.Tensor) else torch.tensor(float(x))
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        t = t.clone()
+        dist.all_reduce(t, group=group)
+        t /= dist.get_world_size(group)
+    return t

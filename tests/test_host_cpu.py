@@ -103,8 +103,21 @@ def _gloo_worker(rank, world, port, total, T, q):
     # scalar statistics the way mpi_statistics_scalar does them: two all-reduces
     acc = torch.tensor([block[..., 16].sum(dtype=np.float64), block[..., 16].size], dtype=torch.float64)
     dist.all_reduce(acc)
+    # data-parallel optimiser plumbing (mpi_tf.py:16-62): parameter broadcast, gradient averaging, mpi_avg
+    torch.manual_seed(100 + rank)
+    params = [torch.randn(9, 80, requires_grad=True), torch.randn(80, requires_grad=True), torch.randn(7, requires_grad=True)]
+    D.sync_params(params, root=0)
+    psum = float(sum(p.detach().sum() for p in params))
+    for p in params:
+        p.grad = torch.full_like(p, float(rank + 1))
+    D.average_gradients(params)
+    gmean = float(params[0].grad[0, 0])
+    kl = float(D.mean_across_ranks(torch.tensor(0.01 * (rank + 1))))
+    chk = torch.tensor([psum, gmean, kl], dtype=torch.float64)
+    lst = [torch.zeros(3, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(lst, chk)
     if rank == 0:
-        q.put((full, float(acc[0] / acc[1])))
+        q.put((full, float(acc[0] / acc[1]), [x.tolist() for x in lst]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -119,7 +132,7 @@ def test_two_rank_gloo_gather_matches_single_process_run():
     procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, total, T, q)) for r in range(world)]
     for p in procs:
         p.start()
-    full, mean_rew = q.get(timeout=120)
+    full, mean_rew, dp = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -139,6 +152,8 @@ def test_two_rank_gloo_gather_matches_single_process_run():
     assert np.array_equal(full, ref), 'sharded + gathered rollout must equal the single-process rollout bit for bit'
     assert (ref[..., 17] != 0).sum() >= total        # episodes ended and were re-sampled (Philox keyed by global id)
     assert abs(mean_rew - ref[..., 16].mean(dtype=np.float64)) < 1e-9
+    # after sync_params both ranks hold rank 0's parameters; averaged gradients = (1 + 2) / 2; mpi_avg of (0.01, 0.02)
+    assert dp[0][0] == dp[1][0] and dp[0][1] == dp[1][1] == 1.5 and abs(dp[0][2] - 0.015) < 1e-9 and abs(dp[1][2] - 0.015) < 1e-9
 
 
 def test_current_drift_is_a_stationary_gauss_markov_process():

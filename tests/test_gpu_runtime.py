@@ -132,3 +132,34 @@ def test_argument_checking_is_loud():
     with pytest.raises(ml4ca_amd.DpenvError):
         ml4ca_amd.BatchedRevoltEnv(64, vessel_params=np.zeros(32, np.float32))  # singular mass matrix
     env.step(good)                                                              # and the handle still works
+
+
+def test_soak_262_million_env_steps():
+    """65 536 envs x 4 000 steps of the fused rollout with auto-reset, drifting current and Gaussian actions: no
+    fault bit, nothing non-finite, every observation of a running env inside the termination bounds, episode
+    bookkeeping consistent with the time limit."""
+    torch = torch_()
+    n, chunk, reps = 65536, 100, 40
+    env, _ = H.make_pair('final_cont', n, auto_reset=True, seed=17, current=True, current_drift=True)
+    env.set_current(torch.full((n,), 0.2, device=env.device), torch.full((n,), float(np.deg2rad(135)), device=env.device))
+    env.reset()
+    g = torch.Generator(device=env.device).manual_seed(4)
+    acts = (torch.randn((chunk, n, 7), generator=g, device=env.device) * 0.6065).contiguous()
+    b = torch.tensor(env.real_ss_bounds, device=env.device)
+    n_end = torch.zeros((), dtype=torch.int64, device=env.device)
+    for r in range(reps):
+        obs, rew, done = env.rollout(acts)
+        assert not bool((done & 4).any()), 'fault bit raised'
+        assert bool(torch.isfinite(obs).all()) and bool(torch.isfinite(rew).all())
+        n_end += (done != 0).sum()
+        # rows returned after a finished step are reset observations: inside the sampled box; the others were not terminal
+        assert bool((obs[..., :6].abs() <= b * 1.0001)[done == 0].all())
+        assert float(rew.max()) <= 3.5 + 1e-5
+    st, ctr = env.get_state()
+    ctr = ctr.cpu().numpy()
+    T = chunk * reps
+    assert (ctr[0] < env.max_ep_len).all() and (ctr[0] >= 0).all()
+    assert (ctr[1] >= 1 + T // env.max_ep_len).all()           # at least one reset per time limit
+    assert int(n_end) == int(ctr[1].sum()) - n                  # every finished episode was re-sampled exactly once
+    vc, beta = env.get_current()
+    assert 0.1 < float(vc.mean()) < 0.3 and float(vc.std()) < 0.05

@@ -21,20 +21,26 @@ def shard(total_envs, rank, world):
     return n_local, start
 
 
-def gather_trajectories(block, group=None, out=None):
+def gather_trajectories(block, group=None, out=None, async_op=False):
     """All-gather of equally shaped per-rank trajectory blocks [T, n_local, F] -> [world, T, n_local, F]
-    (rank-major = global env order for contiguous shards).  One collective per episode, nothing per step."""
+    (rank-major = global env order for contiguous shards).  One collective per episode, nothing per step.
+
+    async_op=True returns (out, work): the collective runs on the backend's own stream, so the next rollout can be
+    launched while the previous episode's block is still crossing xGMI (double-buffer ``block``; ``work.wait()``
+    before reading ``out`` or overwriting ``block``)."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return block.unsqueeze(0) if out is None else out.copy_(block.unsqueeze(0))
+        res = block.unsqueeze(0) if out is None else out.copy_(block.unsqueeze(0))
+        return (res, None) if async_op else res
     world = dist.get_world_size(group)
     block = block.contiguous()
     if out is None:
         out = torch.empty((world,) + tuple(block.shape), dtype=block.dtype, device=block.device)
     # concatenated-along-dim-0 view: the form every backend (RCCL and gloo) accepts
-    dist.all_gather_into_tensor(out.view((world * block.shape[0],) + tuple(block.shape[1:])), block, group=group)
-    return out
+    work = dist.all_gather_into_tensor(out.view((world * block.shape[0],) + tuple(block.shape[1:])), block, group=group,
+                                       async_op=async_op)
+    return (out, work) if async_op else out
 
 
 def to_global_env_order(gathered):

@@ -100,6 +100,9 @@ def _gloo_worker(rank, world, port, total, T, q):
         block[t, :, 17] = done
     g = D.gather_trajectories(torch.from_numpy(block))
     full = D.to_global_env_order(g).numpy()
+    g2, work = D.gather_trajectories(torch.from_numpy(block), async_op=True)     # overlappable form
+    work.wait()
+    assert torch.equal(g, g2)
     # scalar statistics the way mpi_statistics_scalar does them: two all-reduces
     acc = torch.tensor([block[..., 16].sum(dtype=np.float64), block[..., 16].size], dtype=torch.float64)
     dist.all_reduce(acc)

@@ -152,6 +152,53 @@ def test_reference_golden_sequences_through_kernel(mode, ext):
         assert np.array_equal(done.cpu().numpy() & 1, d[p + 'done'][:, t])
 
 
+@pytest.mark.parametrize('mode', sorted(H.MODES))
+def test_reference_closed_loop_through_kernel(mode):
+    """tests/golden/closedloop_*.npz: the reference's own env classes stepped around oracle/twin_shim.TwinShim (a plant
+    that moves).  (1) every recorded (pre-step state, action, new_ref) goes through ONE kernel launch with the plant
+    live - obs, reward, done and the post-step pose/velocity must be the reference's at the fp32 tolerance;
+    (2) free-running from the recorded reset for 25 steps stays within a loose trajectory tolerance (fp32 vs float64
+    on a directionally unstable hull)."""
+    torch = torch_()
+    d = np.load(os.path.join(G, 'closedloop_%s.npz' % mode))
+    ext = mode != 'simple'
+    od = 9 if ext else 6
+    A = d['action'].astype(np.float32)
+    E, T = A.shape[:2]
+    M = E * T
+    env, _ = H.make_pair(mode, M, ext=ext, time_limit=False, vessel_params=d['vessel'].astype(np.float32))
+    flat = lambda k: d[k].reshape(M, -1).T
+    st = np.zeros((O.NSTATE, M), np.float32)
+    st[0:3], st[3:6], st[6:9], st[9:12], st[12:15] = flat('eta'), flat('nu'), flat('ref'), flat('prev_thrust'), flat('angles')
+    use = d['use_new_ref'].reshape(M).astype(bool)
+    nr = np.where(use[:, None], d['new_ref'].reshape(M, 3), d['ref'].reshape(M, 3)).T.astype(np.float32)
+    env.set_state(H.to_dev(st), H.to_dev(np.zeros((2, M), np.int32)))
+    obs, rew, done, _ = env.step(H.to_dev(A.reshape(M, -1)), new_ref=H.to_dev(nr))
+    st2, _ = env.get_state()
+    st2 = st2.cpu().numpy()
+    floor = TOL.OBS_FLOOR[:od].copy()
+    floor[0:2], floor[2] = 16.0, 13.0          # positions O(10 m) rotate into the body-frame error; |psi| up to 13 rad
+    TOL.assert_close(obs.cpu().numpy(), d['obs'].reshape(M, od), floor, what='obs vs reference')
+    TOL.assert_close(rew.cpu().numpy(), d['reward'].reshape(M), 2.0 * TOL.REWARD_FLOOR, what='reward vs reference')
+    TOL.assert_close(st2[0:3].T, d['eta_after'].reshape(M, 3), np.array([16.0, 16.0, 13.0]), what='eta after')
+    TOL.assert_close(st2[3:6].T, d['nu_after'].reshape(M, 3), np.array([1.0, 0.3, 0.5]), what='nu after')
+    assert ((done.cpu().numpy() & 1) != d['done'].reshape(M)).sum() <= 2      # only within rounding of a bound
+    nxt = np.where(use[:, None], d['new_ref'].reshape(M, 3), d['ref'].reshape(M, 3))
+    assert np.array_equal(st2[6:9].T, nxt.astype(np.float32))                   # late setpoint stored for the next step
+
+    # (2) free run from the reference's reset
+    env2, _ = H.make_pair(mode, E, ext=ext, time_limit=False, vessel_params=d['vessel'].astype(np.float32))
+    init = np.concatenate([d['init_eta'].T, d['init_nu'].T], 0).astype(np.float32)
+    obs0 = env2.reset(init=H.to_dev(init), new_ref=H.to_dev(np.zeros((3, E), np.float32)))
+    TOL.assert_close(obs0.cpu().numpy(), d['obs0'], TOL.OBS_FLOOR[:od], what='reset obs vs reference')
+    for t in range(25):
+        u = d['use_new_ref'][:, t].astype(bool)
+        r = np.where(u[:, None], d['new_ref'][:, t], d['ref'][:, t]).T.astype(np.float32)
+        o, rw, dn, _ = env2.step(H.to_dev(A[:, t]), new_ref=H.to_dev(r))
+        assert np.abs(o.cpu().numpy() - d['obs'][:, t]).max() < 2e-3, t
+        assert np.abs(rw.cpu().numpy() - d['reward'][:, t]).max() < 2e-3, t
+
+
 def test_force_map_vs_reference_fixture():
     """SupervisedTau.py:42-83 golden (2016 constants, asymmetric bow thruster)."""
     import ml4ca_amd

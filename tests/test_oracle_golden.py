@@ -236,3 +236,75 @@ def test_philox_known_answers():
     assert O.philox([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     assert O.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def _closedloop_oracle(mode, dt, d):
+    variant, cont = O.MODES[mode]
+    ext = 0 if mode == 'simple' else 1
+    return O.Oracle(O.make_config(variant=variant, extended_state=ext, cont_ang=cont), dt, vessel=d['vessel'].astype(dt)), ext
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_closed_loop_reference_env_free_running(mode):
+    """The reference's env classes stepped around oracle/twin_shim.TwinShim (tests/golden/gen_closedloop.py): 6 episodes
+    x 160 steps per variant - training and testing resets, noise / random-walk / hard-over action scripts, late
+    setpoints.  The float64 oracle, started from the same reset and fed the same actions, must reproduce the
+    reference's observation, reward and termination at EVERY step without re-synchronisation: this pins the whole
+    composition of customEnv.py:92-194 (command writes, 20 sub-steps, three plant reads, previous-thrust lag, late
+    new_ref) around a plant that moves."""
+    d = load('closedloop_' + mode)
+    orc, ext = _closedloop_oracle(mode, np.float64, d)
+    od = 9 if ext else 6
+    A = d['action']
+    E, T = A.shape[:2]
+    assert set(d['reset_substeps'].tolist()) == {50}             # customEnv.py:166: 50 held sub-steps per reset
+    state, ctr = orc.new_state(E)
+    obs0 = orc.reset(state, ctr, init=np.concatenate([d['init_eta'].T, d['init_nu'].T], 0), ref=np.zeros((3, E)))
+    assert np.allclose(obs0, d['obs0'], rtol=0, atol=1e-10)
+    worst = 0.0
+    for t in range(T):
+        # bookkeeping before the step is the reference env's own
+        assert np.allclose(state[0:3].T, d['eta'][:, t], rtol=0, atol=1e-8), t
+        assert np.allclose(state[3:6].T, d['nu'][:, t], rtol=0, atol=1e-8), t
+        assert np.allclose(state[O.S['PT_BOW']:O.S['PT_BOW'] + 3].T, d['prev_thrust'][:, t], rtol=0, atol=1e-10), t
+        assert np.allclose(state[O.S['A_BOW']:O.S['A_BOW'] + 3].T, d['angles'][:, t], rtol=0, atol=1e-10), t
+        assert np.allclose(state[O.S['REF_N']:O.S['REF_N'] + 3].T, d['ref'][:, t], rtol=0, atol=1e-12), t
+        use = d['use_new_ref'][:, t].astype(bool)
+        nr = np.where(use[:, None], d['new_ref'][:, t], d['ref'][:, t]).T
+        obs, rew, done = orc.step(state, ctr, A[:, t], new_ref=nr)
+        worst = max(worst, np.abs(obs - d['obs'][:, t]).max(), np.abs(rew - d['reward'][:, t]).max())
+        assert np.allclose(obs, d['obs'][:, t], rtol=0, atol=TOL.ATOL_F64), 'obs t=%d err %g' % (t, np.abs(obs - d['obs'][:, t]).max())
+        assert np.allclose(rew, d['reward'][:, t], rtol=0, atol=TOL.ATOL_F64), 'reward t=%d' % t
+        assert np.array_equal(done & 1, d['done'][:, t]), 'done t=%d' % t
+    assert d['done'].any() and not d['done'].all()
+    assert d['use_new_ref'].sum() >= 4
+    assert worst < 1e-13            # measured: 3.6e-15 (one ulp at the metre scale)
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_closed_loop_reference_env_single_steps_f32(mode):
+    """Same fixtures, one step at a time from the recorded pre-step state (the float32 build cannot free-run against a
+    float64 trajectory for 160 steps on a directionally unstable hull): 960 (state, action) pairs per variant."""
+    d = load('closedloop_' + mode)
+    orc, ext = _closedloop_oracle(mode, np.float32, d)
+    od = 9 if ext else 6
+    A = d['action'].reshape(-1, d['action'].shape[-1])
+    M = A.shape[0]
+    state, ctr = orc.new_state(M)
+    flat = lambda k: d[k].reshape(M, -1).T
+    state[0:3], state[3:6] = flat('eta'), flat('nu')
+    state[O.S['REF_N']:O.S['REF_N'] + 3] = flat('ref')
+    state[O.S['PT_BOW']:O.S['PT_BOW'] + 3] = flat('prev_thrust')
+    state[O.S['A_BOW']:O.S['A_BOW'] + 3] = flat('angles')
+    obs, rew, done = orc.step(state, ctr, A)
+    # positions are O(10 m) here and enter the body-frame error through a rotation: floor at that scale
+    floor = TOL.OBS_FLOOR[:od].copy()
+    floor[0:2] = 16.0
+    floor[2] = 13.0                                    # heading error = psi - ref with |psi| up to 13 rad
+    TOL.assert_close(obs, d['obs'].reshape(M, od), floor, what='obs')
+    TOL.assert_close(state[0:3].T, d['eta_after'].reshape(M, 3), np.array([16.0, 16.0, 13.0]), what='eta after')
+    TOL.assert_close(state[3:6].T, d['nu_after'].reshape(M, 3), np.array([1.0, 0.3, 0.5]), what='nu after')
+    TOL.assert_close(rew, d['reward'].reshape(M), 2.0 * TOL.REWARD_FLOOR, what='reward')
+    # termination can only differ within rounding distance of a bound
+    dd = (done & 1) != d['done'].reshape(M)
+    assert dd.sum() <= 2

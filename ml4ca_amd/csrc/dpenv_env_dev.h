@@ -434,6 +434,7 @@ __device__ __forceinline__ void env_step(const StepArgs& a, const Vessel& ve, En
     const float yur = ve.Yur + ve.m11;      // fy gets -(Yr + (Yur + m11) u) r
     const float nuv = ve.Nuv - ve.m11;      // fn gets -(Nv + (Nuv - m11) u) v
     const int nsub = a.hold_plant ? 0 : a.n_substeps;
+    float aN = 0.0f, aE = 0.0f;
     // unrolled x10 (20 sub-steps = 2 trips): the loop counter / compare / branch are SALU issue slots of the same lone wave
 #pragma unroll 10
     for (int k = 0; k < nsub; ++k) {
@@ -449,17 +450,26 @@ __device__ __forceinline__ void env_step(const StepArgs& a, const Vessel& ve, En
         u = fmaf(hA, fx, u);
         v = fmaf(h22, fy, fmaf(h23, fn, v));
         r = fmaf(h23, fy, fmaf(h33, fn, r));
-        // kinematics with the old heading and the new velocity
-        N = fmaf(h, fmaf(-sn, v, fmaf(cs, u, vcN)), N);
-        E = fmaf(h, fmaf(cs, v, fmaf(sn, u, vcE)), E);
+        // kinematics with the old heading and the new velocity: the NED velocity over water is summed here and the
+        // position advanced once after the loop (h * sum: one rounding of N, E per env step instead of twenty)
+        aN = fmaf(-sn, v, fmaf(cs, u, aN));
+        aE = fmaf(cs, v, fmaf(sn, u, aE));
         // heading: psi += d, d = h r; its sin/cos by the rotation (1 - d^2/2, d), i.e. exact to second order - one
-        // order above the integrator's own - and re-seeded from the exact sin/cos of psi at every env step
+        // order above the integrator's own - and re-seeded from the exact sin/cos of psi at every env step.
+        // cs' = cs - sn d - cs d^2/2 and sn' = sn + cs d - sn d^2/2 in Horner form
         const float d = h * r;
-        const float cd = fmaf(-0.5f * d, d, 1.0f);
+        const float e = -0.5f * d;
         psi += d;
-        const float c2 = fmaf(cs, cd, -(sn * d));
-        const float s2n = fmaf(sn, cd, cs * d);
+        const float c2 = fmaf(fmaf(e, cs, -sn), d, cs);
+        const float s2n = fmaf(fmaf(e, sn, cs), d, sn);
         cs = c2; sn = s2n;
+    }
+    N = fmaf(h, aN, N);
+    E = fmaf(h, aE, E);
+    if (cur) {
+        const float hn = h * (float)nsub;       // the current carries the hull along for the whole step
+        N = fmaf(hn, vcN, N);
+        E = fmaf(hn, vcE, E);
     }
     // exact sin/cos of the heading reached: needed by the observation, by the current term and by the next step
     const bool deg = (a.wrap_mode == WRAP_REFERENCE);

@@ -111,7 +111,7 @@ extern "C" int dpenv_default_vessel(float* p)
 {
     if (!p) return DPENV_EINVAL;
     for (int i = 0; i < DPENV_NPARAM; ++i) p[i] = 0.0f;
-    // fitted to the reference's recorded Cybersea runs by tools/calibrate_plant.py
+    // fitted to the reference's recorded Cybersea runs by tests/calibration/calibrate_plant.py
     p[DPENV_P_M11] = 263.93f; p[DPENV_P_M22] = 300.9f; p[DPENV_P_M23] = 7.0f; p[DPENV_P_M33] = 300.0f;
     p[DPENV_P_XU] = 3.0f;  p[DPENV_P_XUU] = 7.1f;
     p[DPENV_P_YV] = 19.8f; p[DPENV_P_YVV] = 80.3f;

@@ -63,7 +63,7 @@ int FN(dpo_obs_dim)(const dpo_config* c) { return c->extended_state ? 9 : 6; } /
 void FN(dpo_default_vessel)(REAL* p)
 {
     for (int i = 0; i < DPO_NPARAM; ++i) p[i] = R(0);
-    /* fitted to the reference's recorded Cybersea runs by tools/calibrate_plant.py */
+    /* fitted to the reference's recorded Cybersea runs by tests/calibration/calibrate_plant.py */
     p[DPO_P_M11] = R(263.93); p[DPO_P_M22] = R(300.9); p[DPO_P_M23] = R(7.0); p[DPO_P_M33] = R(300.0);
     p[DPO_P_XU] = R(3.0);  p[DPO_P_XUU] = R(7.1);
     p[DPO_P_YV] = R(19.8); p[DPO_P_YVV] = R(80.3);

@@ -311,6 +311,35 @@ def test_plant_tracks_the_recorded_cybersea_box_run():
     assert np.abs(dev[:, :2]).max() < 1.5
 
 
+def test_recorded_cybersea_commands_open_loop_through_kernel():
+    """tests/golden/cybersea_replay.npz: 392 ten-second windows of seven recorded Cybersea runs, the recorded thruster
+    commands applied open loop (one env per window, the fused rollout kernel, constant 0.2 m/s current where the run
+    had one).  The kernel's predicted poses must agree with the float64 oracle's replay (fp32 over 50 steps) and
+    reproduce its error statistics against the record (soft validation of the BUILD-OWNED plant)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'calibration'))
+    import replay_cybersea as RC
+    torch = torch_()
+    W = RC.load_windows()
+    n, T = W['eta0'].shape[0], W['act'].shape[0]
+    env, _ = H.make_pair('final_cont', n, terminate=False, time_limit=False, current=True)
+    env.set_current(H.to_dev(W['current'][0].astype(np.float32)), H.to_dev(W['current'][1].astype(np.float32)))
+    env.reset(init=H.to_dev(np.concatenate([W['eta0'].T, W['nu0'].T], 0).astype(np.float32)),
+              new_ref=H.to_dev(np.zeros((3, n), np.float32)))
+    pred = np.zeros((T, n, 3))
+    for t in range(T):
+        env.step(H.to_dev(W['act'][t].astype(np.float32)))
+        st, _ = env.get_state()
+        pred[t] = st[0:3].T.cpu().numpy()
+    ref = RC.replay_oracle(W)
+    assert np.abs(pred[..., :2] - ref[..., :2]).max() < 2e-3 and np.abs(pred[..., 2] - ref[..., 2]).max() < 2e-3
+    e, eo = RC.errors(pred, W), RC.errors(ref, W)
+    for h in RC.HORIZONS:
+        assert abs(e[h][0] - eo[h][0]) < 1e-3 and abs(e[h][1] - eo[h][1]) < 0.05, (h, e[h], eo[h])
+    assert e[50][0] < 0.65 and e[50][1] < 17.0
+
+
 def test_run_RL_policy_harness_with_the_trained_actor():
     """test_policy.py:97-186 semantics, batched: six fixed starts on the 5 m circle, deterministic trained actor,
     optional setpoint change at half time through a zero-action step."""

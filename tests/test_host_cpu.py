@@ -228,7 +228,7 @@ def test_qp_allocator_restatement_matches_reference_fixture():
 
 
 def test_default_hull_soft_pins_and_free_drift_record():
-    """The BUILD-OWNED default hull (calibrated by tools/calibrate_plant.py; no parity claim) against what the reference
+    """The BUILD-OWNED default hull (calibrated by tests/calibration/calibrate_plant.py; no parity claim) against what the reference
     records about its plant: steady full-thrust speeds (customEnv.py:13-14: +2.20 m/s, 0.60 rad/s) and the free-drift
     run in a 0.2 m/s / 135 deg current (results/all_plots/stationKeep135, fixture cybersea_free_drift.npz), incl. the
     swing towards broadside that the Munk moment produces."""
@@ -256,3 +256,28 @@ def test_default_hull_soft_pins_and_free_drift_record():
     assert np.sqrt((err[:, :2] ** 2).sum(1).mean()) < 0.6          # measured 0.36 m over 60 s
     assert np.degrees(np.sqrt((err[:, 2] ** 2).mean())) < 12.0       # measured 8.1 deg
     assert np.degrees(np.array(traj)[:, 2].max()) > 30.0             # the hull does swing towards broadside (record: 49 deg)
+
+
+def test_default_hull_open_loop_against_recorded_cybersea_commands():
+    """Soft validation of the BUILD-OWNED plant (no parity claim): seven recorded Cybersea runs with the thruster commands
+    that produced them (tests/golden/cybersea_replay.npz from results/all_plots/{box_test,large_setpoints,
+    current_box_test}, tools/gen_golden.py replay).  392 windows of 10 s start from the recorded pose and are driven
+    OPEN LOOP by the recorded commands: the prediction must beat the no-model predictors (stay put, constant velocity)
+    at every horizon and stay inside the error band measured when the default hull was fixed."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'calibration'))
+    import replay_cybersea as RC
+    W = RC.load_windows()
+    assert W['eta0'].shape[0] == 392 and len(W['names']) == 7
+    pred = RC.replay_oracle(W)
+    assert np.isfinite(pred).all()
+    e = RC.errors(pred, W)
+    cv = RC.errors(RC.constant_velocity(W), W)
+    still = RC.errors(np.repeat(W['eta0'][None], W['truth'].shape[0], 0), W)
+    band = {10: (0.07, 2.2), 25: (0.26, 7.5), 50: (0.65, 17.0)}        # measured 0.05/1.7, 0.21/6.6, 0.57/15.4
+    for h in RC.HORIZONS:
+        assert e[h][0] < band[h][0] and e[h][1] < band[h][1], (h, e[h])
+        assert e[h][0] < 0.7 * cv[h][0] and e[h][1] < 0.7 * cv[h][1], (h, e[h], cv[h])
+        assert e[h][0] < 0.35 * still[h][0] and e[h][1] < 0.8 * still[h][1], (h, e[h], still[h])
+    # the current run is predicted as well as the calm-water one: the relative-velocity current model is in the right place
+    sel = W['run'] == W['names'].index('current_box_test_QP')
+    assert RC.errors(pred, W, sel)[50][0] < 0.5

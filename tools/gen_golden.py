@@ -520,6 +520,49 @@ def gen_cybersea_box():
     print('wrote cybersea_free_drift.npz (%d samples at 5 Hz)' % Tf)
 
 
+def gen_cybersea_replay():
+    """Recorded Cybersea runs WITH the thruster commands that produced them (results/all_plots/{box_test,large_setpoints,
+    current_box_test}/bagfile__<allocator>_{observer_eta_ned, bow_control, thrusterAllocation_pod_angle_input,
+    thrusterAllocation_stern_thruster_setpoints}.csv; units: percent thrust and degrees, utils.py:88-115 of the
+    rl_allocator node): pose, a body-velocity estimate (central difference of the 20 Hz pose over +-0.25 s) and the
+    command in force, on the env's 0.2 s grid.  Lets the build-owned plant be driven OPEN LOOP by the commands Cybersea
+    received - a plant check no feedback loop can mask (tests/test_host_cpu.py, tests/calibration/replay_cybersea.py)."""
+    runs = [('box_test', 'QP', None), ('box_test', 'pseudo', None), ('box_test', 'RL', None),
+            ('large_setpoints', 'QP', None), ('large_setpoints', 'RL', None),
+            ('current_box_test', 'QP', (0.2, np.radians(135.0))), ('current_box_test', 'RL', (0.2, np.radians(135.0)))]
+    out = {}
+    names = []
+    for d, m, cur in runs:
+        p = os.path.join(REF, 'results/all_plots', d, 'bagfile__%s_' % m)
+        g = lambda s: np.genfromtxt(p + s, delimiter=',', skip_header=1)
+        st, an = g('thrusterAllocation_stern_thruster_setpoints.csv'), g('thrusterAllocation_pod_angle_input.csv')
+        bw, eta = g('bow_control.csv'), g('observer_eta_ned.csv')
+        t0 = eta[0, 0]
+        te = (eta[:, 0] - t0) * 1e-9
+        pose = np.stack([eta[:, 1] - eta[0, 1], eta[:, 2] - eta[0, 2], np.unwrap(np.radians(eta[:, 6]))], 1)
+        tq = np.arange(0.0, te[-1] - 0.3, 0.2)
+
+        def zoh(t, x):
+            i = np.clip(np.searchsorted(t, tq, side='right') - 1, 0, len(t) - 1)
+            return x[i]
+
+        ts, ta, tb = (st[:, 0] - t0) * 1e-9, (an[:, 0] - t0) * 1e-9, (bw[:, 0] - t0) * 1e-9
+        pq = np.stack([np.interp(tq, te, pose[:, k]) for k in range(3)], 1)
+        dq = np.stack([(np.interp(tq + 0.25, te, pose[:, k]) - np.interp(tq - 0.25, te, pose[:, k])) / 0.5 for k in range(3)], 1)
+        c, s = np.cos(pq[:, 2]), np.sin(pq[:, 2])
+        nu = np.stack([c * dq[:, 0] + s * dq[:, 1], -s * dq[:, 0] + c * dq[:, 1], dq[:, 2]], 1)
+        n = np.stack([zoh(tb, bw[:, 1]), zoh(ts, st[:, 2]), zoh(ts, st[:, 1])], 1)        # bow, port, star  [%]
+        a = np.stack([np.radians(zoh(tb, bw[:, 2])), np.radians(zoh(ta, an[:, 1])), np.radians(zoh(ta, an[:, 2]))], 1)
+        key = '%s_%s' % (d, m)
+        names.append(key)
+        out[key + '_pose'], out[key + '_nu'] = pq.astype(np.float32), nu.astype(np.float32)
+        out[key + '_n'], out[key + '_a'] = n.astype(np.float32), a.astype(np.float32)
+        out[key + '_current'] = np.array(cur if cur is not None else (0.0, 0.0))
+    out['runs'] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, 'cybersea_replay.npz'), **out)
+    print('wrote cybersea_replay.npz:', ', '.join('%s (%d)' % (k, out[k + '_pose'].shape[0]) for k in names))
+
+
 def gen_qp():
     """src/qp/ROS/qp_allocator/src/qp_allocator.py (QPTA.solve_QP :108-234, tau_controller_callback_func :247-320)
     behind stubs for rospy / custom_msgs / geometry_msgs: a sequence of desired wrenches through the SLSQP allocator,
@@ -614,11 +657,11 @@ def main():
         if what in MODES:
             gen_mode(what)
         else:
-            {'errorframe': gen_errorframe, 'gae': gen_gae, 'forcemap': gen_forcemap, 'policy': gen_policy, 'cybersea': gen_cybersea_box, 'qp': gen_qp}[what]()
+            {'errorframe': gen_errorframe, 'gae': gen_gae, 'forcemap': gen_forcemap, 'policy': gen_policy, 'cybersea': gen_cybersea_box, 'replay': gen_cybersea_replay, 'qp': gen_qp}[what]()
         return
     assert os.path.isdir(REF), 'reference tree not present: fixtures can only be regenerated in the build container'
     os.makedirs(OUT, exist_ok=True)
-    for what in list(MODES) + ['errorframe', 'gae', 'forcemap', 'policy', 'cybersea', 'qp']:
+    for what in list(MODES) + ['errorframe', 'gae', 'forcemap', 'policy', 'cybersea', 'replay', 'qp']:
         subprocess.check_call([sys.executable, '-B', os.path.abspath(__file__), what])
     # the reference tree must stay pristine
     for root, dirs, files in os.walk(REF):

@@ -6,6 +6,8 @@ import os
 import numpy as np
 import pytest
 
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FIX = os.path.join(ROOT, 'tests', 'golden', 'final_policy.npz')
 REF_CKPT = '/root/reference/src/rl/windows_workspace/data/finalmodel/finconttothighbowder_s0/tf1_save/variables/variables'
@@ -86,3 +88,62 @@ def test_evaluation_metrics():
     assert steps == (50, 300, 550, 700, 950) and refs.shape == (5, 3, 2)
     assert np.allclose(refs[2, :, 0].numpy(), [5.0, -5.0, -np.pi / 4])
     assert np.allclose(EV.commanded_thrust(torch.tensor([[[2.0, -0.5, 0.1]]])).numpy(), [[[100.0, -50.0, 10.0]]])
+
+
+@pytest.mark.parametrize('kind', ['plain', 'integral'])
+def test_ros_node_adapter_against_the_imported_node(kind):
+    """src/rl/ROS/rl_allocator/src/rl_allocator.py run behind ROS stubs (tools/gen_golden.py rosnode[_integral]) with the
+    trained actor: 420 callback rounds - approach, dwell near the setpoint (the integral action winds up to its
+    bounds), a kick outside the 5 m box (reset), a setpoint change.  ml4ca_amd.deploy.RLAllocatorNode must reproduce
+    the node's state vector, its command vector in ROS order, the integrator and every published message field."""
+    from ml4ca_amd import deploy as DP
+    d = np.load(os.path.join(G, 'ros_rl_node_%s.npz' % kind))
+    pol = np.load(os.path.join(G, 'final_policy.npz'))
+    Wb = [(pol['pi.dense%s.kernel' % k].astype(np.float64), pol['pi.dense%s.bias' % k].astype(np.float64)) for k in ('', '_1', '_2', '_3')]
+
+    def actor(x):
+        for i, (w, b) in enumerate(Wb):
+            x = x @ w + b
+            if i < 3:
+                x = np.where(x > 0, x, 0.2 * x)
+        return x
+
+    node = DP.RLAllocatorNode(actor, variant='final', cont_ang=True, integrator=(kind == 'integral'), simulation=True,
+                              now=float(d['t0'][0]))
+    T = d['pose'].shape[0]
+    for k in range(T):
+        now = float(d['t'][k])
+        node.on_eta(d['pose'][k, 0], d['pose'][k, 1], d['pose'][k, 2], now)
+        node.on_nu(*d['nu'][k])
+        u, msg = node.on_reference(d['ref'][k, 0], d['ref'][k, 1], d['ref'][k, 2], now)
+        assert abs(node.h - d['h'][k]) < 1e-9
+        assert np.allclose(node.state, d['state'][k], rtol=0, atol=1e-9), (k, np.abs(node.state - d['state'][k]).max())
+        assert np.allclose(u, d['u'][k], rtol=0, atol=1e-9), k
+        if node.integrator is not None:
+            assert np.allclose(node.integrator.value, d['integ'][k], rtol=0, atol=1e-12), k
+        assert np.allclose([msg['pod_angle.port'], msg['pod_angle.star']], d['pod'][k], rtol=0, atol=1e-9)
+        assert np.allclose([msg['stern.port_effort'], msg['stern.star_effort']], d['stern'][k], rtol=0, atol=1e-9)
+        assert np.allclose([msg['bow.throttle_bow'], msg['bow.position_bow'], msg['bow.lin_act_bow']], d['bow'][k], rtol=0, atol=1e-9)
+    if kind == 'integral':
+        assert np.allclose(np.abs(d['integ']).max(0), DP.BodyFrameIntegrator.BOUND)      # wound up to every bound
+        assert (np.abs(d['integ'][262:300]).max() == 0.0)                                 # and reset by the kick
+    else:
+        assert np.abs(d['integ']).max() == 0.0
+
+
+def test_ros_order_maps_and_hardware_bow_mapping():
+    from ml4ca_amd import deploy as DP
+    # limited: 5 outputs, stern angles scale to +-pi/2, bow fixed at pi/2 (rl_allocator.py:92-106)
+    u = DP.to_ros_order(np.array([0.5, -0.25, 2.0, 1.0, -0.5]), 'limited', cont_ang=False)
+    assert np.allclose(u, [-25.0, 100.0, 50.0, np.pi / 2, -np.pi / 4, np.pi / 2])
+    # full: 6 outputs, a_bow is the network's 4th output
+    u = DP.to_ros_order(np.array([0.1, 0.2, 0.3, 0.5, -0.5, 0.25]), 'full', cont_ang=False)
+    assert np.allclose(u, [20.0, 30.0, 10.0, -np.pi / 2, np.pi / 4, np.pi / 2])
+    # batched input keeps its leading shape
+    assert DP.to_ros_order(np.zeros((4, 3, 7)), 'final', True).shape == (4, 3, 6)
+    # on the vessel the bow thruster gets 2.5x the command, clipped, at a fixed 45 % position (utils.py:112-113)
+    m = DP.publishable(np.array([10.0, -10.0, 60.0, 0.1, -0.1, np.pi / 2]), simulation=False)
+    assert m['bow.throttle_bow'] == 100.0 and m['bow.position_bow'] == 45
+    assert abs(DP.shortest_path(np.radians(170), np.radians(-170)) - np.radians(20)) < 1e-12
+    with pytest.raises(ValueError):
+        DP.RLAllocatorNode(lambda s: s, variant='simple')

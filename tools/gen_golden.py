@@ -651,17 +651,120 @@ def gen_qp():
     print('wrote qp_allocator.npz (%d wrenches, %d successes)' % (len(taus), sum(succ)))
 
 
+def gen_rosnode(integrator):
+    """src/rl/ROS/rl_allocator/src/rl_allocator.py (RLTA callbacks :168-220, get_action :228-250, integral action
+    :252-273) and utils.py:88-115 behind stubs for rospy / std_msgs / custom_msgs / geometry_msgs / tensorflow, with the
+    trained actor evaluated in NumPy from tests/golden/final_policy.npz in place of the TF session.  A scripted pose
+    series (approach, dwell near the setpoint, jump away) drives the callbacks; the state vector, the command vector in
+    ROS order, the published message fields and the integrator are recorded.  One interpreter per INTEGRATOR flag."""
+    class _Any(object):
+        def __init__(self, *a, **k):
+            pass
+
+        def __getattr__(self, k):
+            return _Any()
+
+        def __call__(self, *a, **k):
+            return _Any()
+
+    published = []
+
+    class Pub(object):
+        def __init__(self, topic, *a, **k):
+            self.topic = topic
+
+        def publish(self, msg):
+            published.append((self.topic, dict(msg.__dict__)))
+
+    class Msg(object):
+        def __init__(self, **k):
+            self.__dict__.update(k)
+
+    clock = [100.0]
+    rospy = types.ModuleType('rospy')
+    rospy.init_node = lambda *a, **k: None
+    rospy.Rate = _Any
+    rospy.Publisher = Pub
+    rospy.Subscriber = _Any
+    rospy.get_time = lambda: clock[0]
+    rospy.loginfo = rospy.logerr = rospy.logwarn = lambda *a, **k: None
+    mods = {'rospy': rospy}
+    for name, classes in (('std_msgs', ('Float64',)), ('geometry_msgs', ('Wrench', 'Twist', 'Pose2D')),
+                          ('custom_msgs', ('podAngle', 'SternThrusterSetpoints', 'bowControl', 'NorthEastHeading', 'diffThrottleStern'))):
+        m, mm = types.ModuleType(name), types.ModuleType(name + '.msg')
+        for c in classes:
+            setattr(mm, c, type(c, (Msg,), {}))
+        m.msg = mm
+        mods[name], mods[name + '.msg'] = m, mm
+    mods['tensorflow'] = types.ModuleType('tensorflow')
+    sys.modules.update(mods)
+    sys.path.insert(0, os.path.join(REF, 'src/rl/ROS/rl_allocator/src'))
+    import rl_allocator as RA
+    faketime = types.ModuleType('time')
+    faketime.time = lambda: clock[0]
+    RA.time = faketime                      # the integrator's dwell timer reads time.time() (:258,261)
+    RA.SIMULATION, RA.INTEGRATOR = True, bool(integrator)
+    pol = np.load(os.path.join(OUT, 'final_policy.npz'))
+    Wb = [(pol['pi.dense%s.kernel' % k].astype(np.float64), pol['pi.dense%s.bias' % k].astype(np.float64)) for k in ('', '_1', '_2', '_3')]
+
+    def actor(x):
+        for i, (w, b) in enumerate(Wb):
+            x = x @ w + b
+            if i < 3:
+                x = np.where(x > 0, x, 0.2 * x)
+        return x
+
+    RA.load_policy = lambda fpath=None, num_hidden_layers=None: actor
+    import builtins
+    real_print = builtins.print
+    builtins.print = lambda *a, **k: None   # get_error_states prints every call
+    try:
+        node = RA.RLTA()
+        T = 420
+        t = np.arange(T) * 0.2
+        # approach (7 m, -6 m, 150 deg) -> dwell at a standing offset -> kicked outside the 5 m box -> back
+        off = np.array([1.5, -3.0, 10.0])
+        pose = off[None] + np.array([5.5, -3.0, 140.0])[None] * np.exp(-t / 4.0)[:, None]
+        pose[260:300] += np.array([6.0, 0.0, 0.0])
+        pose += np.array([100.0, 50.0, 0.0])
+        ref = np.tile(np.array([100.0, 50.0, 0.0]), (T, 1))
+        ref[330:] += np.array([0.5, 0.5, -20.0])
+        nu = np.gradient(pose, 0.2, axis=0) * np.array([1.0, 1.0, np.pi / 180.0])
+        rec = dict(pose=pose, ref=ref, nu=nu, t=np.zeros(T), state=np.zeros((T, 9)), u=np.zeros((T, 6)),
+                   integ=np.zeros((T, 3)), pod=np.zeros((T, 2)), stern=np.zeros((T, 2)), bow=np.zeros((T, 3)), h=np.zeros(T))
+        for k in range(T):
+            clock[0] = 100.0 + 0.2 * k + (0.013 if k % 7 == 3 else 0.0)      # a little callback jitter
+            rec['t'][k] = clock[0]
+            node.eta_obs_callback(Msg(linear=Msg(x=pose[k, 0], y=pose[k, 1], z=0.0), angular=Msg(x=0.0, y=0.0, z=pose[k, 2])))
+            node.nu_obs_callback(Msg(linear=Msg(x=nu[k, 0], y=nu[k, 1], z=0.0), angular=Msg(x=0.0, y=0.0, z=nu[k, 2])))
+            del published[:]
+            node.state_desired_callback(Msg(pos_north=ref[k, 0], pos_east=ref[k, 1], pos_heading=ref[k, 2],
+                                            vel_north=0.0, vel_east=0.0, vel_heading=0.0))
+            rec['state'][k], rec['u'][k], rec['integ'][k], rec['h'][k] = node.state, node.prev_thrust_state, node.integrator, node.h
+            msgs = dict(published)
+            pa, st, bw = msgs['thrusterAllocation/pod_angle_input'], msgs['thrusterAllocation/stern_thruster_setpoints'], msgs['bow_control']
+            rec['pod'][k] = [pa['port'], pa['star']]
+            rec['stern'][k] = [st['port_effort'], st['star_effort']]
+            rec['bow'][k] = [bw['throttle_bow'], bw['position_bow'], bw['lin_act_bow']]
+    finally:
+        builtins.print = real_print
+    rec['t0'] = np.array([100.0])
+    np.savez_compressed(os.path.join(OUT, 'ros_rl_node_%s.npz' % ('integral' if integrator else 'plain')), **rec)
+    print('wrote ros_rl_node_%s.npz; max |integrator| %s' % ('integral' if integrator else 'plain', np.abs(rec['integ']).max(0)))
+
+
 def main():
     if len(sys.argv) > 1:
         what = sys.argv[1]
         if what in MODES:
             gen_mode(what)
         else:
-            {'errorframe': gen_errorframe, 'gae': gen_gae, 'forcemap': gen_forcemap, 'policy': gen_policy, 'cybersea': gen_cybersea_box, 'replay': gen_cybersea_replay, 'qp': gen_qp}[what]()
+            {'errorframe': gen_errorframe, 'gae': gen_gae, 'forcemap': gen_forcemap, 'policy': gen_policy, 'cybersea': gen_cybersea_box, 'replay': gen_cybersea_replay, 'qp': gen_qp,
+             'rosnode': lambda: gen_rosnode(False), 'rosnode_integral': lambda: gen_rosnode(True)}[what]()
         return
     assert os.path.isdir(REF), 'reference tree not present: fixtures can only be regenerated in the build container'
     os.makedirs(OUT, exist_ok=True)
-    for what in list(MODES) + ['errorframe', 'gae', 'forcemap', 'policy', 'cybersea', 'replay', 'qp']:
+    for what in list(MODES) + ['errorframe', 'gae', 'forcemap', 'policy', 'cybersea', 'replay', 'qp', 'rosnode', 'rosnode_integral']:
         subprocess.check_call([sys.executable, '-B', os.path.abspath(__file__), what])
     # the reference tree must stay pristine
     for root, dirs, files in os.walk(REF):

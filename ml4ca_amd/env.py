@@ -86,7 +86,8 @@ class BatchedRevoltEnv(object):
                  testing=False, realtime=False, max_ep_len=800, auto_reset=False, terminate=True,
                  wrap_mode='reference', seed=0, env_id_base=0, obs_dtype='float32', current=False,
                  vessel_params=None, layout='aos', reset_fraction=0.8, time_limit=True, hold_plant=False,
-                 current_drift=False, current_tau=100.0, current_sigma_v=0.02, current_sigma_beta=5.0 * math.pi / 180.0):
+                 current_drift=False, current_tau=100.0, current_sigma_v=0.02, current_sigma_beta=5.0 * math.pi / 180.0,
+                 n_steps=None):
         torch = _torch()
         if not torch.cuda.is_available():
             raise RuntimeError('BatchedRevoltEnv needs a ROCm device: the env.step path is a HIP kernel and has no CPU fallback')
@@ -108,6 +109,8 @@ class BatchedRevoltEnv(object):
         self.act_2_act_map = k['act_2_act_map']
         self.act_2_act_map_inv = k['act_2_act_map_inv']
         self.n_steps = 1 if (testing and realtime) else 20           # ENV:79-80
+        if n_steps is not None:                                      # any other agent rate: n_steps plant sub-steps of 10 ms
+            self.n_steps = int(n_steps)
         self.dt = 0.01 * self.n_steps                                # ENV:81
         self.max_ep_len = int(max_ep_len * 10.0 / self.n_steps)      # ENV:83
         self.vel_rew_coeffs = [0.5, 0.5, 1.0]                        # ENV:78

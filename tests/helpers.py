@@ -24,8 +24,9 @@ def make_pair(mode, n, ext=True, dtype=np.float32, device='cuda:0', **kw):
         reset_fraction=kw.get('reset_fraction', 0.8), time_limit=kw.get('time_limit', True),
         max_ep_len=kw.get('max_ep_len', 800), hold_plant=kw.get('hold_plant', False),
         current_drift=kw.get('current_drift', False), current_tau=kw.get('current_tau', 100.0),
-        current_sigma_v=kw.get('current_sigma_v', 0.02), current_sigma_beta=kw.get('current_sigma_beta', 5.0 * np.pi / 180.0))
-    cfg = O.make_config(variant=ovar, extended_state=int(ext), cont_ang=ocont,
+        current_sigma_v=kw.get('current_sigma_v', 0.02), current_sigma_beta=kw.get('current_sigma_beta', 5.0 * np.pi / 180.0),
+        n_steps=kw.get('n_steps'), testing=kw.get('testing', False), realtime=kw.get('realtime', False))
+    cfg = O.make_config(variant=ovar, extended_state=int(ext), cont_ang=ocont, n_substeps=env.n_steps,
                         wrap_mode=O.WRAP_RADIANS if kw.get('wrap_mode') == 'radians' else O.WRAP_REFERENCE,
                         terminate=int(kw.get('terminate', True)),
                         max_ep_len=env.max_ep_len if kw.get('time_limit', True) else 0,

@@ -199,6 +199,34 @@ def test_reference_closed_loop_through_kernel(mode):
         assert np.abs(rw.cpu().numpy() - d['reward'][:, t]).max() < 2e-3, t
 
 
+@pytest.mark.parametrize('n_steps', [1, 3, 7, 10, 13, 25, 40])
+def test_other_agent_rates_match_oracle(n_steps):
+    """ENV:79-83: n_steps plant sub-steps of 10 ms per env step (20 in training, 1 with testing + realtime).  The
+    kernel's sub-step loop is unrolled by ten with a remainder loop: every count must match the oracle, including
+    the rate-dependent reward terms (action derivatives over dt = 0.01 n_steps) and the episode length 8000 / n_steps."""
+    torch = torch_()
+    n = 300
+    env, orc = H.make_pair('final_cont', n, n_steps=n_steps)
+    assert env.n_steps == n_steps and abs(env.dt - 0.01 * n_steps) < 1e-12 and env.max_ep_len == int(8000 / n_steps)
+    rng = np.random.RandomState(70 + n_steps)
+    st = H.random_state(rng, n, spread=0.5)
+    ctr = np.zeros((2, n), np.int32)
+    env.set_state(H.to_dev(st), H.to_dev(ctr))
+    ost, octr = st.copy(), ctr.copy()
+    for t in range(6):
+        A = H.random_actions(rng, n, 7)
+        o, r, d, _ = env.step(H.to_dev(A))
+        oo, orw, od_ = orc.step(ost, octr, A)
+        TOL.assert_close(o.cpu().numpy(), oo, TOL.OBS_FLOOR, what='obs n_steps=%d t=%d' % (n_steps, t))
+        TOL.assert_close(r.cpu().numpy(), orw, TOL.REWARD_FLOOR, what='reward n_steps=%d t=%d' % (n_steps, t))
+        assert (d.cpu().numpy() != od_).sum() <= 1
+        s2, _ = env.get_state()
+        ost[:] = s2.cpu().numpy()                      # re-synchronise: fp32 vs fp32 but different operation order
+    if n_steps == 1:
+        rt = __import__('ml4ca_amd').BatchedRevoltEnv(2, testing=True, realtime=True)
+        assert rt.n_steps == 1 and rt.max_ep_len == 8000
+
+
 def test_force_map_vs_reference_fixture():
     """SupervisedTau.py:42-83 golden (2016 constants, asymmetric bow thruster)."""
     import ml4ca_amd

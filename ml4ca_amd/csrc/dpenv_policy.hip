@@ -29,6 +29,10 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 
+#ifndef DPENV_JOINT_EVAL
+#define DPENV_JOINT_EVAL 1          // actor + critic of one observation as one interleaved routine (mlp_eval2)
+#endif
+
 constexpr int PBLOCK = 256;          // 4 waves share one LDS image of the weights
 constexpr int PWAVES = PBLOCK / 64;
 
@@ -118,6 +122,149 @@ __device__ __forceinline__ void mlp_eval(const uint4* W, int n_hidden, half8 in0
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Actor AND critic of the same observation as one interleaved routine.
+//
+// Evaluated one after the other (mlp_eval twice) every row-block is "12 MFMAs, wait for them, ~48 VALU of
+// leaky-relu + f16 packing" - the activation needs the tile the matrix pipe has just been given, so MFMA and VALU
+// never overlap and a lone wave per SIMD pays for both in full (PMC: matrix pipe 27 % busy, VALU issue the rest).
+// The two networks are independent, so their row-blocks are alternated P0 V0 P1 V1 P2 V2 per layer and software-
+// pipelined across that sequence: while the matrix pipe works through the MFMAs of block i+1 the wave issues the
+// activation/packing VALU of block i (sched_group_barrier: 1 MFMA, 4 VALU, ...).  Across a layer boundary the pending
+// block is the critic's last one, which the actor's first block of the next layer does not depend on.
+// Same MFMA chains and same packing as mlp_eval: results are bit-identical to two separate evaluations.
+// ---------------------------------------------------------------------------------------------
+struct Acc2 {
+    float16v c0, c1;
+};
+
+template <int KS>
+__device__ __forceinline__ Acc2 mfma_block(const half8 (&w)[6], const half8 (&b)[6][2])
+{
+    const float16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    Acc2 r = {zero, zero};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        r.c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks][0], r.c0, 0, 0, 0);
+        r.c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks][1], r.c1, 0, 0, 0);
+    }
+    return r;
+}
+
+__device__ __forceinline__ void pack_block(const Acc2& a, half8 (&dst)[6][2], int mo, _Float16 leak)
+{
+    dst[2 * mo][0] = act_pack(a.c0, 0, leak); dst[2 * mo + 1][0] = act_pack(a.c0, 1, leak);
+    dst[2 * mo][1] = act_pack(a.c1, 0, leak); dst[2 * mo + 1][1] = act_pack(a.c1, 1, leak);
+}
+
+// issue order hint for one pipeline stage: the 6 LDS fragment reads of the block after next first, then N x (1 MFMA,
+// 4 VALU) - the MFMAs of the block being multiplied against the packing of the block before it
+template <int N>
+__device__ __forceinline__ void interleave_stage()
+{
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);          // a stage draws only on its own instructions
+}
+
+__device__ __forceinline__ void mlp_eval2(const uint4* Wp, const uint4* Wv, int n_hidden, half8 in0, half8 in1, _Float16 leak,
+                                          float outp[8], float outv[8])
+{
+    const int lane = threadIdx.x & 63;
+    half8 bP[6][2], bV[6][2], nP[6][2], nV[6][2], w[6], wn[6];
+    Acc2 pend;                                   // the block whose activation/packing is still to be issued
+    // ---- first layer: one k-step per block (2 MFMAs against ~48 VALU): VALU-bound whatever the order -------------
+    {
+        half8 wp[3], wv[3];
+#pragma unroll
+        for (int mo = 0; mo < 3; ++mo) { wp[mo] = ldfrag(Wp, mo, lane); wv[mo] = ldfrag(Wv, mo, lane); }
+        const float16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        auto first = [&](const half8& wf) {
+            Acc2 r;
+            r.c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, in0, zero, 0, 0, 0);
+            r.c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, in1, zero, 0, 0, 0);
+            return r;
+        };
+        Acc2 a = first(wp[0]);
+#pragma unroll
+        for (int mo = 0; mo < 3; ++mo) {
+            Acc2 v = first(wv[mo]);
+            pack_block(a, bP, mo, leak);
+            if (mo < 2) a = first(wp[mo + 1]);
+            if (mo < 2) pack_block(v, bV, mo, leak); else pend = v;
+        }
+    }
+    // bV[4], bV[5] are still pending in `pend`
+    int fbase = 3;
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) w[ks] = ldfrag(Wp, fbase + ks, lane);
+    for (int l = 1; l < n_hidden; ++l) {
+        // stage P0: needs bP only; the critic's last block of the layer before is packed underneath it
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) wn[ks] = ldfrag(Wv, fbase + ks, lane);
+        Acc2 cur = mfma_block<6>(w, bP);
+        pack_block(pend, bV, 2, leak);
+        interleave_stage<12>();
+        Acc2 prev = cur;
+#pragma unroll
+        for (int mo = 0; mo < 3; ++mo) {
+            // stage V_mo under the packing of P_mo
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) w[ks] = wn[ks];
+            if (mo < 2) {
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) wn[ks] = ldfrag(Wp, fbase + (mo + 1) * 6 + ks, lane);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) wn[ks] = ldfrag(Wp, fbase + 18 + ks, lane);     // next layer's (or the output's) P0
+            }
+            cur = mfma_block<6>(w, bV);
+            pack_block(prev, nP, mo, leak);
+            interleave_stage<12>();
+            prev = cur;
+            if (mo < 2) {
+                // stage P_{mo+1} under the packing of V_mo
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) w[ks] = wn[ks];
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) wn[ks] = ldfrag(Wv, fbase + (mo + 1) * 6 + ks, lane);
+                cur = mfma_block<6>(w, bP);
+                pack_block(prev, nV, mo, leak);
+                interleave_stage<12>();
+                prev = cur;
+            }
+        }
+        pend = prev;                              // V2 of this layer
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) { bP[ks][0] = nP[ks][0]; bP[ks][1] = nP[ks][1]; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { bV[ks][0] = nV[ks][0]; bV[ks][1] = nV[ks][1]; }
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) w[ks] = wn[ks];
+        fbase += 18;
+    }
+    // ---- output layer: one row-block per network --------------------------------------------------------------
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) wn[ks] = ldfrag(Wv, fbase + ks, lane);
+    const Acc2 op = mfma_block<6>(w, bP);
+    pack_block(pend, bV, 2, leak);
+    interleave_stage<12>();
+    const Acc2 ov = mfma_block<6>(wn, bV);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(op.c0[j]), __float_as_uint(op.c1[j]), false, false);
+        outp[j] = __uint_as_float(r[0]);
+        outp[4 + j] = __uint_as_float(r[1]);
+        const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(ov.c0[j]), __float_as_uint(ov.c1[j]), false, false);
+        outv[j] = __uint_as_float(q[0]);
+        outv[4 + j] = __uint_as_float(q[1]);
+    }
+}
+
 // first-layer B fragments from the per-lane observation row: input slot k < OD = obs[k], slot 15 = 1 (bias)
 template <int OD>
 __device__ __forceinline__ void obs_to_frags(const float o[9], half8& in0, half8& in1)
@@ -190,8 +337,12 @@ __global__ __launch_bounds__(PBLOCK) void policy_forward_kernel(const PolicyArgs
     half8 in0, in1;
     obs_to_frags<OD>(o, in0, in1);
     float mu[8], vv[8];
+#if DPENV_JOINT_EVAL
+    mlp_eval2(lds_w, lds_w + pa.nfrag * 64, pa.n_hidden, in0, in1, (_Float16)pa.leak, mu, vv);
+#else
     mlp_eval(lds_w, pa.n_hidden, in0, in1, (_Float16)pa.leak, mu);
     mlp_eval(lds_w + pa.nfrag * 64, pa.n_hidden, in0, in1, (_Float16)pa.leak, vv);
+#endif
     wave_store_rows<A>(lds_io, mu_out, (int64_t)wave0 * A, (int64_t)(n - wave0) * A, mu, lane);
     if (live) v_out[i] = vv[0];
 }
@@ -249,18 +400,23 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
     }
     half8 in0, in1;
     obs_to_frags<OD>(o, in0, in1);
-    float vout[8];
+    float vout[8], mu[8];
+#if DPENV_JOINT_EVAL
+    mlp_eval2(Wpi, Wv, pa.n_hidden, in0, in1, leak, mu, vout);     // actor and critic of o_0
+#else
     mlp_eval(Wv, pa.n_hidden, in0, in1, leak, vout);
+#endif
     float v_t = vout[0];
 
     float pre[A];
     if (pa.noise) load_rows<A, 64>(pa.noise + w_a, rem_a, lane, pre);
     int next_switch = 0;
     for (int t = 0; t < pa.T; ++t) {
-        // ---- store the policy input row, evaluate the actor ----------------------------------
+        // ---- store the policy input row; the actor's mean for it is already there (joint evaluation) -------------
         wave_store_rows<OD>(lds_io, pa.obs_out, (int64_t)t * stride_o + w_o, rem_o, o, lane, a.obs_bf16 != 0);
-        float mu[8];
+#if !DPENV_JOINT_EVAL
         mlp_eval(Wpi, pa.n_hidden, in0, in1, leak, mu);
+#endif
         // ---- sample: a = mu + std * xi (core.py:85), log-likelihood (core.py:42-46) -----------
         float act[A];
         float logp = 0.0f;
@@ -293,10 +449,44 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
         env_step<MODE, EXT>(a, ve, s, act, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out);
         if (a.current_drift) current_drift_step(a, cur, vc0, beta0, a.env_id_base + i);
 
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o[k] = out.o[k];
+        const bool do_reset = a.auto_reset && out.d != 0u && live;
+#if DPENV_JOINT_EVAL
+        // ---- value of the observation this step produced, and the next policy input ------------------------------
+        // No env of the wave finished (the common case): the next policy input IS that observation, so one joint
+        // evaluation gives V(o') for the bootstrap and the actor's mean for the next step.  Otherwise the critic is
+        // run once more on the pre-reset observation of the wave before the finished envs are re-drawn.
+        float v_pre = 0.0f;
+        if (__ballot(do_reset) != 0ull) {                       // wave-uniform
+            obs_to_frags<OD>(o, in0, in1);
+            mlp_eval(Wv, pa.n_hidden, in0, in1, leak, vout);
+            v_pre = vout[0];
+            if (do_reset) {
+                env_auto_reset<MODE>(a, s, a.env_id_base + i, episode, o);
+                ++episode; ep_dirty = true; rf_dirty = true;
+            }
+        }
+        obs_to_frags<OD>(o, in0, in1);
+        mlp_eval2(Wpi, Wv, pa.n_hidden, in0, in1, leak, mu, vout);
+        const float v_next = do_reset ? v_pre : vout[0];
+        const float v_new = vout[0];
+#else
         // ---- critic on the observation this step produced (pre-reset) --------------------------
         obs_to_frags<OD>(out.o, in0, in1);
         mlp_eval(Wv, pa.n_hidden, in0, in1, leak, vout);
         const float v_next = vout[0];
+        float v_new = v_next;
+        if (__ballot(do_reset) != 0ull) {                       // wave-uniform: rare
+            if (do_reset) {
+                env_auto_reset<MODE>(a, s, a.env_id_base + i, episode, o);
+                ++episode; ep_dirty = true; rf_dirty = true;
+            }
+            obs_to_frags<OD>(o, in0, in1);
+            mlp_eval(Wv, pa.n_hidden, in0, in1, leak, vout);
+            v_new = do_reset ? vout[0] : v_new;
+        }
+#endif
         // bootstrap value at a path end (ppo.py:311): 0 if the env terminated, V(o) if only the time limit or the
         // end of this launch cut the path
         const bool terminal = (out.d & DONE_TERMINAL) != 0u;
@@ -310,21 +500,7 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
             (pa.logp + (int64_t)t * n)[(unsigned)i] = logp;
             (pa.boot + (int64_t)t * n)[(unsigned)i] = boot;
         }
-
-        // ---- next policy input: the new observation, or the reset observation -------------------
-#pragma unroll
-        for (int k = 0; k < 9; ++k) o[k] = out.o[k];
-        v_t = v_next;
-        const bool do_reset = a.auto_reset && out.d != 0u && live;
-        if (__ballot(do_reset) != 0ull) {                       // wave-uniform: rare
-            if (do_reset) {
-                env_auto_reset<MODE>(a, s, a.env_id_base + i, episode, o);
-                ++episode; ep_dirty = true; rf_dirty = true;
-            }
-            obs_to_frags<OD>(o, in0, in1);
-            mlp_eval(Wv, pa.n_hidden, in0, in1, leak, vout);
-            v_t = do_reset ? vout[0] : v_t;
-        }
+        v_t = v_new;
     }
     // observation after the last step (policy input of the next launch) and final state
     wave_store_rows<OD>(lds_io, pa.last_obs, w_o, rem_o, o, lane, a.obs_bf16 != 0);

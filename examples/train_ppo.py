@@ -31,13 +31,19 @@ def main():
     ap.add_argument('--steps', type=int, default=400, help='rollout length per epoch = max_ep_len (train.py:70-73)')
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--minibatch', type=int, default=1 << 18, help='samples per gradient step (full batch in the reference)')
+    ap.add_argument('--backend', default='nccl', help="'nccl' (RCCL, one GPU per rank) or 'gloo' (rehearsal)")
+    ap.add_argument('--same-device', action='store_true', help='all ranks on cuda:0 (multi-rank rehearsal on a one-GPU box)')
     args = ap.parse_args()
     # one process per GPU under torch.distributed.run (backend nccl = RCCL); envs shard by global id, gradients average
     rank, world, local = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('LOCAL_RANK', 0))
-    dev = torch.device('cuda', local)
+    dev = torch.device('cuda', 0 if args.same_device else local)
     torch.cuda.set_device(dev)
     if world > 1:
-        torch.distributed.init_process_group('nccl', device_id=dev)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if args.backend == 'nccl':
+            torch.distributed.init_process_group('nccl', device_id=dev)
+        else:
+            torch.distributed.init_process_group(args.backend)
     torch.manual_seed(args.seed + 1000 * rank)
     env = ml4ca_amd.BatchedRevoltEnv(args.envs, auto_reset=True, seed=args.seed, device=dev,
                                      env_id_base=rank * args.envs)               # final / ext / cont_ang

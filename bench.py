@@ -103,6 +103,13 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
+    if not os.path.exists(os.path.join(ROOT, 'ml4ca_amd', 'lib', 'libdpenv.so')):
+        # a fresh checkout (built artefacts are git-ignored): build once, rank 0 first
+        if rank == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        if world > 1:
+            dist.barrier()
     import ml4ca_amd
     n = args.envs
     env = ml4ca_amd.BatchedRevoltEnv(n, variant='final', extended_state=True, cont_ang=True, device=dev,

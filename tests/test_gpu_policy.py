@@ -300,8 +300,10 @@ def test_plant_tracks_the_recorded_cybersea_box_run():
     ActorCritic.from_tensors({k.replace('.', '/'): d[k] for k in d.files if '.' in k}, device=env.device).upload(env)
     obs = env.reset(init=torch.zeros((6, 1), device=env.device), new_ref=H.to_dev(refs[:, :1]))
     traj = np.zeros((T, 3))
+    acts = []
     for k in range(T):
         mu, _ = policy_forward(env, obs)
+        acts.append(mu.clone())
         obs, _, _, _ = env.step(mu.contiguous(), new_ref=H.to_dev(refs[:, k + 1:k + 2]))
         st, _ = env.get_state()
         traj[k] = st[0:3, 0].cpu().numpy()
@@ -309,6 +311,15 @@ def test_plant_tracks_the_recorded_cybersea_box_run():
     rms = np.sqrt((dev ** 2).mean(0))
     assert rms[0] < 0.5 and rms[1] < 0.5 and np.degrees(rms[2]) < 8.0, rms
     assert np.abs(dev[:, :2]).max() < 1.5
+    # the energy the actor spends on the manoeuvre in this plant against what it spent in Cybersea (the thesis' "fuel":
+    # integral of the thruster power model, plot_act.py:128-135, over the RECORDED commands of the same run)
+    from ml4ca_amd import evaluate as EV
+    w_here = float(EV.work(EV.commanded_thrust(torch.stack(acts))).sum())
+    cmd = np.load(os.path.join(g, 'cybersea_replay.npz'))['box_test_RL_n'].astype(np.float32)
+    w_cyb = float(EV.work(torch.from_numpy(cmd)[:, None, :]).sum())
+    assert 600.0 < w_cyb < 850.0                       # 720: the recorded run
+    assert 0.85 * w_cyb < w_here < 1.15 * w_cyb, (w_here, w_cyb)      # measured 727 against 720
+    print('work in this plant %.0f, in Cybersea %.0f' % (w_here, w_cyb))
 
 
 def test_recorded_cybersea_commands_open_loop_through_kernel():

@@ -319,7 +319,13 @@ def test_plant_tracks_the_recorded_cybersea_box_run():
     w_cyb = float(EV.work(torch.from_numpy(cmd)[:, None, :]).sum())
     assert 600.0 < w_cyb < 850.0                       # 720: the recorded run
     assert 0.85 * w_cyb < w_here < 1.15 * w_cyb, (w_here, w_cyb)      # measured 727 against 720
-    print('work in this plant %.0f, in Cybersea %.0f' % (w_here, w_cyb))
+    # ... and the tracking error it leaves: IAE (common.py:56-74, normalised by [5 m, 5 m, 25 deg]) against the filtered
+    # setpoint series, for this plant's trajectory and for the recorded one
+    sp = rec['setpoint'][1:].astype(np.float64)
+    iae_here = float(EV.iae(torch.from_numpy(traj - sp)[:, None, :])[0])
+    iae_cyb = float(EV.iae(torch.from_numpy(rec['pose'][1:].astype(np.float64) - sp)[:, None, :])[0])
+    assert 0.6 * iae_cyb < iae_here < 1.4 * iae_cyb, (iae_here, iae_cyb)
+    print('work in this plant %.0f, in Cybersea %.0f; IAE vs the filtered setpoints %.2f here, %.2f in Cybersea' % (w_here, w_cyb, iae_here, iae_cyb))
 
 
 def test_recorded_cybersea_commands_open_loop_through_kernel():

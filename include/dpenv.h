@@ -193,7 +193,7 @@ int dpenv_rollout(dpenv_handle h, const dpenv_rollout_io* io, dpenv_stream s);
  * trajectory buffer (o, a, r, v, logp) of ppo.py:298 for every env. */
 typedef struct dpenv_mlp {
     int32_t n_layers;        /* dense layers = hidden layers + 1, in [2, 5] */
-    int32_t sizes[6];        /* n_layers + 1 widths, e.g. {9, 80, 80, 80, 7}; hidden widths equal and <= 95 */
+    int32_t sizes[6];        /* n_layers + 1 widths, e.g. {9, 80, 80, 80, 7}; hidden widths equal and <= 96 */
     const float* W[5];       /* HOST pointers, W[l][in][out] row-major (tf.layers.dense kernel layout) */
     const float* b[5];       /* HOST pointers, b[l][out] */
 } dpenv_mlp;

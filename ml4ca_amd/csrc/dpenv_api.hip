@@ -484,19 +484,26 @@ static uint16_t float_to_half(float f)
 // Pack one MLP into MFMA A-operand fragments (see dpenv_policy.hip).  Fragment f, lane l = (r = l & 31, h = l >> 5),
 // element j holds W^T[out row 32 mo + r][input slot k(f, h, j)]:
 //   first layer : k = 8 h + j                                  (slots 0..in-1 = inputs, slot 15 = bias)
-//   later layers: k = 32 mt + 16 s + 8 (j >> 2) + 4 h + (j & 3) (the accumulator-as-operand order; feature H = bias)
-static int pack_net(const dpenv_mlp* m, int in_dim, int out_dim, std::vector<uint16_t>& out, std::string* why)
+//   later layers: k = 32 mt + 16 s + 8 (j >> 2) + 4 h + (j & 3) (the accumulator-as-operand order), KS = ceil(H / 16)
+//                 k-steps; their biases go into `bias` as accumulator-layout tiles: block b, half h, register r16
+//                 -> b[out row 32 mo + 8 (r16 >> 2) + 4 h + (r16 & 3)]
+static int pack_net(const dpenv_mlp* m, int in_dim, int out_dim, std::vector<uint16_t>& out, std::vector<float>& bias, int* ks_out,
+                    std::string* why)
 {
     const int nl = m->n_layers;
     if (nl < 2 || nl > 5) { *why = "n_layers must be in [2, 5]"; return DPENV_EINVAL; }
     const int H = m->sizes[1];
     if (m->sizes[0] != in_dim || m->sizes[nl] != out_dim) { *why = "network input/output width does not match the env"; return DPENV_EINVAL; }
-    if (in_dim > 15 || out_dim > 8 || H < 1 || H > 95) { *why = "limits: obs_dim <= 15, out <= 8, hidden width <= 95"; return DPENV_EINVAL; }
+    if (in_dim > 15 || out_dim > 8 || H < 1 || H > 96) { *why = "limits: obs_dim <= 15, out <= 8, hidden width <= 96"; return DPENV_EINVAL; }
     for (int l = 1; l < nl; ++l) if (m->sizes[l] != H) { *why = "hidden widths must be equal"; return DPENV_EINVAL; }
     for (int l = 0; l < nl; ++l) if (!m->W[l] || !m->b[l]) { *why = "NULL weight pointer"; return DPENV_EINVAL; }
     const int n_hidden = nl - 1;
-    const int nfrag = 3 + 18 * (n_hidden - 1) + 6;
+    const int KS = H <= 80 ? 5 : 6;
+    const int nfrag = 3 + 3 * KS * (n_hidden - 1) + KS;
+    const int nblk = 3 * (n_hidden - 1) + 1;
+    *ks_out = KS;
     out.assign((size_t)nfrag * 64 * 8, 0);
+    bias.assign((size_t)nblk * 32, 0.0f);
     auto put = [&](int f, int lane, int j, float v) { out[((size_t)f * 64 + lane) * 8 + j] = float_to_half(v); };
     for (int lane = 0; lane < 64; ++lane) {
         const int r = lane & 31, hh = lane >> 5;
@@ -505,26 +512,30 @@ static int pack_net(const dpenv_mlp* m, int in_dim, int out_dim, std::vector<uin
                 const int k = 8 * hh + j, row = 32 * mo + r;
                 float v = 0.0f;
                 if (row < H) v = (k < in_dim) ? m->W[0][(size_t)k * H + row] : (k == 15 ? m->b[0][row] : 0.0f);
-                else if (row == H) v = (k == 15) ? 1.0f : 0.0f;
                 put(mo, lane, j, v);
             }
-            for (int ks = 0; ks < 6; ++ks) {
+            for (int ks = 0; ks < KS; ++ks) {
                 const int mt = ks >> 1, s2 = ks & 1;
                 const int f = 32 * mt + 16 * s2 + 8 * (j >> 2) + 4 * hh + (j & 3);
                 for (int l = 1; l < n_hidden; ++l)                 // hidden -> hidden
                     for (int mo = 0; mo < 3; ++mo) {
                         const int row = 32 * mo + r;
-                        float v = 0.0f;
-                        if (row < H) v = (f < H) ? m->W[l][(size_t)f * H + row] : (f == H ? m->b[l][row] : 0.0f);
-                        else if (row == H) v = (f == H) ? 1.0f : 0.0f;
-                        put(3 + 18 * (l - 1) + mo * 6 + ks, lane, j, v);
+                        put(3 + 3 * KS * (l - 1) + mo * KS + ks, lane, j, (row < H && f < H) ? m->W[l][(size_t)f * H + row] : 0.0f);
                     }
-                float v = 0.0f;                                    // output layer
-                if (r < out_dim) v = (f < H) ? m->W[nl - 1][(size_t)f * out_dim + r] : (f == H ? m->b[nl - 1][r] : 0.0f);
-                put(3 + 18 * (n_hidden - 1) + ks, lane, j, v);
+                put(3 + 3 * KS * (n_hidden - 1) + ks, lane, j, (r < out_dim && f < H) ? m->W[nl - 1][(size_t)f * out_dim + r] : 0.0f);   // output layer
             }
         }
     }
+    for (int hh = 0; hh < 2; ++hh)
+        for (int r16 = 0; r16 < 16; ++r16) {
+            const int rr = 8 * (r16 >> 2) + 4 * hh + (r16 & 3);
+            for (int l = 1; l < n_hidden; ++l)
+                for (int mo = 0; mo < 3; ++mo) {
+                    const int row = 32 * mo + rr;
+                    bias[((size_t)(3 * (l - 1) + mo)) * 32 + hh * 16 + r16] = row < H ? m->b[l][row] : 0.0f;
+                }
+            bias[((size_t)(3 * (n_hidden - 1))) * 32 + hh * 16 + r16] = rr < out_dim ? m->b[nl - 1][rr] : 0.0f;
+        }
     return nfrag;
 }
 
@@ -537,27 +548,35 @@ extern "C" int dpenv_set_policy(dpenv_handle h, const dpenv_mlp* pi, const dpenv
         return fail(h, DPENV_EINVAL, "actor and critic must have the same hidden shape");
     const int od = dpenv_obs_dim(&h->cfg), ad = dpenv_act_dim(&h->cfg);
     std::vector<uint16_t> fp, fv;
+    std::vector<float> bp, bv;
     std::string why;
-    const int nf = pack_net(pi, od, ad, fp, &why);
+    int ks = 0, ks2 = 0;
+    const int nf = pack_net(pi, od, ad, fp, bp, &ks, &why);
     if (nf < 0) return fail(h, DPENV_EINVAL, "actor: %s", why.c_str());
-    const int nf2 = pack_net(v, od, 1, fv, &why);
+    const int nf2 = pack_net(v, od, 1, fv, bv, &ks2, &why);
     if (nf2 < 0) return fail(h, DPENV_EINVAL, "critic: %s", why.c_str());
-    const size_t bytes_net = (size_t)nf * 64 * 16;
-    if (2 * bytes_net + 4 * 64 * 9 * 4 > 160 * 1024) return fail(h, DPENV_EINVAL, "networks do not fit the 160 KiB LDS");
+    const size_t bytes_net = (size_t)nf * 64 * 16, bytes_bias = bp.size() * sizeof(float);
+    if (2 * (bytes_net + bytes_bias) + 4 * 64 * 9 * 4 > 160 * 1024) return fail(h, DPENV_EINVAL, "networks do not fit the 160 KiB LDS");
     if (h->pol_frags && h->pol.nfrag != nf) { (void)hipFree(h->pol_frags); h->pol_frags = nullptr; }
     if (!h->pol_frags) {
         void* p = nullptr;
-        if (hipMalloc(&p, 2 * bytes_net) != hipSuccess) return fail(h, DPENV_ENOMEM, "hipMalloc of the policy fragments failed");
+        if (hipMalloc(&p, 2 * (bytes_net + bytes_bias)) != hipSuccess) return fail(h, DPENV_ENOMEM, "hipMalloc of the policy fragments failed");
         h->pol_frags = (uint4*)p;
     }
     // not on the step path: make sure no launch that still reads the previous weights is in flight on any stream
     HIP_TRY(h, hipDeviceSynchronize());
-    HIP_TRY(h, hipMemcpy(h->pol_frags, fp.data(), bytes_net, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy((char*)h->pol_frags + bytes_net, fv.data(), bytes_net, hipMemcpyHostToDevice));
+    char* base = (char*)h->pol_frags;
+    HIP_TRY(h, hipMemcpy(base, fp.data(), bytes_net, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(base + bytes_net, fv.data(), bytes_net, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(base + 2 * bytes_net, bp.data(), bytes_bias, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(base + 2 * bytes_net + bytes_bias, bv.data(), bytes_bias, hipMemcpyHostToDevice));
     PolicyArgs& pa = h->pol;
     std::memset(&pa, 0, sizeof pa);
     pa.frags = h->pol_frags;
+    pa.bias = (const float*)(base + 2 * bytes_net);
     pa.nfrag = nf;
+    pa.nblk = (int)(bp.size() / 32);
+    pa.ks = ks;
     pa.n_hidden = pi->n_layers - 1;
     pa.leak = leak;
     for (int k = 0; k < 8; ++k) {

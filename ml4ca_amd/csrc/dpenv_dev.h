@@ -96,7 +96,10 @@ struct RolloutArgs {
 // actor-critic evaluated in-kernel (dpenv_policy.hip)
 struct PolicyArgs {
     const uint4* frags;       // [2][nfrag][64] x 16 B: MFMA A-operand fragments (f16), actor then critic
-    int32_t nfrag;            // fragments per net = 3 + 18 (n_hidden - 1) + 6
+    const float* bias;        // [2][nblk][32] f32: bias tiles of the row-blocks after the first layer, accumulator layout
+    int32_t nfrag;            // fragments per net = 3 + 3 ks (n_hidden - 1) + ks
+    int32_t nblk;             // bias blocks per net = 3 (n_hidden - 1) + 1
+    int32_t ks;               // k-steps of 16 hidden features: 5 (width <= 80) or 6 (width <= 96)
     int32_t n_hidden;
     float leak;               // leaky-relu slope (0.2)
     float std[8];             // exp(log_std)                        (core.py:84)

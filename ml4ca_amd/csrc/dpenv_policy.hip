@@ -15,8 +15,9 @@
 //                  leaky-relu + convert to f16 in place, no lane movement, no LDS (cdna_hip_programming.md
 //                  section 3, "an accumulator tile as the next MFMA's operand"; the k-order permutation that
 //                  comes with it is folded into the host-side weight packing).
-//   * biases     = a constant-1 feature (input slot 15 of the first layer, feature H of every hidden layer)
-//                  whose weight column holds the bias, so the bias add happens inside the MFMA.
+//   * biases     = first layer: a constant-1 input (slot 15) whose weight column holds the bias; later layers: the
+//                  accumulator's INITIAL value (srcC of the first MFMA of a row-block is a bias tile read from LDS,
+//                  one 64-byte broadcast read per lane half), so hidden width 80 needs K = 80 = 5 k-steps, not 96.
 //   * in/out     = the env-per-lane <-> (32-env tile, lane-half) exchange at both ends is one
 //                  v_permlane32_swap per register.
 // Precision: f16 weights and activations, f32 accumulation.  This is the only MFMA use in the library; the
@@ -42,6 +43,16 @@ __device__ __forceinline__ half8 ldfrag(const uint4* W, int f, int lane)
     return __builtin_bit_cast(half8, q);
 }
 
+// bias tile of one 32-row block in accumulator layout: register r of a lane in half h holds output row
+// 8 (r >> 2) + 4 h + (r & 3); all lanes of a half read the same 64 bytes (LDS broadcast)
+__device__ __forceinline__ float16v ldbias(const float* B, int blk, int lane)
+{
+    const float4* p = (const float4*)(B + blk * 32 + (lane >> 5) * 16);
+    const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+    const float16v r = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+    return r;
+}
+
 // leaky-relu + f32 -> f16 of registers 8s .. 8s+7 of an accumulator tile = the B fragment of k-step s
 __device__ __forceinline__ half8 act_pack(const float16v& acc, int s, _Float16 leak)
 {
@@ -65,11 +76,12 @@ __device__ __forceinline__ half8 act_pack(const float16v& acc, int s, _Float16 l
 // into the next layer's B fragments; weight fragments are fetched from LDS one row-block ahead.  That keeps the
 // evaluation under the 256 architectural VGPRs, so the accumulators stay out of the AGPR half (every AGPR value
 // a VALU instruction needs costs a v_accvgpr_read).
-__device__ __forceinline__ void mlp_eval(const uint4* W, int n_hidden, half8 in0, half8 in1, _Float16 leak, float out[8])
+template <int KS>
+__device__ __forceinline__ void mlp_eval(const uint4* W, const float* B, int n_hidden, half8 in0, half8 in1, _Float16 leak, float out[8])
 {
     const int lane = threadIdx.x & 63;
     const float16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    half8 b[6][2], bn[6][2], w[6];
+    half8 b[KS][2], bn[KS][2], w[KS];
     // first layer: one k-step, three row-blocks
 #pragma unroll
     for (int mo = 0; mo < 3; ++mo) w[mo] = ldfrag(W, mo, lane);
@@ -77,38 +89,41 @@ __device__ __forceinline__ void mlp_eval(const uint4* W, int n_hidden, half8 in0
     for (int mo = 0; mo < 3; ++mo) {
         const float16v c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[mo], in0, zero, 0, 0, 0);
         const float16v c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[mo], in1, zero, 0, 0, 0);
-        b[2 * mo][0] = act_pack(c0, 0, leak); b[2 * mo + 1][0] = act_pack(c0, 1, leak);
-        b[2 * mo][1] = act_pack(c1, 0, leak); b[2 * mo + 1][1] = act_pack(c1, 1, leak);
+        b[2 * mo][0] = act_pack(c0, 0, leak); b[2 * mo][1] = act_pack(c1, 0, leak);
+        if (2 * mo + 1 < KS) { b[2 * mo + 1][0] = act_pack(c0, 1, leak); b[2 * mo + 1][1] = act_pack(c1, 1, leak); }
     }
-    int fbase = 3;
+    int fbase = 3, bblk = 0;
     for (int l = 1; l < n_hidden; ++l) {
 #pragma unroll
-        for (int ks = 0; ks < 6; ++ks) w[ks] = ldfrag(W, fbase + ks, lane);
+        for (int ks = 0; ks < KS; ++ks) w[ks] = ldfrag(W, fbase + ks, lane);
 #pragma unroll
         for (int mo = 0; mo < 3; ++mo) {
-            float16v c0 = zero, c1 = zero;
+            const float16v cb = ldbias(B, bblk + mo, lane);
+            float16v c0 = cb, c1 = cb;
 #pragma unroll
-            for (int ks = 0; ks < 6; ++ks) {
+            for (int ks = 0; ks < KS; ++ks) {
                 c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks][0], c0, 0, 0, 0);
                 c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks][1], c1, 0, 0, 0);
             }
             // the MFMAs above have read w: refill it for the next row-block while they execute
             if (mo < 2) {
 #pragma unroll
-                for (int ks = 0; ks < 6; ++ks) w[ks] = ldfrag(W, fbase + (mo + 1) * 6 + ks, lane);
+                for (int ks = 0; ks < KS; ++ks) w[ks] = ldfrag(W, fbase + (mo + 1) * KS + ks, lane);
             }
-            bn[2 * mo][0] = act_pack(c0, 0, leak); bn[2 * mo + 1][0] = act_pack(c0, 1, leak);
-            bn[2 * mo][1] = act_pack(c1, 0, leak); bn[2 * mo + 1][1] = act_pack(c1, 1, leak);
+            bn[2 * mo][0] = act_pack(c0, 0, leak); bn[2 * mo][1] = act_pack(c1, 0, leak);
+            if (2 * mo + 1 < KS) { bn[2 * mo + 1][0] = act_pack(c0, 1, leak); bn[2 * mo + 1][1] = act_pack(c1, 1, leak); }
         }
 #pragma unroll
-        for (int ks = 0; ks < 6; ++ks) { b[ks][0] = bn[ks][0]; b[ks][1] = bn[ks][1]; }
-        fbase += 18;
+        for (int ks = 0; ks < KS; ++ks) { b[ks][0] = bn[ks][0]; b[ks][1] = bn[ks][1]; }
+        fbase += 3 * KS;
+        bblk += 3;
     }
 #pragma unroll
-    for (int ks = 0; ks < 6; ++ks) w[ks] = ldfrag(W, fbase + ks, lane);
-    float16v c0 = zero, c1 = zero;
+    for (int ks = 0; ks < KS; ++ks) w[ks] = ldfrag(W, fbase + ks, lane);
+    const float16v cb = ldbias(B, bblk, lane);
+    float16v c0 = cb, c1 = cb;
 #pragma unroll
-    for (int ks = 0; ks < 6; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
         c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks][0], c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks][1], c1, 0, 0, 0);
     }
@@ -139,10 +154,9 @@ struct Acc2 {
 };
 
 template <int KS>
-__device__ __forceinline__ Acc2 mfma_block(const half8 (&w)[6], const half8 (&b)[6][2])
+__device__ __forceinline__ Acc2 mfma_block(const half8 (&w)[KS], const half8 (&b)[KS][2], const float16v& cinit)
 {
-    const float16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    Acc2 r = {zero, zero};
+    Acc2 r = {cinit, cinit};
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         r.c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks][0], r.c0, 0, 0, 0);
@@ -151,31 +165,34 @@ __device__ __forceinline__ Acc2 mfma_block(const half8 (&w)[6], const half8 (&b)
     return r;
 }
 
-__device__ __forceinline__ void pack_block(const Acc2& a, half8 (&dst)[6][2], int mo, _Float16 leak)
+template <int KS>
+__device__ __forceinline__ void pack_block(const Acc2& a, half8 (&dst)[KS][2], int mo, _Float16 leak)
 {
-    dst[2 * mo][0] = act_pack(a.c0, 0, leak); dst[2 * mo + 1][0] = act_pack(a.c0, 1, leak);
-    dst[2 * mo][1] = act_pack(a.c1, 0, leak); dst[2 * mo + 1][1] = act_pack(a.c1, 1, leak);
+    dst[2 * mo][0] = act_pack(a.c0, 0, leak); dst[2 * mo][1] = act_pack(a.c1, 0, leak);
+    if (2 * mo + 1 < KS) { dst[2 * mo + 1][0] = act_pack(a.c0, 1, leak); dst[2 * mo + 1][1] = act_pack(a.c1, 1, leak); }
 }
 
-// issue order hint for one pipeline stage: the 6 LDS fragment reads of the block after next first, then N x (1 MFMA,
-// 4 VALU) - the MFMAs of the block being multiplied against the packing of the block before it
-template <int N>
+// issue order hint for one pipeline stage: the LDS reads of the block after next first (KS weight fragments + 4 for the
+// bias tile), then N x (1 MFMA, 4 VALU) - the MFMAs of the block being multiplied against the packing of the block
+// before it
+template <int KS>
 __device__ __forceinline__ void interleave_stage()
 {
-    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, KS + 4, 0);
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
+    for (int k = 0; k < 2 * KS; ++k) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
     }
     __builtin_amdgcn_sched_barrier(0);          // a stage draws only on its own instructions
 }
 
-__device__ __forceinline__ void mlp_eval2(const uint4* Wp, const uint4* Wv, int n_hidden, half8 in0, half8 in1, _Float16 leak,
-                                          float outp[8], float outv[8])
+template <int KS>
+__device__ __forceinline__ void mlp_eval2(const uint4* Wp, const uint4* Wv, const float* Bp, const float* Bv, int n_hidden,
+                                          half8 in0, half8 in1, _Float16 leak, float outp[8], float outv[8])
 {
     const int lane = threadIdx.x & 63;
-    half8 bP[6][2], bV[6][2], nP[6][2], nV[6][2], w[6], wn[6];
+    half8 bP[KS][2], bV[KS][2], nP[KS][2], nV[KS][2], w[KS], wn[KS];
     Acc2 pend;                                   // the block whose activation/packing is still to be issued
     // ---- first layer: one k-step per block (2 MFMAs against ~48 VALU): VALU-bound whatever the order -------------
     {
@@ -193,67 +210,77 @@ __device__ __forceinline__ void mlp_eval2(const uint4* Wp, const uint4* Wv, int 
 #pragma unroll
         for (int mo = 0; mo < 3; ++mo) {
             Acc2 v = first(wv[mo]);
-            pack_block(a, bP, mo, leak);
+            pack_block<KS>(a, bP, mo, leak);
             if (mo < 2) a = first(wp[mo + 1]);
-            if (mo < 2) pack_block(v, bV, mo, leak); else pend = v;
+            if (mo < 2) pack_block<KS>(v, bV, mo, leak); else pend = v;
         }
     }
-    // bV[4], bV[5] are still pending in `pend`
-    int fbase = 3;
+    // bV[4] (and bV[5]) are still pending in `pend`
+    int fbase = 3, bblk = 0;
 #pragma unroll
-    for (int ks = 0; ks < 6; ++ks) w[ks] = ldfrag(Wp, fbase + ks, lane);
+    for (int ks = 0; ks < KS; ++ks) w[ks] = ldfrag(Wp, fbase + ks, lane);
+    float16v cb = ldbias(Bp, bblk, lane), cbn;
     for (int l = 1; l < n_hidden; ++l) {
         // stage P0: needs bP only; the critic's last block of the layer before is packed underneath it
 #pragma unroll
-        for (int ks = 0; ks < 6; ++ks) wn[ks] = ldfrag(Wv, fbase + ks, lane);
-        Acc2 cur = mfma_block<6>(w, bP);
-        pack_block(pend, bV, 2, leak);
-        interleave_stage<12>();
+        for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(Wv, fbase + ks, lane);
+        cbn = ldbias(Bv, bblk, lane);
+        Acc2 cur = mfma_block<KS>(w, bP, cb);
+        pack_block<KS>(pend, bV, 2, leak);
+        interleave_stage<KS>();
         Acc2 prev = cur;
 #pragma unroll
         for (int mo = 0; mo < 3; ++mo) {
             // stage V_mo under the packing of P_mo
 #pragma unroll
-            for (int ks = 0; ks < 6; ++ks) w[ks] = wn[ks];
+            for (int ks = 0; ks < KS; ++ks) w[ks] = wn[ks];
+            cb = cbn;
             if (mo < 2) {
 #pragma unroll
-                for (int ks = 0; ks < 6; ++ks) wn[ks] = ldfrag(Wp, fbase + (mo + 1) * 6 + ks, lane);
+                for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(Wp, fbase + (mo + 1) * KS + ks, lane);
+                cbn = ldbias(Bp, bblk + mo + 1, lane);
             } else {
 #pragma unroll
-                for (int ks = 0; ks < 6; ++ks) wn[ks] = ldfrag(Wp, fbase + 18 + ks, lane);     // next layer's (or the output's) P0
+                for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(Wp, fbase + 3 * KS + ks, lane);   // next layer's (or the output's) P0
+                cbn = ldbias(Bp, bblk + 3, lane);
             }
-            cur = mfma_block<6>(w, bV);
-            pack_block(prev, nP, mo, leak);
-            interleave_stage<12>();
+            cur = mfma_block<KS>(w, bV, cb);
+            pack_block<KS>(prev, nP, mo, leak);
+            interleave_stage<KS>();
             prev = cur;
             if (mo < 2) {
                 // stage P_{mo+1} under the packing of V_mo
 #pragma unroll
-                for (int ks = 0; ks < 6; ++ks) w[ks] = wn[ks];
+                for (int ks = 0; ks < KS; ++ks) w[ks] = wn[ks];
+                cb = cbn;
 #pragma unroll
-                for (int ks = 0; ks < 6; ++ks) wn[ks] = ldfrag(Wv, fbase + (mo + 1) * 6 + ks, lane);
-                cur = mfma_block<6>(w, bP);
-                pack_block(prev, nV, mo, leak);
-                interleave_stage<12>();
+                for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(Wv, fbase + (mo + 1) * KS + ks, lane);
+                cbn = ldbias(Bv, bblk + mo + 1, lane);
+                cur = mfma_block<KS>(w, bP, cb);
+                pack_block<KS>(prev, nV, mo, leak);
+                interleave_stage<KS>();
                 prev = cur;
             }
         }
         pend = prev;                              // V2 of this layer
 #pragma unroll
-        for (int ks = 0; ks < 6; ++ks) { bP[ks][0] = nP[ks][0]; bP[ks][1] = nP[ks][1]; }
+        for (int ks = 0; ks < KS; ++ks) { bP[ks][0] = nP[ks][0]; bP[ks][1] = nP[ks][1]; }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) { bV[ks][0] = nV[ks][0]; bV[ks][1] = nV[ks][1]; }
 #pragma unroll
-        for (int ks = 0; ks < 6; ++ks) w[ks] = wn[ks];
-        fbase += 18;
+        for (int ks = 0; ks < KS; ++ks) w[ks] = wn[ks];
+        cb = cbn;
+        fbase += 3 * KS;
+        bblk += 3;
     }
     // ---- output layer: one row-block per network --------------------------------------------------------------
 #pragma unroll
-    for (int ks = 0; ks < 6; ++ks) wn[ks] = ldfrag(Wv, fbase + ks, lane);
-    const Acc2 op = mfma_block<6>(w, bP);
-    pack_block(pend, bV, 2, leak);
-    interleave_stage<12>();
-    const Acc2 ov = mfma_block<6>(wn, bV);
+    for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(Wv, fbase + ks, lane);
+    cbn = ldbias(Bv, bblk, lane);
+    const Acc2 op = mfma_block<KS>(w, bP, cb);
+    pack_block<KS>(pend, bV, 2, leak);
+    interleave_stage<KS>();
+    const Acc2 ov = mfma_block<KS>(wn, bV, cbn);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(op.c0[j]), __float_as_uint(op.c1[j]), false, false);
@@ -285,11 +312,19 @@ __device__ __forceinline__ void obs_to_frags(const float o[9], half8& in0, half8
     in1 = __builtin_bit_cast(half8, b);   // envs 32..63
 }
 
+// LDS image: [2][nfrag][64] weight fragments (16 B each) | [2][nblk][32] bias floats | wave-private row staging
 __device__ __forceinline__ void stage_weights(uint4* lds, const PolicyArgs& pa)
 {
     const int total = 2 * pa.nfrag * 64;
     for (int k = threadIdx.x; k < total; k += PBLOCK) lds[k] = pa.frags[k];
+    float* lb = (float*)(lds + total);
+    for (int k = threadIdx.x; k < 2 * pa.nblk * 32; k += PBLOCK) lb[k] = pa.bias[k];
     __syncthreads();
+}
+
+__device__ __forceinline__ int policy_lds_io_offset_floats(const PolicyArgs& pa)      // after fragments and biases
+{
+    return 2 * pa.nfrag * 64 * 4 + 2 * pa.nblk * 32;
 }
 
 // wave-private AoS row I/O through LDS for a 64-env slice of a 256-thread workgroup
@@ -318,13 +353,14 @@ __device__ __forceinline__ void wave_rows_from_regs(float* lds_w, const float pr
 // =============================================================================================
 //  standalone forward pass: mu [n][A], v [n] for obs [n][OD]   (deterministic policy / validation)
 // =============================================================================================
-template <int OD, int A>
+template <int OD, int A, int KS>
 __global__ __launch_bounds__(PBLOCK) void policy_forward_kernel(const PolicyArgs pa, const float* obs, float* mu_out,
                                                                  float* v_out, int n)
 {
     extern __shared__ uint4 lds_dyn[];
     uint4* lds_w = lds_dyn;                                                     // [2 * nfrag][64] fragments
-    float* lds_io = (float*)(lds_dyn + 2 * pa.nfrag * 64) + (threadIdx.x >> 6) * (64 * 9);   // wave-private staging
+    const float* lds_b = (const float*)(lds_dyn + 2 * pa.nfrag * 64);                       // [2][nblk][32] bias floats
+    float* lds_io = (float*)lds_dyn + policy_lds_io_offset_floats(pa) + (threadIdx.x >> 6) * (64 * 9);   // wave-private staging
     stage_weights(lds_w, pa);
     const int lane = threadIdx.x & 63;
     const int wave0 = blockIdx.x * PBLOCK + (threadIdx.x & ~63);               // first env of this wave
@@ -338,10 +374,10 @@ __global__ __launch_bounds__(PBLOCK) void policy_forward_kernel(const PolicyArgs
     obs_to_frags<OD>(o, in0, in1);
     float mu[8], vv[8];
 #if DPENV_JOINT_EVAL
-    mlp_eval2(lds_w, lds_w + pa.nfrag * 64, pa.n_hidden, in0, in1, (_Float16)pa.leak, mu, vv);
+    mlp_eval2<KS>(lds_w, lds_w + pa.nfrag * 64, lds_b, lds_b + pa.nblk * 32, pa.n_hidden, in0, in1, (_Float16)pa.leak, mu, vv);
 #else
-    mlp_eval(lds_w, pa.n_hidden, in0, in1, (_Float16)pa.leak, mu);
-    mlp_eval(lds_w + pa.nfrag * 64, pa.n_hidden, in0, in1, (_Float16)pa.leak, vv);
+    mlp_eval<KS>(lds_w, lds_b, pa.n_hidden, in0, in1, (_Float16)pa.leak, mu);
+    mlp_eval<KS>(lds_w + pa.nfrag * 64, lds_b + pa.nblk * 32, pa.n_hidden, in0, in1, (_Float16)pa.leak, vv);
 #endif
     wave_store_rows<A>(lds_io, mu_out, (int64_t)wave0 * A, (int64_t)(n - wave0) * A, mu, lane);
     if (live) v_out[i] = vv[0];
@@ -351,17 +387,19 @@ __global__ __launch_bounds__(PBLOCK) void policy_forward_kernel(const PolicyArgs
 //  policy-in-the-loop rollout: T steps of (policy -> sample -> env.step -> value) per launch,
 //  writing the PPO trajectory rows (ppo.py:298) straight into [T][n][.] blocks.
 // =============================================================================================
-template <int MODE, bool EXT>
+template <int MODE, bool EXT, int KS>
 __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a, const PolicyArgs pa)
 {
     constexpr int A = ModeTraits<MODE>::A;
     constexpr int OD = EXT ? 9 : 6;
     extern __shared__ uint4 lds_dyn[];
     uint4* lds_w = lds_dyn;
-    float* lds_io = (float*)(lds_dyn + 2 * pa.nfrag * 64) + (threadIdx.x >> 6) * (64 * 9);
+    float* lds_io = (float*)lds_dyn + policy_lds_io_offset_floats(pa) + (threadIdx.x >> 6) * (64 * 9);
     stage_weights(lds_w, pa);
     const uint4* Wpi = lds_w;
     const uint4* Wv = lds_w + pa.nfrag * 64;
+    const float* Bpi = (const float*)(lds_dyn + 2 * pa.nfrag * 64);
+    const float* Bv = Bpi + pa.nblk * 32;
     const _Float16 leak = (_Float16)pa.leak;
 
     const int lane = threadIdx.x & 63;
@@ -402,9 +440,9 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
     obs_to_frags<OD>(o, in0, in1);
     float vout[8], mu[8];
 #if DPENV_JOINT_EVAL
-    mlp_eval2(Wpi, Wv, pa.n_hidden, in0, in1, leak, mu, vout);     // actor and critic of o_0
+    mlp_eval2<KS>(Wpi, Wv, Bpi, Bv, pa.n_hidden, in0, in1, leak, mu, vout);     // actor and critic of o_0
 #else
-    mlp_eval(Wv, pa.n_hidden, in0, in1, leak, vout);
+    mlp_eval<KS>(Wv, Bv, pa.n_hidden, in0, in1, leak, vout);
 #endif
     float v_t = vout[0];
 
@@ -415,7 +453,7 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
         // ---- store the policy input row; the actor's mean for it is already there (joint evaluation) -------------
         wave_store_rows<OD>(lds_io, pa.obs_out, (int64_t)t * stride_o + w_o, rem_o, o, lane, a.obs_bf16 != 0);
 #if !DPENV_JOINT_EVAL
-        mlp_eval(Wpi, pa.n_hidden, in0, in1, leak, mu);
+        mlp_eval<KS>(Wpi, Bpi, pa.n_hidden, in0, in1, leak, mu);
 #endif
         // ---- sample: a = mu + std * xi (core.py:85), log-likelihood (core.py:42-46) -----------
         float act[A];
@@ -460,7 +498,7 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
         float v_pre = 0.0f;
         if (__ballot(do_reset) != 0ull) {                       // wave-uniform
             obs_to_frags<OD>(o, in0, in1);
-            mlp_eval(Wv, pa.n_hidden, in0, in1, leak, vout);
+            mlp_eval<KS>(Wv, Bv, pa.n_hidden, in0, in1, leak, vout);
             v_pre = vout[0];
             if (do_reset) {
                 env_auto_reset<MODE>(a, s, a.env_id_base + i, episode, o);
@@ -468,13 +506,13 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
             }
         }
         obs_to_frags<OD>(o, in0, in1);
-        mlp_eval2(Wpi, Wv, pa.n_hidden, in0, in1, leak, mu, vout);
+        mlp_eval2<KS>(Wpi, Wv, Bpi, Bv, pa.n_hidden, in0, in1, leak, mu, vout);
         const float v_next = do_reset ? v_pre : vout[0];
         const float v_new = vout[0];
 #else
         // ---- critic on the observation this step produced (pre-reset) --------------------------
         obs_to_frags<OD>(out.o, in0, in1);
-        mlp_eval(Wv, pa.n_hidden, in0, in1, leak, vout);
+        mlp_eval<KS>(Wv, Bv, pa.n_hidden, in0, in1, leak, vout);
         const float v_next = vout[0];
         float v_new = v_next;
         if (__ballot(do_reset) != 0ull) {                       // wave-uniform: rare
@@ -483,7 +521,7 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
                 ++episode; ep_dirty = true; rf_dirty = true;
             }
             obs_to_frags<OD>(o, in0, in1);
-            mlp_eval(Wv, pa.n_hidden, in0, in1, leak, vout);
+            mlp_eval<KS>(Wv, Bv, pa.n_hidden, in0, in1, leak, vout);
             v_new = do_reset ? vout[0] : v_new;
         }
 #endif
@@ -516,21 +554,30 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
 
 using namespace dpenv;
 
-static size_t policy_lds_bytes(const PolicyArgs& pa) { return (size_t)2 * pa.nfrag * 64 * 16 + (size_t)PWAVES * 64 * 9 * 4; }
+static size_t policy_lds_bytes(const PolicyArgs& pa)
+{
+    return (size_t)2 * pa.nfrag * 64 * 16 + (size_t)2 * pa.nblk * 32 * 4 + (size_t)PWAVES * 64 * 9 * 4;
+}
 
 extern "C" hipError_t dpenv_dev_launch_policy_forward(const PolicyArgs* pa, int od, int adim, const float* obs, float* mu,
                                                       float* v, int n, hipStream_t s)
 {
     const dim3 grid((n + PBLOCK - 1) / PBLOCK), block(PBLOCK);
     const size_t lds = policy_lds_bytes(*pa);
-#define FWD(OD_, A_)                                                                                                     \
+#define FWD_K(OD_, A_, KS_)                                                                                              \
     do {                                                                                                                 \
-        hipError_t e = hipFuncSetAttribute((const void*)policy_forward_kernel<OD_, A_>,                                   \
+        hipError_t e = hipFuncSetAttribute((const void*)policy_forward_kernel<OD_, A_, KS_>,                              \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
         if (e != hipSuccess) return e;                                                                                   \
-        hipLaunchKernelGGL((policy_forward_kernel<OD_, A_>), grid, block, lds, s, *pa, obs, mu, v, n);                    \
+        hipLaunchKernelGGL((policy_forward_kernel<OD_, A_, KS_>), grid, block, lds, s, *pa, obs, mu, v, n);               \
         return hipGetLastError();                                                                                        \
     } while (0)
+#define FWD(OD_, A_)                                                                                                     \
+    do {                                                                                                                 \
+        if (pa->ks == 5) FWD_K(OD_, A_, 5);                                                                              \
+        FWD_K(OD_, A_, 6);                                                                                               \
+    } while (0)
+    if (pa->ks != 5 && pa->ks != 6) return hipErrorInvalidValue;
     if (od == 9 && adim == 7) FWD(9, 7);
     if (od == 9 && adim == 5) FWD(9, 5);
     if (od == 9 && adim == 6) FWD(9, 6);
@@ -538,28 +585,29 @@ extern "C" hipError_t dpenv_dev_launch_policy_forward(const PolicyArgs* pa, int 
     if (od == 6 && adim == 5) FWD(6, 5);
     if (od == 6 && adim == 6) FWD(6, 6);
     if (od == 6 && adim == 3) FWD(6, 3);
+#undef FWD_K
 #undef FWD
     return hipErrorInvalidValue;
+}
+
+template <int MODE, bool EXT, int KS>
+static hipError_t launch_policy_rollout_one(const StepArgs& a, const PolicyArgs& pa, hipStream_t s)
+{
+    const dim3 grid((a.n + PBLOCK - 1) / PBLOCK), block(PBLOCK);
+    const size_t lds = policy_lds_bytes(pa);
+    hipError_t e = hipFuncSetAttribute((const void*)policy_rollout_kernel<MODE, EXT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((policy_rollout_kernel<MODE, EXT, KS>), grid, block, lds, s, a, pa);
+    return hipGetLastError();
 }
 
 template <int MODE>
 static hipError_t launch_policy_rollout_mode(const StepArgs& a, const PolicyArgs& pa, bool ext, hipStream_t s)
 {
-    const dim3 grid((a.n + PBLOCK - 1) / PBLOCK), block(PBLOCK);
-    const size_t lds = policy_lds_bytes(pa);
-    hipError_t e;
-    if (ext) {
-        e = hipFuncSetAttribute((const void*)policy_rollout_kernel<MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((policy_rollout_kernel<MODE, true>), grid, block, lds, s, a, pa);
-    } else {
-        e = hipFuncSetAttribute((const void*)policy_rollout_kernel<MODE, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((policy_rollout_kernel<MODE, false>), grid, block, lds, s, a, pa);
-    }
-    return hipGetLastError();
+    if (pa.ks == 5) return ext ? launch_policy_rollout_one<MODE, true, 5>(a, pa, s) : launch_policy_rollout_one<MODE, false, 5>(a, pa, s);
+    if (pa.ks == 6) return ext ? launch_policy_rollout_one<MODE, true, 6>(a, pa, s) : launch_policy_rollout_one<MODE, false, 6>(a, pa, s);
+    return hipErrorInvalidValue;
 }
 
 extern "C" hipError_t dpenv_dev_launch_policy_rollout(const StepArgs* a, const PolicyArgs* pa, int mode, int ext,

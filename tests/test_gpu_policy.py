@@ -33,6 +33,8 @@ def make_ac(obs_dim, act_dim, hidden, seed, device, scale_bias=True):
     ('final_cont', True, (80, 80, 80)),      # the shipped model shape (config.json)
     ('final_cont', True, (64,)),
     ('final_cont', True, (95, 95)),
+    ('final_cont', True, (96, 96, 96)),      # the widest supported: 6 k-steps, no padding row
+    ('final_cont', True, (81, 81)),          # one feature into the sixth k-step
     ('final_cont', True, (33, 33, 33, 33)),
     ('limited', False, (80, 80, 80)),
     ('full', True, (48, 48)),
@@ -244,7 +246,7 @@ def test_policy_argument_validation():
     with pytest.raises(ml4ca_amd.DpenvError):
         ActorCritic(9, 6, (80, 80), device=env.device).upload(env)                 # act_dim mismatch
     with pytest.raises(ml4ca_amd.DpenvError):
-        ActorCritic(9, 7, (96, 96), device=env.device).upload(env)                 # hidden width > 95
+        ActorCritic(9, 7, (97, 97), device=env.device).upload(env)                 # hidden width > 96
     ActorCritic(9, 7, (80, 80, 80), device=env.device).upload(env)
     env_soa, _ = H.make_pair('final_cont', 128, layout='soa')
     ActorCritic(9, 7, (80, 80, 80), device=env.device).upload(env_soa)

@@ -61,6 +61,46 @@ def replay_oracle(W, vessel=None, dtype=np.float64):
     return out
 
 
+def replay_numpy(W, vessel=None, h=0.01, n_substeps=20):
+    """The same replay with the plant written out in NumPy (vectorised over the windows): an independent second
+    implementation of the model equations of DESIGN.md section 3, used to cross-check the C oracle's plant."""
+    from oracle import oracle as O
+    v = np.asarray(O.Oracle(O.make_config(), np.float64).vessel if vessel is None else vessel, np.float64)
+    m11, m22, m23, m33 = v[0:4]
+    Xu, Xuu, Yv, Yvv, Yr, Nv, Nr, Nrr = v[4:12]
+    Kf, Kr, lx, ly = v[12:15], v[15:18], v[18:21], v[21:24]
+    Nuv, Yur = v[24], v[25]
+    det = m22 * m33 - m23 * m23
+    i22, i23, i33 = m33 / det, -m23 / det, m22 / det
+    N, E, psi = (W['eta0'][:, k].copy() for k in range(3))
+    u, vv, r = (W['nu0'][:, k].copy() for k in range(3))
+    vcN, vcE = W['current'][0] * np.cos(W['current'][1]), W['current'][0] * np.sin(W['current'][1])
+    out = np.zeros(W['truth'].shape)
+    for t in range(W['act'].shape[0]):
+        A = W['act'][t]
+        n = np.clip(A[:, 0:3] * 100.0, -100.0, 100.0)
+        al = np.stack([np.full(len(N), np.pi / 2), np.arctan2(A[:, 3], A[:, 4]), np.arctan2(A[:, 5], A[:, 6])], 1)
+        F = np.where(n >= 0, Kf, Kr) * n * np.abs(n)
+        tx, ty = (np.cos(al) * F).sum(1), (np.sin(al) * F).sum(1)
+        tn = ((lx * np.sin(al) - ly * np.cos(al)) * F).sum(1)
+        c, s = np.cos(psi), np.sin(psi)
+        u, vv = u - (c * vcN + s * vcE), vv - (-s * vcN + c * vcE)              # relative velocity
+        for _ in range(n_substeps):
+            c13, c23 = -(m22 * vv + m23 * r), m11 * u
+            fx = tx - c13 * r - (Xu + Xuu * np.abs(u)) * u
+            fy = ty - c23 * r - ((Yv + Yvv * np.abs(vv)) * vv + (Yr + Yur * u) * r)
+            fn = tn + (c13 * u + c23 * vv) - ((Nv + Nuv * u) * vv + (Nr + Nrr * np.abs(r)) * r)
+            u, vv, r = u + h * fx / m11, vv + h * (i22 * fy + i23 * fn), r + h * (i23 * fy + i33 * fn)
+            N, E = N + h * (c * u - s * vv + vcN), E + h * (s * u + c * vv + vcE)
+            d = h * r
+            psi = psi + d
+            c, s = c * (1 - 0.5 * d * d) - s * d, s * (1 - 0.5 * d * d) + c * d    # second-order rotation, re-seeded per step
+        c, s = np.cos(psi), np.sin(psi)
+        u, vv = u + (c * vcN + s * vcE), vv + (-s * vcN + c * vcE)
+        out[t, :, 0], out[t, :, 1], out[t, :, 2] = N, E, psi
+    return out
+
+
 def errors(pred, W, sel=None):
     """{horizon_steps: (rms position error [m], rms yaw error [deg])}"""
     res = {}

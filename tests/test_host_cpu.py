@@ -278,6 +278,8 @@ def test_default_hull_open_loop_against_recorded_cybersea_commands():
         assert e[h][0] < band[h][0] and e[h][1] < band[h][1], (h, e[h])
         assert e[h][0] < 0.7 * cv[h][0] and e[h][1] < 0.7 * cv[h][1], (h, e[h], cv[h])
         assert e[h][0] < 0.35 * still[h][0] and e[h][1] < 0.8 * still[h][1], (h, e[h], still[h])
+    # an independent NumPy statement of the model equations reproduces the C oracle's plant over all 392 x 50 steps
+    assert np.abs(RC.replay_numpy(W) - pred).max() < 1e-9
     # the current run is predicted as well as the calm-water one: the relative-velocity current model is in the right place
     sel = W['run'] == W['names'].index('current_box_test_QP')
     assert RC.errors(pred, W, sel)[50][0] < 0.5

@@ -262,6 +262,46 @@ def test_step_matches_oracle(mode, ext, layout):
     assert 0.02 < (g['done'] & 1).mean() < 0.98     # both outcomes exercised
 
 
+@pytest.mark.parametrize('case', range(24))
+def test_random_feature_combinations_match_oracle(case):
+    """Features that the other tests exercise one at a time, drawn together at random: variant x extended state x
+    layout x wrap mode x termination x time limit x agent rate x current x ragged size x late setpoint, two steps each
+    (the second from the kernel's own state), against the fp32 oracle."""
+    rng = np.random.RandomState(9000 + case)
+    mode = ['full', 'simple', 'limited', 'final_wrap', 'final_cont'][rng.randint(5)]
+    ext = bool(rng.randint(2)) and mode != 'simple'
+    kw = dict(layout=['aos', 'soa'][rng.randint(2)], wrap_mode=['reference', 'radians'][rng.randint(2)],
+              terminate=bool(rng.randint(2)), time_limit=bool(rng.randint(2)), current=bool(rng.randint(2)),
+              n_steps=[None, 1, 5, 20, 33][rng.randint(5)])
+    n = int(rng.choice([1, 31, 64, 100, 257, 1000, 4099]))
+    env, orc = H.make_pair(mode, n, ext=ext, **kw)
+    cur = None
+    if kw['current']:
+        vc = rng.uniform(0.0, 0.3, size=n).astype(np.float32)
+        beta = rng.uniform(-np.pi, np.pi, size=n).astype(np.float32)
+        env.set_current(H.to_dev(vc), H.to_dev(beta))
+        cur = np.stack([vc, beta])
+    st = H.random_state(rng, n, spread=0.6)
+    ctr = np.zeros((2, n), np.int32)
+    ctr[0] = rng.randint(0, max(2, env.max_ep_len), size=n)
+    for t in range(2):
+        act = H.random_actions(rng, n, orc.act_dim)
+        nr = rng.uniform(-4, 4, size=(3, n)).astype(np.float32) if rng.randint(2) else None
+        g, o = step_both(env, orc, st, ctr, act, new_ref=nr, current=cur)
+        if kw['wrap_mode'] == 'radians':
+            seam = np.abs(g['obs'][:, 2] - o['obs'][:, 2]) > 6.0       # +-pi seam: 2 pi apart between precisions
+            assert seam.mean() <= 0.02
+            for k in ('obs', 'parts', 'rew'):
+                g[k], o[k] = g[k][~seam], o[k][~seam]
+            g['done'], o['done'] = g['done'][~seam], o['done'][~seam]
+            for k in ('st', 'ctr'):
+                g[k], o[k] = g[k][:, ~seam], o[k][:, ~seam]
+        compare(g, o, orc.obs_dim, env.real_ss_bounds)
+        if kw['wrap_mode'] == 'radians' and seam.any():
+            break
+        st, ctr = g['st'].copy(), g['ctr'].copy()
+
+
 @pytest.mark.parametrize('n', [1, 63, 64, 65, 255, 256, 257, 1000])
 def test_ragged_sizes(n):
     rng = np.random.RandomState(n)

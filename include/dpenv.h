@@ -201,6 +201,12 @@ typedef struct dpenv_mlp {
  * leaky-relu slope (0.2 = tf.nn.leaky_relu default; 0 = relu).  Packs and uploads; may be called again after
  * every PPO update. */
 int dpenv_set_policy(dpenv_handle h, const dpenv_mlp* pi, const dpenv_mlp* v, const float* log_std, float leak);
+/* The same with the hidden activation named: the reference's --activation {leaky, relu, tanh} (train.py:24,31;
+ * spinup core.py:29-33 takes any activation, tanh being Spinning Up's default).  relu = DPENV_ACT_LEAKY_RELU with
+ * leak 0; leak is ignored for DPENV_ACT_TANH. */
+enum { DPENV_ACT_LEAKY_RELU = 0, DPENV_ACT_TANH = 1 };
+int dpenv_set_policy_ex(dpenv_handle h, const dpenv_mlp* pi, const dpenv_mlp* v, const float* log_std, int32_t activation,
+                        float leak);
 /* mu_out [n][act_dim], v_out [n] for obs [n][obs_dim] (all device, row-major): the deterministic policy of
  * test_policy.py:90 and the critic. */
 int dpenv_policy_forward(dpenv_handle h, const float* obs, float* mu_out, float* v_out, int32_t n, dpenv_stream s);

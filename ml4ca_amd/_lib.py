@@ -15,6 +15,7 @@ FULL, SIMPLE, LIMITED, FINAL = 0, 1, 2, 3
 AOS, SOA = 0, 1
 WRAP_REFERENCE, WRAP_RADIANS = 0, 1
 F32, BF16 = 0, 1
+ACT_LEAKY_RELU, ACT_TANH = 0, 1
 DONE_TERMINAL, DONE_TIMELIMIT, DONE_FAULT = 1, 2, 4
 NSTATE, NPARAM, MAX_CLASSES = 15, 32, 64
 ABI_VERSION = 1
@@ -81,6 +82,7 @@ SYMBOLS = {
     'dpenv_step_ex': (C.c_int, [_VP, C.POINTER(StepIO), _VP]),
     'dpenv_rollout': (C.c_int, [_VP, C.POINTER(RolloutIO), _VP]),
     'dpenv_set_policy': (C.c_int, [_VP, C.POINTER(Mlp), C.POINTER(Mlp), C.POINTER(C.c_float), _F]),
+    'dpenv_set_policy_ex': (C.c_int, [_VP, C.POINTER(Mlp), C.POINTER(Mlp), C.POINTER(C.c_float), C.c_int32, _F]),
     'dpenv_policy_forward': (C.c_int, [_VP, _VP, _VP, _VP, _I32, _VP]),
     'dpenv_policy_rollout': (C.c_int, [_VP, C.POINTER(PolicyRolloutIO), _VP]),
     'dpenv_get_state': (C.c_int, [_VP, _VP, _VP, _VP]),

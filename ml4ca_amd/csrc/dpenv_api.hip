@@ -541,7 +541,15 @@ static int pack_net(const dpenv_mlp* m, int in_dim, int out_dim, std::vector<uin
 
 extern "C" int dpenv_set_policy(dpenv_handle h, const dpenv_mlp* pi, const dpenv_mlp* v, const float* log_std, float leak)
 {
+    return dpenv_set_policy_ex(h, pi, v, log_std, DPENV_ACT_LEAKY_RELU, leak);
+}
+
+extern "C" int dpenv_set_policy_ex(dpenv_handle h, const dpenv_mlp* pi, const dpenv_mlp* v, const float* log_std, int32_t activation,
+                                   float leak)
+{
     if (!h) return DPENV_EINVAL;
+    if (activation != DPENV_ACT_LEAKY_RELU && activation != DPENV_ACT_TANH)
+        return fail(h, DPENV_EINVAL, "dpenv_set_policy_ex: activation must be DPENV_ACT_LEAKY_RELU or DPENV_ACT_TANH");
     DeviceGuard dev_guard(h->device);
     if (!pi || !v || !log_std) return fail(h, DPENV_EINVAL, "dpenv_set_policy: NULL argument");
     if (pi->n_layers != v->n_layers || pi->sizes[1] != v->sizes[1])
@@ -577,6 +585,7 @@ extern "C" int dpenv_set_policy(dpenv_handle h, const dpenv_mlp* pi, const dpenv
     pa.nfrag = nf;
     pa.nblk = (int)(bp.size() / 32);
     pa.ks = ks;
+    pa.act = activation;
     pa.n_hidden = pi->n_layers - 1;
     pa.leak = leak;
     for (int k = 0; k < 8; ++k) {

@@ -53,17 +53,33 @@ __device__ __forceinline__ float16v ldbias(const float* B, int blk, int lane)
     return r;
 }
 
-// leaky-relu + f32 -> f16 of registers 8s .. 8s+7 of an accumulator tile = the B fragment of k-step s
+// hidden activation + f32 -> f16 of registers 8s .. 8s+7 of an accumulator tile = the B fragment of k-step s.
+// ACT_LEAKY: leaky-relu of slope `leak` (0 = relu), the reference's default ('leaky', train.py:24,31); ACT_TANH: its
+// '--activation tanh' option (Spinning Up's own default), evaluated in f32 as 1 - 2 / (exp(2x) + 1).
+constexpr int ACT_LEAKY = 0, ACT_TANH = 1;
+
+template <int ACT>
 __device__ __forceinline__ half8 act_pack(const float16v& acc, int s, _Float16 leak)
 {
     half8 r;
     const half2v lk = {leak, leak};
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
-        // v_cvt_pkrtz_f16_f32, then packed f16 mul + max: 1.5 instructions per activation
-        half2v h = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(acc[8 * s + j], acc[8 * s + j + 1]));
-        h = __builtin_elementwise_max(h, h * lk);
-        r[j] = h[0]; r[j + 1] = h[1];
+        if (ACT == ACT_TANH) {
+            float t[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float e = __builtin_amdgcn_exp2f(acc[8 * s + j + q] * 2.8853900817779268f);      // exp(2x)
+                t[q] = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+            }
+            const half2v h = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(t[0], t[1]));
+            r[j] = h[0]; r[j + 1] = h[1];
+        } else {
+            // v_cvt_pkrtz_f16_f32, then packed f16 mul + max: 1.5 instructions per activation
+            half2v h = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(acc[8 * s + j], acc[8 * s + j + 1]));
+            h = __builtin_elementwise_max(h, h * lk);
+            r[j] = h[0]; r[j + 1] = h[1];
+        }
     }
     return r;
 }
@@ -76,9 +92,11 @@ __device__ __forceinline__ half8 act_pack(const float16v& acc, int s, _Float16 l
 // into the next layer's B fragments; weight fragments are fetched from LDS one row-block ahead.  That keeps the
 // evaluation under the 256 architectural VGPRs, so the accumulators stay out of the AGPR half (every AGPR value
 // a VALU instruction needs costs a v_accvgpr_read).
-template <int KS>
+// KA = KS + 16 ACT: k-steps of 16 hidden features (5 or 6) and the hidden activation, as one template parameter
+template <int KA>
 __device__ __forceinline__ void mlp_eval(const uint4* W, const float* B, int n_hidden, half8 in0, half8 in1, _Float16 leak, float out[8])
 {
+    constexpr int KS = KA & 15, ACT = KA >> 4;
     const int lane = threadIdx.x & 63;
     const float16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     half8 b[KS][2], bn[KS][2], w[KS];
@@ -89,8 +107,8 @@ __device__ __forceinline__ void mlp_eval(const uint4* W, const float* B, int n_h
     for (int mo = 0; mo < 3; ++mo) {
         const float16v c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[mo], in0, zero, 0, 0, 0);
         const float16v c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[mo], in1, zero, 0, 0, 0);
-        b[2 * mo][0] = act_pack(c0, 0, leak); b[2 * mo][1] = act_pack(c1, 0, leak);
-        if (2 * mo + 1 < KS) { b[2 * mo + 1][0] = act_pack(c0, 1, leak); b[2 * mo + 1][1] = act_pack(c1, 1, leak); }
+        b[2 * mo][0] = act_pack<ACT>(c0, 0, leak); b[2 * mo][1] = act_pack<ACT>(c1, 0, leak);
+        if (2 * mo + 1 < KS) { b[2 * mo + 1][0] = act_pack<ACT>(c0, 1, leak); b[2 * mo + 1][1] = act_pack<ACT>(c1, 1, leak); }
     }
     int fbase = 3, bblk = 0;
     for (int l = 1; l < n_hidden; ++l) {
@@ -110,8 +128,8 @@ __device__ __forceinline__ void mlp_eval(const uint4* W, const float* B, int n_h
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) w[ks] = ldfrag(W, fbase + (mo + 1) * KS + ks, lane);
             }
-            bn[2 * mo][0] = act_pack(c0, 0, leak); bn[2 * mo][1] = act_pack(c1, 0, leak);
-            if (2 * mo + 1 < KS) { bn[2 * mo + 1][0] = act_pack(c0, 1, leak); bn[2 * mo + 1][1] = act_pack(c1, 1, leak); }
+            bn[2 * mo][0] = act_pack<ACT>(c0, 0, leak); bn[2 * mo][1] = act_pack<ACT>(c1, 0, leak);
+            if (2 * mo + 1 < KS) { bn[2 * mo + 1][0] = act_pack<ACT>(c0, 1, leak); bn[2 * mo + 1][1] = act_pack<ACT>(c1, 1, leak); }
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) { b[ks][0] = bn[ks][0]; b[ks][1] = bn[ks][1]; }
@@ -165,11 +183,12 @@ __device__ __forceinline__ Acc2 mfma_block(const half8 (&w)[KS], const half8 (&b
     return r;
 }
 
-template <int KS>
-__device__ __forceinline__ void pack_block(const Acc2& a, half8 (&dst)[KS][2], int mo, _Float16 leak)
+template <int KA>
+__device__ __forceinline__ void pack_block(const Acc2& a, half8 (&dst)[KA & 15][2], int mo, _Float16 leak)
 {
-    dst[2 * mo][0] = act_pack(a.c0, 0, leak); dst[2 * mo][1] = act_pack(a.c1, 0, leak);
-    if (2 * mo + 1 < KS) { dst[2 * mo + 1][0] = act_pack(a.c0, 1, leak); dst[2 * mo + 1][1] = act_pack(a.c1, 1, leak); }
+    constexpr int KS = KA & 15, ACT = KA >> 4;
+    dst[2 * mo][0] = act_pack<ACT>(a.c0, 0, leak); dst[2 * mo][1] = act_pack<ACT>(a.c1, 0, leak);
+    if (2 * mo + 1 < KS) { dst[2 * mo + 1][0] = act_pack<ACT>(a.c0, 1, leak); dst[2 * mo + 1][1] = act_pack<ACT>(a.c1, 1, leak); }
 }
 
 // issue order hint for one pipeline stage: the LDS reads of the block after next first (KS weight fragments + 4 for the
@@ -187,10 +206,11 @@ __device__ __forceinline__ void interleave_stage()
     __builtin_amdgcn_sched_barrier(0);          // a stage draws only on its own instructions
 }
 
-template <int KS>
+template <int KA>
 __device__ __forceinline__ void mlp_eval2(const uint4* Wp, const uint4* Wv, const float* Bp, const float* Bv, int n_hidden,
                                           half8 in0, half8 in1, _Float16 leak, float outp[8], float outv[8])
 {
+    constexpr int KS = KA & 15;
     const int lane = threadIdx.x & 63;
     half8 bP[KS][2], bV[KS][2], nP[KS][2], nV[KS][2], w[KS], wn[KS];
     Acc2 pend;                                   // the block whose activation/packing is still to be issued
@@ -210,9 +230,9 @@ __device__ __forceinline__ void mlp_eval2(const uint4* Wp, const uint4* Wv, cons
 #pragma unroll
         for (int mo = 0; mo < 3; ++mo) {
             Acc2 v = first(wv[mo]);
-            pack_block<KS>(a, bP, mo, leak);
+            pack_block<KA>(a, bP, mo, leak);
             if (mo < 2) a = first(wp[mo + 1]);
-            if (mo < 2) pack_block<KS>(v, bV, mo, leak); else pend = v;
+            if (mo < 2) pack_block<KA>(v, bV, mo, leak); else pend = v;
         }
     }
     // bV[4] (and bV[5]) are still pending in `pend`
@@ -226,7 +246,7 @@ __device__ __forceinline__ void mlp_eval2(const uint4* Wp, const uint4* Wv, cons
         for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(Wv, fbase + ks, lane);
         cbn = ldbias(Bv, bblk, lane);
         Acc2 cur = mfma_block<KS>(w, bP, cb);
-        pack_block<KS>(pend, bV, 2, leak);
+        pack_block<KA>(pend, bV, 2, leak);
         interleave_stage<KS>();
         Acc2 prev = cur;
 #pragma unroll
@@ -245,7 +265,7 @@ __device__ __forceinline__ void mlp_eval2(const uint4* Wp, const uint4* Wv, cons
                 cbn = ldbias(Bp, bblk + 3, lane);
             }
             cur = mfma_block<KS>(w, bV, cb);
-            pack_block<KS>(prev, nP, mo, leak);
+            pack_block<KA>(prev, nP, mo, leak);
             interleave_stage<KS>();
             prev = cur;
             if (mo < 2) {
@@ -257,7 +277,7 @@ __device__ __forceinline__ void mlp_eval2(const uint4* Wp, const uint4* Wv, cons
                 for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(Wv, fbase + (mo + 1) * KS + ks, lane);
                 cbn = ldbias(Bv, bblk + mo + 1, lane);
                 cur = mfma_block<KS>(w, bP, cb);
-                pack_block<KS>(prev, nV, mo, leak);
+                pack_block<KA>(prev, nV, mo, leak);
                 interleave_stage<KS>();
                 prev = cur;
             }
@@ -278,7 +298,7 @@ __device__ __forceinline__ void mlp_eval2(const uint4* Wp, const uint4* Wv, cons
     for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(Wv, fbase + ks, lane);
     cbn = ldbias(Bv, bblk, lane);
     const Acc2 op = mfma_block<KS>(w, bP, cb);
-    pack_block<KS>(pend, bV, 2, leak);
+    pack_block<KA>(pend, bV, 2, leak);
     interleave_stage<KS>();
     const Acc2 ov = mfma_block<KS>(wn, bV, cbn);
 #pragma unroll
@@ -353,7 +373,7 @@ __device__ __forceinline__ void wave_rows_from_regs(float* lds_w, const float pr
 // =============================================================================================
 //  standalone forward pass: mu [n][A], v [n] for obs [n][OD]   (deterministic policy / validation)
 // =============================================================================================
-template <int OD, int A, int KS>
+template <int OD, int A, int KA>
 __global__ __launch_bounds__(PBLOCK) void policy_forward_kernel(const PolicyArgs pa, const float* obs, float* mu_out,
                                                                  float* v_out, int n)
 {
@@ -374,10 +394,10 @@ __global__ __launch_bounds__(PBLOCK) void policy_forward_kernel(const PolicyArgs
     obs_to_frags<OD>(o, in0, in1);
     float mu[8], vv[8];
 #if DPENV_JOINT_EVAL
-    mlp_eval2<KS>(lds_w, lds_w + pa.nfrag * 64, lds_b, lds_b + pa.nblk * 32, pa.n_hidden, in0, in1, (_Float16)pa.leak, mu, vv);
+    mlp_eval2<KA>(lds_w, lds_w + pa.nfrag * 64, lds_b, lds_b + pa.nblk * 32, pa.n_hidden, in0, in1, (_Float16)pa.leak, mu, vv);
 #else
-    mlp_eval<KS>(lds_w, lds_b, pa.n_hidden, in0, in1, (_Float16)pa.leak, mu);
-    mlp_eval<KS>(lds_w + pa.nfrag * 64, lds_b + pa.nblk * 32, pa.n_hidden, in0, in1, (_Float16)pa.leak, vv);
+    mlp_eval<KA>(lds_w, lds_b, pa.n_hidden, in0, in1, (_Float16)pa.leak, mu);
+    mlp_eval<KA>(lds_w + pa.nfrag * 64, lds_b + pa.nblk * 32, pa.n_hidden, in0, in1, (_Float16)pa.leak, vv);
 #endif
     wave_store_rows<A>(lds_io, mu_out, (int64_t)wave0 * A, (int64_t)(n - wave0) * A, mu, lane);
     if (live) v_out[i] = vv[0];
@@ -387,7 +407,7 @@ __global__ __launch_bounds__(PBLOCK) void policy_forward_kernel(const PolicyArgs
 //  policy-in-the-loop rollout: T steps of (policy -> sample -> env.step -> value) per launch,
 //  writing the PPO trajectory rows (ppo.py:298) straight into [T][n][.] blocks.
 // =============================================================================================
-template <int MODE, bool EXT, int KS>
+template <int MODE, bool EXT, int KA>
 __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a, const PolicyArgs pa)
 {
     constexpr int A = ModeTraits<MODE>::A;
@@ -440,9 +460,9 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
     obs_to_frags<OD>(o, in0, in1);
     float vout[8], mu[8];
 #if DPENV_JOINT_EVAL
-    mlp_eval2<KS>(Wpi, Wv, Bpi, Bv, pa.n_hidden, in0, in1, leak, mu, vout);     // actor and critic of o_0
+    mlp_eval2<KA>(Wpi, Wv, Bpi, Bv, pa.n_hidden, in0, in1, leak, mu, vout);     // actor and critic of o_0
 #else
-    mlp_eval<KS>(Wv, Bv, pa.n_hidden, in0, in1, leak, vout);
+    mlp_eval<KA>(Wv, Bv, pa.n_hidden, in0, in1, leak, vout);
 #endif
     float v_t = vout[0];
 
@@ -453,7 +473,7 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
         // ---- store the policy input row; the actor's mean for it is already there (joint evaluation) -------------
         wave_store_rows<OD>(lds_io, pa.obs_out, (int64_t)t * stride_o + w_o, rem_o, o, lane, a.obs_bf16 != 0);
 #if !DPENV_JOINT_EVAL
-        mlp_eval<KS>(Wpi, Bpi, pa.n_hidden, in0, in1, leak, mu);
+        mlp_eval<KA>(Wpi, Bpi, pa.n_hidden, in0, in1, leak, mu);
 #endif
         // ---- sample: a = mu + std * xi (core.py:85), log-likelihood (core.py:42-46) -----------
         float act[A];
@@ -498,7 +518,7 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
         float v_pre = 0.0f;
         if (__ballot(do_reset) != 0ull) {                       // wave-uniform
             obs_to_frags<OD>(o, in0, in1);
-            mlp_eval<KS>(Wv, Bv, pa.n_hidden, in0, in1, leak, vout);
+            mlp_eval<KA>(Wv, Bv, pa.n_hidden, in0, in1, leak, vout);
             v_pre = vout[0];
             if (do_reset) {
                 env_auto_reset<MODE>(a, s, a.env_id_base + i, episode, o);
@@ -506,13 +526,13 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
             }
         }
         obs_to_frags<OD>(o, in0, in1);
-        mlp_eval2<KS>(Wpi, Wv, Bpi, Bv, pa.n_hidden, in0, in1, leak, mu, vout);
+        mlp_eval2<KA>(Wpi, Wv, Bpi, Bv, pa.n_hidden, in0, in1, leak, mu, vout);
         const float v_next = do_reset ? v_pre : vout[0];
         const float v_new = vout[0];
 #else
         // ---- critic on the observation this step produced (pre-reset) --------------------------
         obs_to_frags<OD>(out.o, in0, in1);
-        mlp_eval<KS>(Wv, Bv, pa.n_hidden, in0, in1, leak, vout);
+        mlp_eval<KA>(Wv, Bv, pa.n_hidden, in0, in1, leak, vout);
         const float v_next = vout[0];
         float v_new = v_next;
         if (__ballot(do_reset) != 0ull) {                       // wave-uniform: rare
@@ -521,7 +541,7 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
                 ++episode; ep_dirty = true; rf_dirty = true;
             }
             obs_to_frags<OD>(o, in0, in1);
-            mlp_eval<KS>(Wv, Bv, pa.n_hidden, in0, in1, leak, vout);
+            mlp_eval<KA>(Wv, Bv, pa.n_hidden, in0, in1, leak, vout);
             v_new = do_reset ? vout[0] : v_new;
         }
 #endif
@@ -574,10 +594,13 @@ extern "C" hipError_t dpenv_dev_launch_policy_forward(const PolicyArgs* pa, int 
     } while (0)
 #define FWD(OD_, A_)                                                                                                     \
     do {                                                                                                                 \
-        if (pa->ks == 5) FWD_K(OD_, A_, 5);                                                                              \
-        FWD_K(OD_, A_, 6);                                                                                               \
+        if (ka == 5) FWD_K(OD_, A_, 5);                                                                                  \
+        if (ka == 6) FWD_K(OD_, A_, 6);                                                                                  \
+        if (ka == 21) FWD_K(OD_, A_, 21);                                                                                \
+        FWD_K(OD_, A_, 22);                                                                                              \
     } while (0)
-    if (pa->ks != 5 && pa->ks != 6) return hipErrorInvalidValue;
+    if ((pa->ks != 5 && pa->ks != 6) || (pa->act != 0 && pa->act != 1)) return hipErrorInvalidValue;
+    const int ka = pa->ks + 16 * pa->act;
     if (od == 9 && adim == 7) FWD(9, 7);
     if (od == 9 && adim == 5) FWD(9, 5);
     if (od == 9 && adim == 6) FWD(9, 6);
@@ -590,24 +613,28 @@ extern "C" hipError_t dpenv_dev_launch_policy_forward(const PolicyArgs* pa, int 
     return hipErrorInvalidValue;
 }
 
-template <int MODE, bool EXT, int KS>
+template <int MODE, bool EXT, int KA>
 static hipError_t launch_policy_rollout_one(const StepArgs& a, const PolicyArgs& pa, hipStream_t s)
 {
     const dim3 grid((a.n + PBLOCK - 1) / PBLOCK), block(PBLOCK);
     const size_t lds = policy_lds_bytes(pa);
-    hipError_t e = hipFuncSetAttribute((const void*)policy_rollout_kernel<MODE, EXT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)policy_rollout_kernel<MODE, EXT, KA>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((policy_rollout_kernel<MODE, EXT, KS>), grid, block, lds, s, a, pa);
+    hipLaunchKernelGGL((policy_rollout_kernel<MODE, EXT, KA>), grid, block, lds, s, a, pa);
     return hipGetLastError();
 }
 
 template <int MODE>
 static hipError_t launch_policy_rollout_mode(const StepArgs& a, const PolicyArgs& pa, bool ext, hipStream_t s)
 {
-    if (pa.ks == 5) return ext ? launch_policy_rollout_one<MODE, true, 5>(a, pa, s) : launch_policy_rollout_one<MODE, false, 5>(a, pa, s);
-    if (pa.ks == 6) return ext ? launch_policy_rollout_one<MODE, true, 6>(a, pa, s) : launch_policy_rollout_one<MODE, false, 6>(a, pa, s);
-    return hipErrorInvalidValue;
+    if ((pa.ks != 5 && pa.ks != 6) || (pa.act != 0 && pa.act != 1)) return hipErrorInvalidValue;
+    switch (pa.ks + 16 * pa.act) {
+    case 5: return ext ? launch_policy_rollout_one<MODE, true, 5>(a, pa, s) : launch_policy_rollout_one<MODE, false, 5>(a, pa, s);
+    case 6: return ext ? launch_policy_rollout_one<MODE, true, 6>(a, pa, s) : launch_policy_rollout_one<MODE, false, 6>(a, pa, s);
+    case 21: return ext ? launch_policy_rollout_one<MODE, true, 21>(a, pa, s) : launch_policy_rollout_one<MODE, false, 21>(a, pa, s);
+    default: return ext ? launch_policy_rollout_one<MODE, true, 22>(a, pa, s) : launch_policy_rollout_one<MODE, false, 22>(a, pa, s);
+    }
 }
 
 extern "C" hipError_t dpenv_dev_launch_policy_rollout(const StepArgs* a, const PolicyArgs* pa, int mode, int ext,

@@ -20,9 +20,16 @@ def _torch():
 
 
 class ActorCritic(object):
-    def __init__(self, obs_dim=9, act_dim=7, hidden_sizes=(80, 80, 80), leak=0.2, log_std_init=-0.5, seed=0, device='cpu'):
+    def __init__(self, obs_dim=9, act_dim=7, hidden_sizes=(80, 80, 80), leak=0.2, log_std_init=-0.5, seed=0, device='cpu',
+                 activation='leaky'):
+        """activation: the reference's --activation choices (train.py:24,31): 'leaky' (slope `leak`, default 0.2 as
+        tf.nn.leaky_relu), 'relu' (= leaky with slope 0) or 'tanh'."""
         torch = _torch()
         assert len(set(hidden_sizes)) == 1 and 1 <= len(hidden_sizes) <= 4, 'equal hidden widths, 1..4 hidden layers'
+        assert activation in ('leaky', 'relu', 'tanh'), activation
+        if activation == 'relu':
+            leak = 0.0
+        self.activation = activation
         self.obs_dim, self.act_dim, self.hidden_sizes, self.leak = obs_dim, act_dim, tuple(hidden_sizes), float(leak)
         g = torch.Generator().manual_seed(seed)
         self.device = torch.device(device)
@@ -42,7 +49,7 @@ class ActorCritic(object):
         self.log_std = torch.full((act_dim,), float(log_std_init), device=self.device)      # core.py:83
 
     @classmethod
-    def from_tensors(cls, tensors, leak=0.2, device='cpu'):
+    def from_tensors(cls, tensors, leak=0.2, device='cpu', activation='leaky'):
         """Build from a {name: array} dict with the reference's variable names (core.py:103-106 scopes 'pi' and 'v',
         tf.layers.dense naming dense, dense_1, ...; pi/log_std) - e.g. the output of tf_checkpoint.read_bundle."""
         torch = _torch()
@@ -63,16 +70,16 @@ class ActorCritic(object):
         if not pW or not vW:
             raise ValueError("no 'pi/dense*/kernel' / 'v/dense*/kernel' variables found")
         hidden = tuple(int(w.shape[1]) for w in pW[:-1])
-        ac = cls(int(pW[0].shape[0]), int(pW[-1].shape[1]), hidden, leak=leak, device=device)
+        ac = cls(int(pW[0].shape[0]), int(pW[-1].shape[1]), hidden, leak=leak, device=device, activation=activation)
         ac.pi_W, ac.pi_b, ac.v_W, ac.v_b = pW, pb, vW, vb
         ac.log_std = torch.tensor(np.asarray(tensors['pi/log_std'], np.float32), device=device)
         return ac
 
     @classmethod
-    def from_tf_checkpoint(cls, prefix, leak=0.2, device='cpu'):
+    def from_tf_checkpoint(cls, prefix, leak=0.2, device='cpu', activation='leaky'):
         """Load a reference-trained model, e.g. '<model dir>/tf1_save/variables/variables' (logx.py:161-228)."""
         from .tf_checkpoint import read_bundle
-        return cls.from_tensors(read_bundle(prefix), leak=leak, device=device)
+        return cls.from_tensors(read_bundle(prefix), leak=leak, device=device, activation=activation)
 
     def state_dict(self):
         """{reference variable name: numpy array} (inverse of from_tensors)."""
@@ -91,7 +98,7 @@ class ActorCritic(object):
     def _mlp(self, x, Ws, bs):
         torch = _torch()
         for W, b in zip(Ws[:-1], bs[:-1]):
-            x = torch.nn.functional.leaky_relu(x @ W + b, self.leak)
+            x = torch.tanh(x @ W + b) if self.activation == 'tanh' else torch.nn.functional.leaky_relu(x @ W + b, self.leak)
         return x @ Ws[-1] + bs[-1]
 
     def forward_ref(self, obs):
@@ -126,8 +133,9 @@ class ActorCritic(object):
         pi, k1 = mk(self.pi_W, self.pi_b)
         v, k2 = mk(self.v_W, self.v_b)
         ls = np.ascontiguousarray(self.log_std.detach().float().cpu().numpy())
-        _lib.check(lib.dpenv_set_policy(env._h, C.byref(pi), C.byref(v), ls.ctypes.data_as(C.POINTER(C.c_float)),
-                                        C.c_float(self.leak)), env._h)
+        act = _lib.ACT_TANH if self.activation == 'tanh' else _lib.ACT_LEAKY_RELU
+        _lib.check(lib.dpenv_set_policy_ex(env._h, C.byref(pi), C.byref(v), ls.ctypes.data_as(C.POINTER(C.c_float)),
+                                           C.c_int32(act), C.c_float(self.leak)), env._h)
         env._has_policy = True
         return self
 

@@ -78,6 +78,57 @@ def test_policy_forward_matches_fp32_reference(mode, ext, hidden):
     assert float((v2 - v2_ref).abs().max()) < 2e-2 * (float(v2_ref.abs().max()) + 1)
 
 
+@pytest.mark.parametrize('activation,hidden', [('tanh', (80, 80, 80)), ('tanh', (96, 96)), ('relu', (80, 80, 80))])
+def test_other_hidden_activations(activation, hidden):
+    """The reference's --activation choices besides 'leaky' (train.py:24,31): tanh (Spinning Up's default) and relu,
+    forward pass against fp32 torch and a closed-loop launch replayed through single steps."""
+    from ml4ca_amd.policy import ActorCritic, policy_forward, policy_rollout
+    torch = torch_()
+    n, T = 777, 12
+    env, _ = H.make_pair('final_cont', n, auto_reset=True, max_ep_len=40)
+    env2, _ = H.make_pair('final_cont', n, auto_reset=True, max_ep_len=40)
+    ac = ActorCritic(9, 7, hidden, seed=11, device=env.device, activation=activation)
+    g = torch.Generator().manual_seed(12)
+    for b in ac.pi_b + ac.v_b:
+        b.copy_((torch.rand(b.shape, generator=g) - 0.5).to(env.device) * 0.6)
+    for W in ac.pi_W + ac.v_W:
+        W.mul_(1.5)                                   # push pre-activations into tanh's curved range
+    ac.upload(env)
+    assert ac.leak == (0.0 if activation == 'relu' else 0.2)
+    gd = torch.Generator(device=env.device).manual_seed(13)
+    obs = torch.randn((n, 9), generator=gd, device=env.device) * torch.tensor([3, 3, 0.3, 0.5, 0.2, 0.2, 0.5, 0.5, 0.5], device=env.device)
+    mu, v = policy_forward(env, obs)
+    mu_ref, v_ref = ac.forward_ref(obs)
+    assert float((mu - mu_ref).abs().max()) < 6e-3 * (float(mu_ref.abs().max()) + 1.0), float((mu - mu_ref).abs().max())
+    assert float((v - v_ref).abs().max()) < 6e-3 * (float(v_ref.abs().max()) + 1.0)
+    # the same weights with the default activation give something else
+    ActorCritic.upload(_with_activation(ac, 'leaky'), env2)
+    mu_l, _ = policy_forward(env2, obs)
+    assert float((mu_l - mu).abs().max()) > (0.05 if activation == 'tanh' else 0.01)
+    # closed loop: rows are consistent with the single-step kernel and with the fp32 networks
+    ac.upload(env2)
+    env.reset(); env2.reset()
+    noise = torch.randn((T, n, 7), generator=gd, device=env.device)
+    blk = policy_rollout(env, T, noise=noise)
+    o = blk['obs'][0]
+    for t in range(T):
+        assert torch.equal(blk['obs'][t], o)
+        mu_t, v_t = ac.forward_ref(o)
+        assert float((blk['act'][t] - (mu_t + torch.exp(ac.log_std) * noise[t])).abs().max()) < 2e-2
+        assert float((blk['val'][t] - v_t).abs().max()) < 6e-3 * (float(v_t.abs().max()) + 1.0)
+        o, r, d, _ = env2.step(blk['act'][t].contiguous())
+        assert torch.equal(r, blk['rew'][t]) and torch.equal(d, blk['done'][t])
+        o = o.clone()
+
+
+def _with_activation(ac, activation):
+    import copy
+    c = copy.copy(ac)
+    c.activation = activation
+    c.leak = 0.2
+    return c
+
+
 @pytest.mark.parametrize('mode,ext,hidden', [('limited', True, (80, 80, 80)), ('full', True, (64, 64)), ('simple', False, (80, 80, 80)),
                                              ('final_wrap', False, (48,))])
 def test_policy_rollout_other_variants_replay_through_single_steps(mode, ext, hidden):

@@ -31,6 +31,7 @@ def main():
     ap.add_argument('--steps', type=int, default=400, help='rollout length per epoch = max_ep_len (train.py:70-73)')
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--minibatch', type=int, default=1 << 18, help='samples per gradient step (full batch in the reference)')
+    ap.add_argument('--activation', default='leaky', choices=('leaky', 'relu', 'tanh'), help='hidden activation (train.py:24,31)')
     ap.add_argument('--backend', default='nccl', help="'nccl' (RCCL, one GPU per rank) or 'gloo' (rehearsal)")
     ap.add_argument('--same-device', action='store_true', help='all ranks on cuda:0 (multi-rank rehearsal on a one-GPU box)')
     args = ap.parse_args()
@@ -47,7 +48,7 @@ def main():
     torch.manual_seed(args.seed + 1000 * rank)
     env = ml4ca_amd.BatchedRevoltEnv(args.envs, auto_reset=True, seed=args.seed, device=dev,
                                      env_id_base=rank * args.envs)               # final / ext / cont_ang
-    ac = ActorCritic(9, 7, (80, 80, 80), leak=0.2, seed=args.seed, device=dev)
+    ac = ActorCritic(9, 7, (80, 80, 80), leak=0.2, seed=args.seed, device=dev, activation=args.activation)
     D.sync_params(ac.parameters())                                               # sync_all_params, ppo.py:255
     for p in ac.parameters():
         p.requires_grad_(True)

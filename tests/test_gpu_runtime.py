@@ -163,3 +163,27 @@ def test_soak_262_million_env_steps():
     assert int(n_end) == int(ctr[1].sum()) - n                  # every finished episode was re-sampled exactly once
     vc, beta = env.get_current()
     assert 0.1 < float(vc.mean()) < 0.3 and float(vc.std()) < 0.05
+
+
+def test_reset_actions_option():
+    """ENV:30,179-188 (--reset_acts): episodes start with previous thrust clip(N(0, 0.1) * 100); thrust only, angles at
+    their defaults; the reset observation carries it; masked resets leave the other envs alone."""
+    import ml4ca_amd
+    from ml4ca_amd import _lib
+    torch = __import__('torch')
+    n = 4096
+    env = ml4ca_amd.BatchedRevoltEnv(n, reset_acts=True, seed=5)
+    obs = env.reset()
+    st, _ = env.get_state()
+    pt = st[_lib.S['PT_BOW']:_lib.S['PT_BOW'] + 3]
+    assert abs(float(pt.mean())) < 1.0 and 9.0 < float(pt.std()) < 11.0 and float(pt.abs().max()) <= 100.0
+    assert torch.allclose(obs[:, 6:9], (pt / 100.0).t())
+    assert torch.equal(st[_lib.S['A_BOW']], torch.full((n,), float(np.pi / 2), device=env.device))
+    mask = torch.zeros(n, dtype=torch.uint8, device=env.device)
+    mask[: n // 2] = 1
+    env.reset(mask=mask)
+    st2, _ = env.get_state()
+    pt2 = st2[_lib.S['PT_BOW']:_lib.S['PT_BOW'] + 3]
+    assert torch.equal(pt2[:, n // 2:], pt[:, n // 2:]) and not torch.equal(pt2[:, : n // 2], pt[:, : n // 2])
+    with pytest.raises(ValueError):
+        ml4ca_amd.BatchedRevoltEnv(8, reset_acts=True, auto_reset=True)

@@ -28,6 +28,7 @@ namespace dpenv {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float2v __attribute__((ext_vector_type(2)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 
 #ifndef DPENV_JOINT_EVAL
@@ -72,11 +73,14 @@ __device__ __forceinline__ half8 act_pack(const float16v& acc, int s, _Float16 l
                 const float e = __builtin_amdgcn_exp2f(acc[8 * s + j + q] * 2.8853900817779268f);      // exp(2x)
                 t[q] = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
             }
-            const half2v h = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(t[0], t[1]));
+            const float2v tf = {t[0], t[1]};
+            const half2v h = __builtin_convertvector(tf, half2v);
             r[j] = h[0]; r[j + 1] = h[1];
         } else {
-            // v_cvt_pkrtz_f16_f32, then packed f16 mul + max: 1.5 instructions per activation
-            half2v h = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(acc[8 * s + j], acc[8 * s + j + 1]));
+            // v_cvt_pk_f16_f32 (gfx950: round-to-nearest-even, unlike v_cvt_pkrtz), then packed f16 mul + max:
+            // 1.5 instructions per activation
+            const float2v af = {acc[8 * s + j], acc[8 * s + j + 1]};
+            half2v h = __builtin_convertvector(af, half2v);
             h = __builtin_elementwise_max(h, h * lk);
             r[j] = h[0]; r[j + 1] = h[1];
         }

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -632,6 +633,11 @@ extern "C" int dpenv_policy_rollout(dpenv_handle h, const dpenv_policy_rollout_i
     pa.T = io->T; pa.noise = io->noise; pa.obs_out = io->obs; pa.act_out = io->act; pa.rew = io->reward; pa.val = io->value;
     pa.logp = io->logp; pa.done = io->done; pa.boot = io->boot; pa.last_obs = io->last_obs; pa.last_val = io->last_value;
     pa.n_switch = io->n_switch; pa.refs = io->refs;
+    {
+        // launch form: DPENV_POLICY_WS=0/1 overrides; default = the wave-specialised form
+        const char* e = getenv("DPENV_POLICY_WS");
+        pa.ws = e ? (e[0] != '0') : 1;
+    }
     for (int k = 0; k < io->n_switch; ++k) pa.switch_step[k] = io->switch_step[k];
     HIP_TRY(h, dpenv_dev_launch_policy_rollout(&a, &pa, h->mode, h->cfg.extended_state, (hipStream_t)s));
     return DPENV_OK;

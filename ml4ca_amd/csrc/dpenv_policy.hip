@@ -574,6 +574,232 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
     }
 }
 
+// =============================================================================================
+//  The same rollout with the work of every 64 envs split over TWO waves (wave specialisation).
+//
+//  At 65 536 envs policy_rollout_kernel puts one wave on each SIMD, and one wave alone issues an instruction every
+//  ~2.3 ns however idle the SIMD is (tools/issue_rate.hip).  Here a 512-thread workgroup owns 256 envs with eight waves:
+//  E-wave g (0..3) carries the environments of group g, M-wave 4+g their networks, so every SIMD holds an E and an M
+//  wave.  Per step:
+//      phase A   M: actor(o_t) -> mu                                      E: stores the policy-input row
+//      barrier
+//      phase B   M: critic(o_t) (+ critic of the pre-reset observation    E: sample, env.step, reset, next policy input
+//                   where step t-1 cut an episode)
+//      barrier   E: val[t] = V(o_t), boot[t-1]
+//  The chain env.step(t) -> actor(o_t+1) -> env.step(t+1) stays serial; the critic - half of the network work - runs
+//  beside the env step.  Same mlp_eval chains and same env_step as policy_rollout_kernel: every row is bit-identical.
+// =============================================================================================
+constexpr int WSBLOCK = 512;
+constexpr int WS_GROUP_FLOATS = 64 * 9 * 5 + 64 * 4 + 64;       // io | obs | pre[2] | mu | v[2] | vpre[2] | sequence words (+ pad)
+
+// pair-level hand-over inside a workgroup: a sequence word in LDS, released by one wave and acquired by its partner.
+// Both waves of a pair belong to the same workgroup, so they are always co-resident; the waiter sleeps between polls.
+__device__ __forceinline__ void ws_post(int* p, int v, int lane)
+{
+    if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void ws_wait(int* p, int v)
+{
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < v)
+        __builtin_amdgcn_s_sleep(2);
+}
+
+#ifdef DPENV_WS_DEBUG_NOMFMA
+#define WS_EVAL(W_, B_, f0_, f1_)                                                   \
+    do {                                                                           \
+        _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) outv[k_] = 0.01f * (float)(f0_[k_ & 7] + f1_[k_ & 7]); \
+        for (int it_ = 0; it_ < 600; ++it_) { _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) outv[k_] = fmaf(outv[k_], 0.999f, 1e-4f); } \
+    } while (0)
+#else
+#define WS_EVAL(W_, B_, f0_, f1_) mlp_eval<KA>(W_, B_, pa.n_hidden, f0_, f1_, leak, outv)
+#endif
+template <int MODE, bool EXT, int KA>
+__global__ __launch_bounds__(WSBLOCK) void policy_rollout_ws_kernel(const StepArgs a, const PolicyArgs pa)
+{
+    constexpr int A = ModeTraits<MODE>::A;
+    constexpr int OD = EXT ? 9 : 6;
+    extern __shared__ uint4 lds_dyn[];
+    uint4* lds_w = lds_dyn;
+    {
+        const int total = 2 * pa.nfrag * 64;
+        for (int k = threadIdx.x; k < total; k += WSBLOCK) lds_w[k] = pa.frags[k];
+        float* lb = (float*)(lds_w + total);
+        for (int k = threadIdx.x; k < 2 * pa.nblk * 32; k += WSBLOCK) lb[k] = pa.bias[k];
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool role_m = wave >= 4;
+    const int g = wave & 3;
+    float* grp = (float*)lds_dyn + policy_lds_io_offset_floats(pa) + g * WS_GROUP_FLOATS;
+    float* lds_io = grp;                         // E-wave row staging
+    float* obs_mb = grp + 64 * 9;                // o_t: one row of 9 per lane (stride 9 is conflict-free)
+    float* pre_mb = grp + 64 * 9 * 2;            // [2][64][9] pre-reset observation of a cut episode, by step parity
+    float* mu_mb = grp + 64 * 9 * 4;             // actor mean, stride 9
+    float* v_mb = grp + 64 * 9 * 5;              // [2][64] V(o_t), by step parity
+    float* vpre_mb = v_mb + 128;                 // [2][64] V(pre-reset o_t), by step parity
+    int* seq = (int*)(vpre_mb + 128);            // [0] observations posted, [1] means posted, [2] values posted, [4..5] pre flags
+    int* flag = seq + 4;
+    const uint4* Wpi = lds_w;
+    const uint4* Wv = lds_w + pa.nfrag * 64;
+    const float* Bpi = (const float*)(lds_dyn + 2 * pa.nfrag * 64);
+    const float* Bv = Bpi + pa.nblk * 32;
+    const _Float16 leak = (_Float16)pa.leak;
+    const int n = a.n;
+    const int wave0 = blockIdx.x * 256 + g * 64;
+    const int i = wave0 + lane;
+    const bool live = i < n;
+    const int il = live ? i : n - 1;
+    if (!role_m && lane < 8) seq[lane] = 0;
+    __syncthreads();                                                         // weights staged, sequence words cleared
+    if (wave0 >= n) return;                                                  // a pair without envs: both waves leave
+
+    if (role_m) {
+        // ------------------------------------------------------------------------------------ M-wave
+        half8 in0, in1;
+        float o[9], outv[8];
+        auto frags_from = [&](const float* mb, half8& f0, half8& f1) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) o[k] = k < OD ? mb[lane * 9 + k] : 0.0f;
+            obs_to_frags<OD>(o, f0, f1);
+        };
+        for (int t = 0; t <= pa.T; ++t) {
+            ws_wait(&seq[0], t + 1);                                         // o_t posted (and step t-1's pre flag)
+            frags_from(obs_mb, in0, in1);
+            if (t < pa.T) {
+                WS_EVAL(Wpi, Bpi, in0, in1);
+#pragma unroll
+                for (int k = 0; k < A; ++k) mu_mb[lane * 9 + k] = outv[k];
+                ws_post(&seq[1], t + 1, lane);                               // mu_t posted
+            }
+            WS_EVAL(Wv, Bv, in0, in1);
+            v_mb[(t & 1) * 64 + lane] = outv[0];
+            if (t > 0 && flag[(t - 1) & 1] != 0) {                           // step t-1 cut an episode that was re-drawn
+                half8 p0, p1;
+                frags_from(pre_mb + ((t - 1) & 1) * (64 * 9), p0, p1);
+                WS_EVAL(Wv, Bv, p0, p1);
+                vpre_mb[(t & 1) * 64 + lane] = outv[0];
+            }
+            ws_post(&seq[2], t + 1, lane);                                   // V(o_t) (and V of the pre-reset o_t) posted
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------------- E-wave
+    Env s;
+    Current cur = {0.0f, 0.0f, 0.0f, 0.0f, 0u};
+    float vc0 = 0.0f, beta0 = 0.0f;
+    bool ep_dirty = false, rf_dirty = (MODE == MODE_FULL);
+    float o[9];
+    const Vessel ve = vessel_from_args(a.v0);
+    const int64_t stride_a = (int64_t)n * A, stride_o = (int64_t)n * OD;
+    const int64_t w_a = (int64_t)wave0 * A, w_o = (int64_t)wave0 * OD;
+    const int64_t rem_a = stride_a - w_a, rem_o = stride_o - w_o;
+    float pre[A];
+    load_env(a, il, s);
+    sincos_lean(s.psi, s.sn, s.cs);
+    if (a.cur_vc) {
+        cur.vc = a.cur_vc[il]; cur.beta = a.cur_beta[il];
+        if (a.current_drift) { vc0 = a.cur_vc0[il]; beta0 = a.cur_beta0[il]; cur.ctr = a.drift_ctr[il]; }
+        current_components(cur);
+    }
+    uint32_t episode = a.auto_reset ? (uint32_t)a.episode[il] : 0u;
+    {
+        float sr_, cr_;
+        bool same_;
+        make_obs(s.N, s.E, s.psi, s.u, s.v, s.r, s.refN, s.refE, s.refPsi, s.pt, a.wrap_mode == WRAP_REFERENCE, o, sr_, cr_, same_);
+    }
+#pragma unroll
+    for (int k = 0; k < OD; ++k) obs_mb[lane * 9 + k] = o[k];
+    ws_post(&seq[0], 1, lane);                                               // o_0 posted
+    if (pa.noise) load_rows<A, 64>(pa.noise + w_a, rem_a, lane, pre);
+    int next_switch = 0;
+    bool boot_wanted = false, was_reset = false;                             // of the step whose boot row is still owed
+    for (int t = 0; t < pa.T; ++t) {
+        wave_store_rows<OD>(lds_io, pa.obs_out, (int64_t)t * stride_o + w_o, rem_o, o, lane, a.obs_bf16 != 0);
+        const bool q_boot_wanted = boot_wanted, q_was_reset = was_reset;     // flags of step t-1
+        ws_wait(&seq[1], t + 1);                                             // mu_t posted
+        float act[A], mu[A];
+        float logp = 0.0f;
+#pragma unroll
+        for (int k = 0; k < A; ++k) mu[k] = mu_mb[lane * 9 + k];
+        if (pa.noise) {
+            float xi[A];
+            wave_rows_from_regs<A>(lds_io, pre, xi, lane);
+            if (t + 1 < pa.T) load_rows<A, 64>(pa.noise + (int64_t)(t + 1) * stride_a + w_a, rem_a, lane, pre);
+#pragma unroll
+            for (int k = 0; k < A; ++k) {
+                act[k] = fmaf(pa.std[k], xi[k], mu[k]);
+                const float z = (act[k] - mu[k]) * pa.inv_std_eps[k];
+                logp += fmaf(-0.5f * z, z, pa.logp_const[k]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < A; ++k) { act[k] = mu[k]; logp += pa.logp_const[k]; }
+        }
+        wave_store_rows<A>(lds_io, pa.act_out, (int64_t)t * stride_a + w_a, rem_a, act, lane);
+        bool has_ref = false;
+        float nrN = 0.0f, nrE = 0.0f, nrP = 0.0f;
+        if (next_switch < pa.n_switch && pa.switch_step[next_switch] == t) {
+            const float* rp = pa.refs + (int64_t)next_switch * 3 * n;
+            nrN = rp[il]; nrE = rp[(int64_t)n + il]; nrP = rp[2 * (int64_t)n + il];
+            has_ref = true; rf_dirty = true;
+            ++next_switch;
+        }
+        StepOut out;
+#ifdef DPENV_WS_DEBUG_RESEED
+        sincos_lean(s.psi, s.sn, s.cs);
+#endif
+        env_step<MODE, EXT>(a, ve, s, act, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out);
+        if (a.current_drift) current_drift_step(a, cur, vc0, beta0, a.env_id_base + i);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o[k] = out.o[k];
+        const bool do_reset = a.auto_reset && out.d != 0u && live;
+        const bool terminal = (out.d & DONE_TERMINAL) != 0u;
+        const bool ended = (out.d != 0u) || (t == pa.T - 1);
+        boot_wanted = ended && !terminal;                                    // ppo.py:311
+        was_reset = do_reset;
+        // the critic is owed the PRE-reset observation only where a cut (not terminated) episode is re-drawn
+        const bool post_pre = __ballot(do_reset && boot_wanted) != 0ull;
+        if (post_pre) {
+            float* pm = pre_mb + (t & 1) * (64 * 9);
+#pragma unroll
+            for (int k = 0; k < OD; ++k) pm[lane * 9 + k] = o[k];
+        }
+        if (lane == 0) flag[t & 1] = post_pre ? 1 : 0;
+        if (__ballot(do_reset) != 0ull) {
+            if (do_reset) {
+                env_auto_reset<MODE>(a, s, a.env_id_base + i, episode, o);
+                ++episode; ep_dirty = true; rf_dirty = true;
+            }
+        }
+        // V(o_t) must have been read by the critic's input stage before o_{t+1} replaces it: the M-wave reads obs_mb
+        // right after it saw seq[0] = t + 1 and BEFORE it posts mu_t, which this wave has already waited for
+#pragma unroll
+        for (int k = 0; k < OD; ++k) obs_mb[lane * 9 + k] = o[k];           // the next policy input
+        ws_post(&seq[0], t + 2, lane);                                       // o_{t+1} (and this step's pre flag) posted
+        if (live) {
+            (pa.rew + (int64_t)t * n)[(unsigned)i] = out.reward;
+            (pa.done + (int64_t)t * n)[(unsigned)i] = (uint8_t)out.d;
+            (pa.logp + (int64_t)t * n)[(unsigned)i] = logp;
+        }
+        ws_wait(&seq[2], t + 1);                                             // V(o_t), V(pre-reset o_t) posted
+        if (live) {
+            const float v_t = v_mb[(t & 1) * 64 + lane];
+            (pa.val + (int64_t)t * n)[(unsigned)i] = v_t;
+            if (t > 0) (pa.boot + (int64_t)(t - 1) * n)[(unsigned)i] = q_boot_wanted ? (q_was_reset ? vpre_mb[(t & 1) * 64 + lane] : v_t) : 0.0f;
+        }
+    }
+    ws_wait(&seq[2], pa.T + 1);                                              // V(o_T) posted
+    wave_store_rows<OD>(lds_io, pa.last_obs, w_o, rem_o, o, lane, a.obs_bf16 != 0);
+    if (live) {
+        const float v_T = v_mb[(pa.T & 1) * 64 + lane];
+        (pa.boot + (int64_t)(pa.T - 1) * n)[(unsigned)i] = boot_wanted ? (was_reset ? vpre_mb[(pa.T & 1) * 64 + lane] : v_T) : 0.0f;
+        pa.last_val[i] = v_T;
+        store_env(a, i, s, rf_dirty);
+        if (ep_dirty) a.episode[i] = (int)episode;
+        if (a.current_drift) { a.cur_vc[i] = cur.vc; a.cur_beta[i] = cur.beta; a.drift_ctr[i] = cur.ctr; }
+    }
+}
+
 }  // namespace dpenv
 
 using namespace dpenv;
@@ -620,6 +846,16 @@ extern "C" hipError_t dpenv_dev_launch_policy_forward(const PolicyArgs* pa, int 
 template <int MODE, bool EXT, int KA>
 static hipError_t launch_policy_rollout_one(const StepArgs& a, const PolicyArgs& pa, hipStream_t s)
 {
+    if (pa.ws) {
+        // two waves per 64 envs: 512-thread workgroups of 256 envs, one LDS image of the weights + four mailboxes
+        const dim3 grid((a.n + 255) / 256), block(WSBLOCK);
+        const size_t lds = (size_t)2 * pa.nfrag * 64 * 16 + (size_t)2 * pa.nblk * 32 * 4 + (size_t)4 * WS_GROUP_FLOATS * 4;
+        hipError_t e = hipFuncSetAttribute((const void*)policy_rollout_ws_kernel<MODE, EXT, KA>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((policy_rollout_ws_kernel<MODE, EXT, KA>), grid, block, lds, s, a, pa);
+        return hipGetLastError();
+    }
     const dim3 grid((a.n + PBLOCK - 1) / PBLOCK), block(PBLOCK);
     const size_t lds = policy_lds_bytes(pa);
     hipError_t e = hipFuncSetAttribute((const void*)policy_rollout_kernel<MODE, EXT, KA>, hipFuncAttributeMaxDynamicSharedMemorySize,

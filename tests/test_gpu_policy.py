@@ -453,3 +453,54 @@ def test_run_RL_policy_harness_with_the_trained_actor():
             assert torch.equal(res['action_vec'][T // 2 + 1], res['action_vec'][0])
             assert np.allclose(res['ned_ref'][T // 2].cpu().numpy(), 0.0)              # visible one step late (Q4)
         env.close()
+
+
+def test_two_wave_rollout_equals_single_wave_rollout_repeatedly():
+    """The default launch form puts an env wave and a network wave on every SIMD (policy_rollout_ws_kernel); with
+    DPENV_POLICY_WS=0 one wave does both.  Same chains of arithmetic: every row must be identical bit for bit, and must
+    stay so over repeated launches - the env wave once lost lanes 48-63 of packed-fp32 results now and then while the
+    network wave's MFMAs ran beside it (hence -fno-slp-vectorize; tools/ws_race_check.py)."""
+    import os
+    from ml4ca_amd.policy import policy_rollout
+    torch = torch_()
+    n, T = 2000 + 11, 45
+    kw = dict(auto_reset=True, max_ep_len=40, seed=8, current=True, current_drift=True)
+    outs = {}
+    old = os.environ.get('DPENV_POLICY_WS')
+    try:
+        for ws, reps in (('0', 1), ('1', 25)):
+            os.environ['DPENV_POLICY_WS'] = ws
+            for rep in range(reps):
+                env, _ = H.make_pair('final_cont', n, **kw)
+                make_ac(9, 7, (80, 80, 80), seed=2, device=env.device).upload(env)
+                g = torch.Generator(device=env.device).manual_seed(1)
+                env.set_current(torch.full((n,), 0.2, device=env.device), torch.full((n,), 2.3, device=env.device))
+                env.reset()
+                refs = torch.randn((2, 3, n), generator=g, device=env.device)
+                noise = torch.randn((T, n, 7), generator=g, device=env.device) if rep % 2 else None
+                out = policy_rollout(env, T, noise=noise, switch_steps=(3, 30), refs=refs)
+                st, ctr = env.get_state()
+                got = {k: v.clone() for k, v in out.items()}
+                got['state'], got['ctr'] = st, ctr
+                key = 'noise' if noise is not None else 'det'
+                if ws == '0' and key not in outs:
+                    outs[key] = got
+                    if 'noise' not in outs:          # the single-wave reference for the other input too
+                        noise2 = torch.randn((T, n, 7), generator=g, device=env.device)
+                        env_b, _ = H.make_pair('final_cont', n, **kw)
+                        make_ac(9, 7, (80, 80, 80), seed=2, device=env_b.device).upload(env_b)
+                        env_b.set_current(torch.full((n,), 0.2, device=env.device), torch.full((n,), 2.3, device=env.device))
+                        env_b.reset()
+                        ob = policy_rollout(env_b, T, noise=noise2, switch_steps=(3, 30), refs=refs)
+                        sb, cb = env_b.get_state()
+                        outs['noise'] = {k: v.clone() for k, v in ob.items()}
+                        outs['noise']['state'], outs['noise']['ctr'] = sb, cb
+                    continue
+                want = outs[key]
+                for k in want:
+                    assert torch.equal(got[k], want[k]), 'two-wave launch, repetition %d: %s differs' % (rep, k)
+    finally:
+        if old is None:
+            os.environ.pop('DPENV_POLICY_WS', None)
+        else:
+            os.environ['DPENV_POLICY_WS'] = old

@@ -88,6 +88,21 @@ __device__ __forceinline__ half8 act_pack(const float16v& acc, int s, _Float16 l
     return r;
 }
 
+// issue order hint for one pipeline stage: the LDS reads of the block after next first (KS weight fragments + 4 for the
+// bias tile), then N x (1 MFMA, 4 VALU) - the MFMAs of the block being multiplied against the packing of the block
+// before it
+template <int KS>
+__device__ __forceinline__ void interleave_stage()
+{
+    __builtin_amdgcn_sched_group_barrier(0x100, KS + 4, 0);
+#pragma unroll
+    for (int k = 0; k < 2 * KS; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);          // a stage draws only on its own instructions
+}
+
 // Evaluate one MLP for the 64 envs of this wave.  in0 / in1: first-layer B fragments of env tiles 0-31 / 32-63.
 // out[j], j < 8: output row j of the lane's OWN env.
 //
@@ -114,27 +129,48 @@ __device__ __forceinline__ void mlp_eval(const uint4* W, const float* B, int n_h
         b[2 * mo][0] = act_pack<ACT>(c0, 0, leak); b[2 * mo][1] = act_pack<ACT>(c1, 0, leak);
         if (2 * mo + 1 < KS) { b[2 * mo + 1][0] = act_pack<ACT>(c0, 1, leak); b[2 * mo + 1][1] = act_pack<ACT>(c1, 1, leak); }
     }
+    // hidden -> hidden layers, software-pipelined over the three row-blocks: the MFMAs of block mo+1 are issued between
+    // the activation/packing VALU of block mo (the blocks of one layer are independent; only the last block's packing
+    // is exposed before the next layer can start)
     int fbase = 3, bblk = 0;
+    half8 wn[KS];
     for (int l = 1; l < n_hidden; ++l) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) w[ks] = ldfrag(W, fbase + ks, lane);
+        float16v cb = ldbias(B, bblk, lane);
 #pragma unroll
-        for (int mo = 0; mo < 3; ++mo) {
-            const float16v cb = ldbias(B, bblk + mo, lane);
+        for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(W, fbase + KS + ks, lane);
+        float16v cbn = ldbias(B, bblk + 1, lane);
+        float16v p0 = cb, p1 = cb;                                          // block 0
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            p0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks][0], p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks][1], p1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mo = 1; mo < 3; ++mo) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) w[ks] = wn[ks];
+            cb = cbn;
+            if (mo < 2) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(W, fbase + 2 * KS + ks, lane);
+                cbn = ldbias(B, bblk + 2, lane);
+            }
             float16v c0 = cb, c1 = cb;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks][0], c0, 0, 0, 0);
                 c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks][1], c1, 0, 0, 0);
             }
-            // the MFMAs above have read w: refill it for the next row-block while they execute
-            if (mo < 2) {
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) w[ks] = ldfrag(W, fbase + (mo + 1) * KS + ks, lane);
-            }
-            bn[2 * mo][0] = act_pack<ACT>(c0, 0, leak); bn[2 * mo][1] = act_pack<ACT>(c1, 0, leak);
-            if (2 * mo + 1 < KS) { bn[2 * mo + 1][0] = act_pack<ACT>(c0, 1, leak); bn[2 * mo + 1][1] = act_pack<ACT>(c1, 1, leak); }
+            bn[2 * (mo - 1)][0] = act_pack<ACT>(p0, 0, leak); bn[2 * (mo - 1)][1] = act_pack<ACT>(p1, 0, leak);
+            bn[2 * (mo - 1) + 1][0] = act_pack<ACT>(p0, 1, leak); bn[2 * (mo - 1) + 1][1] = act_pack<ACT>(p1, 1, leak);
+            interleave_stage<KS>();
+            p0 = c0; p1 = c1;
         }
+        bn[4][0] = act_pack<ACT>(p0, 0, leak); bn[4][1] = act_pack<ACT>(p1, 0, leak);
+        if (5 < KS) { bn[KS - 1][0] = act_pack<ACT>(p0, 1, leak); bn[KS - 1][1] = act_pack<ACT>(p1, 1, leak); }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) { b[ks][0] = bn[ks][0]; b[ks][1] = bn[ks][1]; }
         fbase += 3 * KS;
@@ -193,21 +229,6 @@ __device__ __forceinline__ void pack_block(const Acc2& a, half8 (&dst)[KA & 15][
     constexpr int KS = KA & 15, ACT = KA >> 4;
     dst[2 * mo][0] = act_pack<ACT>(a.c0, 0, leak); dst[2 * mo][1] = act_pack<ACT>(a.c1, 0, leak);
     if (2 * mo + 1 < KS) { dst[2 * mo + 1][0] = act_pack<ACT>(a.c0, 1, leak); dst[2 * mo + 1][1] = act_pack<ACT>(a.c1, 1, leak); }
-}
-
-// issue order hint for one pipeline stage: the LDS reads of the block after next first (KS weight fragments + 4 for the
-// bias tile), then N x (1 MFMA, 4 VALU) - the MFMAs of the block being multiplied against the packing of the block
-// before it
-template <int KS>
-__device__ __forceinline__ void interleave_stage()
-{
-    __builtin_amdgcn_sched_group_barrier(0x100, KS + 4, 0);
-#pragma unroll
-    for (int k = 0; k < 2 * KS; ++k) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);          // a stage draws only on its own instructions
 }
 
 template <int KA>

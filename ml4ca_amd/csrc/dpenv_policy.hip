@@ -624,6 +624,11 @@ __device__ __forceinline__ void ws_wait(int* p, int v)
     while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < v)
         __builtin_amdgcn_s_sleep(2);
 }
+#ifdef DPENV_WS_PROFILE
+#define WS_WAIT_T(acc, p, v) do { const uint64_t t0_ = __builtin_amdgcn_s_memtime(); ws_wait(p, v); acc += __builtin_amdgcn_s_memtime() - t0_; } while (0)
+#else
+#define WS_WAIT_T(acc, p, v) ws_wait(p, v)
+#endif
 
 #ifdef DPENV_WS_DEBUG_NOMFMA
 #define WS_EVAL(W_, B_, f0_, f1_)                                                   \
@@ -677,13 +682,14 @@ __global__ __launch_bounds__(WSBLOCK) void policy_rollout_ws_kernel(const StepAr
         // ------------------------------------------------------------------------------------ M-wave
         half8 in0, in1;
         float o[9], outv[8];
+        uint64_t w_obs = 0; const uint64_t t_start = __builtin_amdgcn_s_memtime(); (void)t_start;
         auto frags_from = [&](const float* mb, half8& f0, half8& f1) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) o[k] = k < OD ? mb[lane * 9 + k] : 0.0f;
             obs_to_frags<OD>(o, f0, f1);
         };
         for (int t = 0; t <= pa.T; ++t) {
-            ws_wait(&seq[0], t + 1);                                         // o_t posted (and step t-1's pre flag)
+            WS_WAIT_T(w_obs, &seq[0], t + 1);                                // o_t posted (and step t-1's pre flag)
             frags_from(obs_mb, in0, in1);
             if (t < pa.T) {
                 WS_EVAL(Wpi, Bpi, in0, in1);
@@ -701,6 +707,9 @@ __global__ __launch_bounds__(WSBLOCK) void policy_rollout_ws_kernel(const StepAr
             }
             ws_post(&seq[2], t + 1, lane);                                   // V(o_t) (and V of the pre-reset o_t) posted
         }
+#ifdef DPENV_WS_PROFILE
+        if (live && pa.T >= 5) { (pa.logp + (int64_t)3 * n)[(unsigned)i] = (float)w_obs; (pa.logp + (int64_t)4 * n)[(unsigned)i] = (float)(__builtin_amdgcn_s_memtime() - t_start); }
+#endif
         return;
     }
 
@@ -733,11 +742,12 @@ __global__ __launch_bounds__(WSBLOCK) void policy_rollout_ws_kernel(const StepAr
     ws_post(&seq[0], 1, lane);                                               // o_0 posted
     if (pa.noise) load_rows<A, 64>(pa.noise + w_a, rem_a, lane, pre);
     int next_switch = 0;
+    uint64_t w_mu = 0, w_v = 0; const uint64_t t_start = __builtin_amdgcn_s_memtime(); (void)t_start;
     bool boot_wanted = false, was_reset = false;                             // of the step whose boot row is still owed
     for (int t = 0; t < pa.T; ++t) {
         wave_store_rows<OD>(lds_io, pa.obs_out, (int64_t)t * stride_o + w_o, rem_o, o, lane, a.obs_bf16 != 0);
         const bool q_boot_wanted = boot_wanted, q_was_reset = was_reset;     // flags of step t-1
-        ws_wait(&seq[1], t + 1);                                             // mu_t posted
+        WS_WAIT_T(w_mu, &seq[1], t + 1);                                     // mu_t posted
         float act[A], mu[A];
         float logp = 0.0f;
 #pragma unroll
@@ -802,7 +812,7 @@ __global__ __launch_bounds__(WSBLOCK) void policy_rollout_ws_kernel(const StepAr
             (pa.done + (int64_t)t * n)[(unsigned)i] = (uint8_t)out.d;
             (pa.logp + (int64_t)t * n)[(unsigned)i] = logp;
         }
-        ws_wait(&seq[2], t + 1);                                             // V(o_t), V(pre-reset o_t) posted
+        WS_WAIT_T(w_v, &seq[2], t + 1);                                      // V(o_t), V(pre-reset o_t) posted
         if (live) {
             const float v_t = v_mb[(t & 1) * 64 + lane];
             (pa.val + (int64_t)t * n)[(unsigned)i] = v_t;
@@ -810,6 +820,9 @@ __global__ __launch_bounds__(WSBLOCK) void policy_rollout_ws_kernel(const StepAr
         }
     }
     ws_wait(&seq[2], pa.T + 1);                                              // V(o_T) posted
+#ifdef DPENV_WS_PROFILE
+    if (live && pa.T >= 5) { (pa.logp + (int64_t)0 * n)[(unsigned)i] = (float)w_mu; (pa.logp + (int64_t)1 * n)[(unsigned)i] = (float)w_v; (pa.logp + (int64_t)2 * n)[(unsigned)i] = (float)(__builtin_amdgcn_s_memtime() - t_start); }
+#endif
     wave_store_rows<OD>(lds_io, pa.last_obs, w_o, rem_o, o, lane, a.obs_bf16 != 0);
     if (live) {
         const float v_T = v_mb[(pa.T & 1) * 64 + lane];

@@ -20,12 +20,14 @@ rows = list(csv.DictReader(open(glob.glob(src + '/kt/*/*_kernel_trace.csv')[0]))
 
 
 def kname(k):
+    if 'policy_rollout_ws_kernel' in k:
+        return 'policy_rollout_ws_kernel'
     if 'policy_rollout_kernel' in k:
         return 'policy_rollout_kernel'
     return 'step_kernel' if 'step_kernel' in k else 'rollout_kernel' if 'rollout_kernel' in k else None
 
 
-for kn in ('step_kernel', 'rollout_kernel', 'policy_rollout_kernel'):
+for kn in ('step_kernel', 'rollout_kernel', 'policy_rollout_kernel', 'policy_rollout_ws_kernel'):
     ks = [r for r in rows if kname(r['Kernel_Name']) == kn]
     if not ks:
         continue
@@ -44,7 +46,7 @@ for name in ('pmc_fetch', 'pmc_write', 'pmc_sq'):
             agg[(kn, r['Counter_Name'])].append(float(r['Counter_Value']))
     for (kn, c), v in agg.items():
         out['kernels'].setdefault(kn, {}).setdefault('pmc_median_per_launch', {})[c] = st.median(v)
-steps_per_launch = {'step_kernel': 1, 'rollout_kernel': 50, 'policy_rollout_kernel': 50}
+steps_per_launch = {'step_kernel': 1, 'rollout_kernel': 50, 'policy_rollout_kernel': 50, 'policy_rollout_ws_kernel': 50}
 for kn, k in out['kernels'].items():
     p = k.get('pmc_median_per_launch', {})
     if 'FETCH_SIZE' in p and 'WRITE_SIZE' in p:

@@ -230,7 +230,9 @@ typedef struct dpenv_policy_rollout_io {
     int32_t switch_step[DPENV_MAX_SWITCH];
     const float* refs;       /* [n_switch][3][n] */
 } dpenv_policy_rollout_io;
-/* Requires AOS layouts. */
+/* Requires AOS layouts.  Launch form: by default every 64 envs get an env wave and a network wave (512-thread
+ * workgroups); the environment variable DPENV_POLICY_WS=0 selects the one-wave-per-64-envs kernel instead.  Both forms
+ * write identical rows. */
 int dpenv_policy_rollout(dpenv_handle h, const dpenv_policy_rollout_io* io, dpenv_stream s);
 
 /* Parity/test access to the library-owned state in the canonical format above. */

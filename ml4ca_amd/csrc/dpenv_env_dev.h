@@ -379,36 +379,34 @@ struct StepOut {
     uint32_t d;           // DONE_* bits
 };
 
-// ENV:104-133 for one env: decode, command map, plant, observation, reward, termination, late new_ref.
-// cur = constant current (vcN, vcE in NED) present.
-template <int MODE, bool EXT>
-__device__ __forceinline__ void env_step(const StepArgs& a, const Vessel& ve, Env& s, const float* act, bool has_ref,
-                                         float nrN, float nrE, float nrP, bool cur, float vcN, float vcE, StepOut& out)
-{
-    const float ang_prev[3] = {s.ang[0], s.ang[1], s.ang[2]};   // ENV:102
-    const float pt_old[3] = {s.pt[0], s.pt[1], s.pt[2]};
+// ENV:104-133 for one env in three pieces, so that a launch can give them to different waves (rollout_ws_kernel):
+// env_decode (action -> commands and wrench), env_plant (the integrator), env_observe (observation, reward, termination,
+// late new_ref).  env_step is their composition.
+struct Wrench {
+    float thr[3];         // thrust commands, percent
+    float tx, ty, tn;     // body-frame wrench of the three thrusters
+};
 
-    // ---- action decode ENV:104-110, scale_and_clip ENV:215-225, command map ENV:117-122 -------------
-    float thr[3];
-    thr[0] = clipf(act[0] * 100.0f, 100.0f);
-    thr[1] = clipf(act[1] * 100.0f, 100.0f);
-    thr[2] = clipf(act[2] * 100.0f, 100.0f);
+// ---- action decode ENV:104-110, scale_and_clip ENV:215-225, command map ENV:117-122, force map --------------
+template <int MODE>
+__device__ __forceinline__ void env_decode(const Vessel& ve, float ang[3], const float* act, Wrench& w)
+{
+    w.thr[0] = clipf(act[0] * 100.0f, 100.0f);
+    w.thr[1] = clipf(act[1] * 100.0f, 100.0f);
+    w.thr[2] = clipf(act[2] * 100.0f, 100.0f);
     if (MODE == MODE_FULL) {
-        s.ang[0] = clipf(act[3] * kPi, kPi); s.ang[1] = clipf(act[4] * kPi, kPi); s.ang[2] = clipf(act[5] * kPi, kPi);
+        ang[0] = clipf(act[3] * kPi, kPi); ang[1] = clipf(act[4] * kPi, kPi); ang[2] = clipf(act[5] * kPi, kPi);
     } else if (MODE == MODE_LIMITED) {
-        s.ang[1] = clipf(act[3] * (kPi * 0.5f), kPi * 0.5f); s.ang[2] = clipf(act[4] * (kPi * 0.5f), kPi * 0.5f);
+        ang[1] = clipf(act[3] * (kPi * 0.5f), kPi * 0.5f); ang[2] = clipf(act[4] * (kPi * 0.5f), kPi * 0.5f);
     } else if (MODE == MODE_FINAL_WRAP) {
         // ENV:237-244: wrap_angle(a*pi, deg=False)/pi, evaluated in units of pi (exact in fp32)
         const float w3 = act[3] - 2.0f * floorf((act[3] + 1.0f) * 0.5f);
         const float w4 = act[4] - 2.0f * floorf((act[4] + 1.0f) * 0.5f);
-        s.ang[1] = clipf(w3 * kPi, kPi); s.ang[2] = clipf(w4 * kPi, kPi);
+        ang[1] = clipf(w3 * kPi, kPi); ang[2] = clipf(w4 * kPi, kPi);
     } else if (MODE == MODE_FINAL_CONT) {
         // ENV:227-235: atan2(sin_head, cos_head)/pi, then *pi and clip
-        s.ang[1] = clipf(atan2_lean(act[3], act[4]), kPi); s.ang[2] = clipf(atan2_lean(act[5], act[6]), kPi);
+        ang[1] = clipf(atan2_lean(act[3], act[4]), kPi); ang[2] = clipf(atan2_lean(act[5], act[6]), kPi);
     }
-
-    // ---- plant: BUILD-OWNED 3-DOF model, n_substeps semi-implicit Euler steps --
-    float tx, ty, tn;
     if (MODE == MODE_FINAL_CONT) {
         // the azimuth is atan2 of the two heads, so its sine and cosine are the normalised heads themselves:
         // no sincos of the angle just computed ((0, 0) -> angle 0 -> (0, 1))
@@ -417,12 +415,18 @@ __device__ __forceinline__ void env_step(const StepArgs& a, const Vessel& ve, En
         const float ip = __builtin_amdgcn_rsqf(np2), is = __builtin_amdgcn_rsqf(ns2);
         sc[0] = (np2 > 0.0f) ? act[3] * ip : 0.0f; sc[1] = (np2 > 0.0f) ? act[4] * ip : 1.0f;
         sc[2] = (ns2 > 0.0f) ? act[5] * is : 0.0f; sc[3] = (ns2 > 0.0f) ? act[6] * is : 1.0f;
-        thrust_map(ve, thr, s.ang, tx, ty, tn, sc);
+        thrust_map(ve, w.thr, ang, w.tx, w.ty, w.tn, sc);
     } else {
-        thrust_map(ve, thr, s.ang, tx, ty, tn);
+        thrust_map(ve, w.thr, ang, w.tx, w.ty, w.tn);
     }
-    float N = s.N, E = s.E, psi = s.psi, u = s.u, v = s.v, r = s.r;
-    float sn = s.sn, cs = s.cs;
+}
+
+// ---- plant: BUILD-OWNED 3-DOF model, n_substeps semi-implicit Euler steps ---------------
+// (sn, cs) = sin/cos of psi on entry; on exit the state after the step.  The caller refreshes (sn, cs) for the heading
+// reached and converts the velocity back to over-ground with it (env_plant_finish).
+__device__ __forceinline__ void env_plant(const StepArgs& a, const Vessel& ve, float tx, float ty, float tn, bool cur, float vcN,
+                                          float vcE, float& N, float& E, float& psi, float& u, float& v, float& r, float sn, float cs)
+{
     if (cur) {
         u -= fmaf(cs, vcN, sn * vcE);      // relative velocity nu_r = nu - R(psi)^T v_c
         v -= fmaf(cs, vcE, -(sn * vcN));
@@ -471,24 +475,25 @@ __device__ __forceinline__ void env_step(const StepArgs& a, const Vessel& ve, En
         N = fmaf(hn, vcN, N);
         E = fmaf(hn, vcE, E);
     }
-    // exact sin/cos of the heading reached: needed by the observation, by the current term and by the next step
-    const bool deg = (a.wrap_mode == WRAP_REFERENCE);
-    float* o = out.o;
-    bool same;
-    float se, ce;
-    {
-        // the observation only depends on nu through o[3..5]; compute the frame first, patch nu after
-        make_obs(N, E, psi, 0.0f, 0.0f, 0.0f, s.refN, s.refE, s.refPsi, pt_old, deg, o, se, ce, same);
-        if (!same) sincos_lean(psi, se, ce);
-    }
+}
+
+// back to velocity over ground with the exact sin/cos (se, ce) of the heading reached
+__device__ __forceinline__ void env_plant_finish(bool cur, float vcN, float vcE, float se, float ce, float& u, float& v)
+{
     if (cur) {
         u += fmaf(ce, vcN, se * vcE);
         v += fmaf(ce, vcE, -(se * vcN));
     }
-    o[3] = u; o[4] = v; o[5] = r;
-    s.N = N; s.E = E; s.psi = psi; s.u = u; s.v = v; s.r = r;
-    s.sn = se; s.cs = ce;
+}
 
+// ---- reward ENV:253-325, termination ENV:207-213, fault check, late new_ref ENV:131, bookkeeping ENV:126 ---------
+// o[0..2], o[6..8] filled by make_obs for the new pose; o[3..5] = the new velocity; act only for the non-finite check
+template <int MODE, bool EXT>
+__device__ __forceinline__ void env_observe(const StepArgs& a, Env& s, const float* act, const Wrench& w, const float pt_old[3],
+                                            const float ang_prev[3], bool has_ref, float nrN, float nrE, float nrP, StepOut& out)
+{
+    float* o = out.o;
+    const float* thr = w.thr;
     float p_der = 0.0f;
     const float p_vel = -sqrt_hw(fmaf(o[3] * o[3], 0.5f, fmaf(o[4] * o[4], 0.5f, o[5] * o[5])));   // ENV:267-273
     const float rr2 = fmaf(o[0], o[0], o[1] * o[1]);
@@ -523,7 +528,7 @@ __device__ __forceinline__ void env_step(const StepArgs& a, const Vessel& ve, En
     {
         // any NaN/Inf in the state or in the action poisons the sum (a NaN thrust would otherwise be clipped to a
         // legal command by fminf/fmaxf and vanish)
-        float chk = N + E + psi + u + v + r;
+        float chk = s.N + s.E + s.psi + s.u + s.v + s.r;
 #pragma unroll
         for (int k = 0; k < ModeTraits<MODE>::A; ++k) chk += act[k];
         if (!(fabsf(chk) <= 3.0e38f)) d |= DONE_TERMINAL | DONE_FAULT;
@@ -533,6 +538,35 @@ __device__ __forceinline__ void env_step(const StepArgs& a, const Vessel& ve, En
     if (a.max_ep_len > 0 && s.steps >= a.max_ep_len) d |= DONE_TIMELIMIT;   // ppo.py:304
     s.pt[0] = thr[0]; s.pt[1] = thr[1]; s.pt[2] = thr[2];   // ENV:126
     out.d = d;
+}
+
+// ENV:104-133 for one env: decode, command map, plant, observation, reward, termination, late new_ref.
+// cur = constant current (vcN, vcE in NED) present.
+template <int MODE, bool EXT>
+__device__ __forceinline__ void env_step(const StepArgs& a, const Vessel& ve, Env& s, const float* act, bool has_ref,
+                                         float nrN, float nrE, float nrP, bool cur, float vcN, float vcE, StepOut& out)
+{
+    const float ang_prev[3] = {s.ang[0], s.ang[1], s.ang[2]};   // ENV:102
+    const float pt_old[3] = {s.pt[0], s.pt[1], s.pt[2]};
+    Wrench w;
+    env_decode<MODE>(ve, s.ang, act, w);
+    float N = s.N, E = s.E, psi = s.psi, u = s.u, v = s.v, r = s.r;
+    env_plant(a, ve, w.tx, w.ty, w.tn, cur, vcN, vcE, N, E, psi, u, v, r, s.sn, s.cs);
+    // exact sin/cos of the heading reached: needed by the observation, by the current term and by the next step
+    const bool deg = (a.wrap_mode == WRAP_REFERENCE);
+    float* o = out.o;
+    bool same;
+    float se, ce;
+    {
+        // the observation only depends on nu through o[3..5]; compute the frame first, patch nu after
+        make_obs(N, E, psi, 0.0f, 0.0f, 0.0f, s.refN, s.refE, s.refPsi, pt_old, deg, o, se, ce, same);
+        if (!same) sincos_lean(psi, se, ce);
+    }
+    env_plant_finish(cur, vcN, vcE, se, ce, u, v);
+    o[3] = u; o[4] = v; o[5] = r;
+    s.N = N; s.E = E; s.psi = psi; s.u = u; s.v = v; s.r = r;
+    s.sn = se; s.cs = ce;
+    env_observe<MODE, EXT>(a, s, act, w, pt_old, ang_prev, has_ref, nrN, nrE, nrP, out);
 }
 
 // auto-reset of one finished env: ENV:135-194 with the training sampler; returns the new episode's first obs

@@ -341,11 +341,21 @@ __device__ __forceinline__ void mlp_eval2(const uint4* Wp, const uint4* Wv, cons
 template <int OD>
 __device__ __forceinline__ void obs_to_frags(const float o[9], half8& in0, half8& in1)
 {
+    // The f32 observation is what gets rounded to f16, whichever kernel produced it: without the barrier the compiler
+    // folds the last FMA of an observation element computed in this kernel into v_fma_mixlo_f16 (ONE rounding), while a
+    // row that came through memory or an LDS mailbox is rounded twice - about one env in a thousand then sees a
+    // different f16 input, and the launch forms of the rollout stop being bit-identical.
+    float x[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        x[k] = o[k];
+        if (k < OD) asm volatile("" : "+v"(x[k]));
+    }
     half8 P, Q;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) P[k] = (_Float16)(k < OD ? o[k] : 0.0f);
+    for (int k = 0; k < 8; ++k) P[k] = (_Float16)(k < OD ? x[k] : 0.0f);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) Q[k] = (_Float16)((8 + k) < OD ? o[(8 + k) < 9 ? (8 + k) : 8] : 0.0f);
+    for (int k = 0; k < 8; ++k) Q[k] = (_Float16)((8 + k) < OD ? x[(8 + k) < 9 ? (8 + k) : 8] : 0.0f);
     Q[7] = (_Float16)1.0f;
     const uint4 p = __builtin_bit_cast(uint4, P), q = __builtin_bit_cast(uint4, Q);
     uint4 a, b;

@@ -504,3 +504,58 @@ def test_two_wave_rollout_equals_single_wave_rollout_repeatedly():
             os.environ.pop('DPENV_POLICY_WS', None)
         else:
             os.environ['DPENV_POLICY_WS'] = old
+
+
+@pytest.mark.parametrize('case', range(12))
+def test_two_wave_rollout_random_configurations(case):
+    """The two launch forms of dpenv_policy_rollout against each other over drawn configurations: variant, observation
+    width, network shape and activation, ragged env counts (partly filled waves and pairs without envs), auto-reset
+    with short episodes, current with drift, bf16 rows, setpoint switches, noise on/off, odd T.  Every output block and
+    the final state must be identical bit for bit."""
+    import os
+    from ml4ca_amd.policy import ActorCritic, policy_rollout
+    torch = torch_()
+    rng = np.random.RandomState(4200 + case)
+    mode = ['full', 'simple', 'limited', 'final_wrap', 'final_cont'][rng.randint(5)]
+    ext = bool(rng.randint(2)) and mode != 'simple'
+    n = int(rng.choice([1, 63, 65, 200, 257, 1000, 2049]))
+    T = int(rng.choice([1, 2, 7, 30, 61]))
+    hidden = [(80, 80, 80), (64,), (96, 96), (33, 33, 33, 33)][rng.randint(4)]
+    activation = ['leaky', 'relu', 'tanh'][rng.randint(3)]
+    kw = dict(auto_reset=bool(rng.randint(2)), max_ep_len=int(rng.choice([20, 40, 800])), seed=int(rng.randint(100)),
+              current=bool(rng.randint(2)), obs_dtype=['float32', 'bfloat16'][rng.randint(2)])
+    kw['current_drift'] = kw['current'] and bool(rng.randint(2))
+    use_noise, n_sw = bool(rng.randint(2)), int(rng.randint(3))
+    switch = tuple(sorted(rng.choice(T, size=min(n_sw, T), replace=False).tolist()))
+    res = {}
+    old = os.environ.get('DPENV_POLICY_WS')
+    try:
+        for ws in ('0', '1'):
+            os.environ['DPENV_POLICY_WS'] = ws
+            env, _ = H.make_pair(mode, n, ext=ext, **kw)
+            ac = ActorCritic(env.num_states, env.num_actions, hidden, seed=case, device=env.device, activation=activation)
+            g = torch.Generator().manual_seed(case)
+            for b in ac.pi_b + ac.v_b:
+                b.copy_((torch.rand(b.shape, generator=g) - 0.5).to(env.device) * 0.4)
+            ac.upload(env)
+            gd = torch.Generator(device=env.device).manual_seed(case)
+            if kw['current']:
+                env.set_current(torch.rand(n, generator=gd, device=env.device) * 0.3, torch.rand(n, generator=gd, device=env.device) * 6.0 - 3.0)
+            env.reset()
+            refs = torch.randn((len(switch), 3, n), generator=gd, device=env.device) if switch else None
+            noise = torch.randn((T, n, env.num_actions), generator=gd, device=env.device) if use_noise else None
+            out = policy_rollout(env, T, noise=noise, switch_steps=switch, refs=refs)
+            st, ctr = env.get_state()
+            res[ws] = {k: v.clone() for k, v in out.items()}
+            res[ws]['state'], res[ws]['ctr'] = st, ctr
+            if kw['current']:
+                res[ws]['vc'], res[ws]['beta'] = env.get_current()
+    finally:
+        if old is None:
+            os.environ.pop('DPENV_POLICY_WS', None)
+        else:
+            os.environ['DPENV_POLICY_WS'] = old
+    for k in res['0']:
+        a_, b_ = res['0'][k], res['1'][k]
+        assert torch.equal(a_.float() if a_.dtype == torch.bfloat16 else a_, b_.float() if b_.dtype == torch.bfloat16 else b_), \
+            '%s differs (mode %s ext %s n %d T %d hidden %s %s %s)' % (k, mode, ext, n, T, hidden, activation, kw)

@@ -671,6 +671,61 @@ def test_full_size_physical_properties():
     assert float((u - u[0]).abs().max()) < 1e-5 and 1.8 < float(u[0]) < 2.05 and float(s[4:6].abs().max()) < 1e-3
 
 
+@pytest.mark.parametrize('case', range(16))
+def test_fused_rollout_equals_single_steps_random_configurations(case):
+    """The fused rollout against single steps over drawn configurations (variant, extended state, layout, auto-reset,
+    termination, current with and without drift, bf16 rows, vessel classes, agent rate, ragged size, switch schedule,
+    launch length): every row, the final state, counters and current bit for bit."""
+    torch = torch_()
+    rng = np.random.RandomState(7100 + case)
+    mode = ['full', 'simple', 'limited', 'final_wrap', 'final_cont'][rng.randint(5)]
+    ext = bool(rng.randint(2)) and mode != 'simple'
+    layout = ['aos', 'soa'][rng.randint(2)]
+    n = int(rng.choice([1, 64, 65, 130, 1000, 4097]))
+    T = int(rng.choice([1, 2, 9, 40]))
+    kw = dict(auto_reset=bool(rng.randint(2)), terminate=bool(rng.randint(2)), time_limit=bool(rng.randint(2)),
+              max_ep_len=int(rng.choice([20, 60, 800])), seed=int(rng.randint(50)), current=bool(rng.randint(2)),
+              obs_dtype=['float32', 'bfloat16'][rng.randint(2)], n_steps=[None, 3, 20, 25][rng.randint(4)],
+              wrap_mode=['reference', 'radians'][rng.randint(2)])
+    kw['current_drift'] = kw['current'] and bool(rng.randint(2))
+    classes = bool(rng.randint(3) == 0)
+    if classes:
+        base = __import__('ml4ca_amd')._lib.default_vessel()
+        kw['vessel_params'] = np.stack([base * (1.0 + 0.1 * k) for k in range(3)]).astype(np.float32)
+    e1, orc = H.make_pair(mode, n, ext=ext, layout=layout, **kw)
+    e2, _ = H.make_pair(mode, n, ext=ext, layout=layout, **kw)
+    A = orc.act_dim
+    acts = rng.normal(0, 0.8, size=(T, n, A)).astype(np.float32)
+    acts_dev = H.to_dev(acts if layout == 'aos' else np.ascontiguousarray(acts.transpose(0, 2, 1)))
+    st = H.to_dev(H.random_state(rng, n, spread=0.5))
+    ctr = H.to_dev(np.zeros((2, n), np.int32))
+    switch = tuple(sorted(rng.choice(T, size=min(int(rng.randint(4)), T), replace=False).tolist()))
+    refs = H.to_dev(rng.uniform(-3, 3, size=(len(switch), 3, n)).astype(np.float32)) if switch else None
+    # identical auxiliary state on both envs
+    if classes:
+        cls = H.to_dev(np.random.RandomState(case).randint(0, 3, size=n).astype(np.int32))
+        e1.set_vessel_class(cls); e2.set_vessel_class(cls)
+    if kw['current']:
+        vc = H.to_dev((0.2 + 0.05 * rng.normal(size=n)).astype(np.float32))
+        beta = H.to_dev(rng.uniform(-3, 3, size=n).astype(np.float32))
+        e1.set_current(vc, beta); e2.set_current(vc, beta)
+    e1.set_state(st, ctr); e2.set_state(st, ctr)
+    obs_r, rew_r, done_r = e2.rollout(acts_dev, switch_steps=switch, refs=refs)
+    for t in range(T):
+        nr = refs[switch.index(t)] if t in switch else None
+        o, r, d, _ = e1.step(acts_dev[t], new_ref=nr)
+        assert torch.equal(o, obs_r[t]), 'obs t=%d' % t
+        assert torch.equal(r, rew_r[t]), 'reward t=%d' % t
+        assert torch.equal(d, done_r[t]), 'done t=%d' % t
+    s1, c1 = e1.get_state()
+    s2, c2 = e2.get_state()
+    assert torch.equal(s1, s2) and torch.equal(c1, c2)
+    if kw['current']:
+        a1, b1 = e1.get_current()
+        a2, b2 = e2.get_current()
+        assert torch.equal(a1, a2) and torch.equal(b1, b2)
+
+
 # --------------------------------------------------------------------------------------------
 # fused rollout == T single steps
 # --------------------------------------------------------------------------------------------

@@ -118,3 +118,25 @@ def test_variant_constants_match_reference_fixtures():
         assert np.allclose([k['default_actions'][i] for i in range(6)], d['default_actions'], rtol=0, atol=1e-15)
         assert list(k['valid_action_indices']) == list(d['valid_action_indices'])
         assert k['num_actions'] == int(d['meta'][3])
+
+
+def test_no_packed_fp32_in_the_kernels_that_share_a_simd_with_mfma():
+    """On MI355X an env wave's packed-fp32 results (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) lost lanes 48-63 now and
+    then while the network wave of the same pair ran MFMAs on that SIMD (tools/ws_race_check.py).
+    The library is therefore built with -fno-slp-vectorize; this compiles the policy translation unit with the
+    Makefile's flags and checks that no packed fp32 arithmetic comes out of the compiler."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc')
+    csrc = os.path.join(ROOT, 'ml4ca_amd', 'csrc')
+    mk = open(os.path.join(csrc, 'Makefile')).read()
+    flags = re.search(r'^CXXFLAGS \?= (.*)$', mk, re.M).group(1).replace('$(BLOCK)', '64').split()
+    assert '-fno-slp-vectorize' in flags
+    asm = subprocess.run([hipcc, '--offload-arch=gfx950'] + flags + ['--cuda-device-only', '-S', '-o', '-',
+                          os.path.join(csrc, 'dpenv_policy.hip')], check=True, capture_output=True, text=True).stdout
+    assert 'v_mfma_f32_32x32x16_f16' in asm
+    packed = sorted(set(re.findall(r'\bv_pk_\w+', asm)))
+    assert all(p.endswith('_f16') for p in packed), packed

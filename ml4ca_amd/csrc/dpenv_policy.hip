@@ -690,6 +690,8 @@ __global__ __launch_bounds__(WSBLOCK) void policy_rollout_ws_kernel(const StepAr
 
     if (role_m) {
         // ------------------------------------------------------------------------------------ M-wave
+        // it is the busy one of the pair (98 % against 60 %): let the SIMD's instruction arbiter prefer it
+        __builtin_amdgcn_s_setprio(3);
         half8 in0, in1;
         float o[9], outv[8];
         uint64_t w_obs = 0; const uint64_t t_start = __builtin_amdgcn_s_memtime(); (void)t_start;

@@ -610,6 +610,20 @@ extern "C" int dpenv_policy_forward(dpenv_handle h, const float* obs, float* mu_
     return DPENV_OK;
 }
 
+#ifdef DPENV_WS_SELFCHECK
+// diagnostic builds only (tools/ws_selfcheck.py): device buffer of mismatch records, see policy_rollout_ws_kernel
+static uint32_t* g_selfcheck_buf = nullptr;
+extern "C" int dpenv_debug_set_buffer(void* p) { g_selfcheck_buf = (uint32_t*)p; return 0; }
+extern "C" hipError_t dpenv_dev_launch_pk_probe(const PolicyArgs* pa, uint32_t* out, float* sink, int blocks, int iters, int variant, int partner,
+                                                hipStream_t s);
+extern "C" int dpenv_debug_pk_probe(dpenv_handle h, void* out, void* sink, int blocks, int iters, int variant, int partner)
+{
+    if (!h || !h->has_policy) return DPENV_EINVAL;
+    HIP_TRY(h, dpenv_dev_launch_pk_probe(&h->pol, (uint32_t*)out, (float*)sink, blocks, iters, variant, partner, nullptr));
+    return DPENV_OK;
+}
+#endif
+
 extern "C" int dpenv_policy_rollout(dpenv_handle h, const dpenv_policy_rollout_io* io, dpenv_stream s)
 {
     if (!h) return DPENV_EINVAL;
@@ -639,6 +653,9 @@ extern "C" int dpenv_policy_rollout(dpenv_handle h, const dpenv_policy_rollout_i
         pa.ws = e ? (e[0] != '0') : 1;
     }
     for (int k = 0; k < io->n_switch; ++k) pa.switch_step[k] = io->switch_step[k];
+#ifdef DPENV_WS_SELFCHECK
+    pa.dbg = g_selfcheck_buf;
+#endif
     HIP_TRY(h, dpenv_dev_launch_policy_rollout(&a, &pa, h->mode, h->cfg.extended_state, (hipStream_t)s));
     return DPENV_OK;
 }

@@ -122,6 +122,7 @@ struct PolicyArgs {
     int32_t n_switch;
     int32_t switch_step[MAX_SWITCH];
     const float* refs;
+    uint32_t* dbg;            // diagnostic builds only (DPENV_WS_SELFCHECK): event records, NULL otherwise
 };
 
 }  // namespace dpenv

@@ -663,7 +663,11 @@ __global__ __launch_bounds__(WSBLOCK) void policy_rollout_ws_kernel(const StepAr
         for (int k = threadIdx.x; k < 2 * pa.nblk * 32; k += WSBLOCK) lb[k] = pa.bias[k];
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#ifdef DPENV_WS_SWAP_ROLES
+    const bool role_m = wave < 4;          // diagnostic: the network waves are the first-dispatched (older) half
+#else
     const bool role_m = wave >= 4;
+#endif
     const int g = wave & 3;
     float* grp = (float*)lds_dyn + policy_lds_io_offset_floats(pa) + g * WS_GROUP_FLOATS;
     float* lds_io = grp;                         // E-wave row staging
@@ -691,7 +695,9 @@ __global__ __launch_bounds__(WSBLOCK) void policy_rollout_ws_kernel(const StepAr
     if (role_m) {
         // ------------------------------------------------------------------------------------ M-wave
         // it is the busy one of the pair (98 % against 60 %): let the SIMD's instruction arbiter prefer it
+#ifndef DPENV_WS_NO_SETPRIO
         __builtin_amdgcn_s_setprio(3);
+#endif
         half8 in0, in1;
         float o[9], outv[8];
         uint64_t w_obs = 0; const uint64_t t_start = __builtin_amdgcn_s_memtime(); (void)t_start;
@@ -788,10 +794,49 @@ __global__ __launch_bounds__(WSBLOCK) void policy_rollout_ws_kernel(const StepAr
             ++next_switch;
         }
         StepOut out;
-#ifdef DPENV_WS_DEBUG_RESEED
-        sincos_lean(s.psi, s.sn, s.cs);
+#ifdef DPENV_WS_SELFCHECK
+        // Diagnostic build only (tools/ws_selfcheck.py): the step is evaluated a second time from opaque copies of the same
+        // inputs AFTER the partner wave has finished its critic (it then only polls), and every field of the two results
+        // is compared bit for bit.  Both evaluations are the same deterministic IEEE arithmetic, so a difference is a
+        // transient fault of the first evaluation (the one that runs beside the partner's MFMAs) - and the record says
+        // which quantity, which lane, by how much.
+        Env sB = s;
+        const float pre6[6] = {s.N, s.E, s.psi, s.u, s.v, s.r};
+        float actB[A];
+#pragma unroll
+        for (int k = 0; k < A; ++k) { actB[k] = act[k]; asm volatile("" : "+v"(actB[k])); }
+        asm volatile("" : "+v"(sB.N), "+v"(sB.E), "+v"(sB.psi), "+v"(sB.u), "+v"(sB.v), "+v"(sB.r), "+v"(sB.sn), "+v"(sB.cs));
+        asm volatile("" : "+v"(sB.refN), "+v"(sB.refE), "+v"(sB.refPsi), "+v"(sB.pt[0]), "+v"(sB.pt[1]), "+v"(sB.pt[2]),
+                          "+v"(sB.ang[0]), "+v"(sB.ang[1]), "+v"(sB.ang[2]), "+v"(sB.steps));
 #endif
         env_step<MODE, EXT>(a, ve, s, act, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out);
+#ifdef DPENV_WS_SELFCHECK
+        {
+            ws_wait(&seq[2], t + 1);                                         // critic(o_t) done: the partner is idle from here
+            StepOut outB;
+            env_step<MODE, EXT>(a, ve, sB, actB, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, outB);
+            const float fa[20] = {s.N, s.E, s.psi, s.u, s.v, s.r, s.sn, s.cs, out.reward, out.o[0], out.o[1], out.o[2], out.o[3],
+                                  out.o[4], out.o[5], out.o[6], out.o[7], out.o[8], __uint_as_float(out.d), s.ang[1]};
+            const float fb[20] = {sB.N, sB.E, sB.psi, sB.u, sB.v, sB.r, sB.sn, sB.cs, outB.reward, outB.o[0], outB.o[1], outB.o[2],
+                                  outB.o[3], outB.o[4], outB.o[5], outB.o[6], outB.o[7], outB.o[8], __uint_as_float(outB.d), sB.ang[1]};
+            uint32_t mask = 0;
+#pragma unroll
+            for (int k = 0; k < 20; ++k) mask |= (__float_as_uint(fa[k]) != __float_as_uint(fb[k])) ? (1u << k) : 0u;
+            if (mask != 0u && pa.dbg != nullptr) {
+                const uint32_t slot = atomicAdd(pa.dbg, 1u);
+                if (slot < 2000u) {
+                    uint32_t* rec = pa.dbg + 4 + (size_t)slot * 60;
+                    rec[0] = (uint32_t)i; rec[1] = (uint32_t)t; rec[2] = mask; rec[3] = (uint32_t)lane;
+#pragma unroll
+                    for (int k = 0; k < 20; ++k) { rec[4 + k] = __float_as_uint(fa[k]); rec[24 + k] = __float_as_uint(fb[k]); }
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) rec[44 + k] = __float_as_uint(pre6[k]);
+#pragma unroll
+                    for (int k = 0; k < A; ++k) rec[50 + k] = __float_as_uint(actB[k]);
+                }
+            }
+        }
+#endif
         if (a.current_drift) current_drift_step(a, cur, vc0, beta0, a.env_id_base + i);
 #pragma unroll
         for (int k = 0; k < 9; ++k) o[k] = out.o[k];
@@ -846,9 +891,18 @@ __global__ __launch_bounds__(WSBLOCK) void policy_rollout_ws_kernel(const StepAr
     }
 }
 
+#ifdef DPENV_WS_SELFCHECK
+#include "dpenv_diag.inc"      // diagnostic builds only: pk_probe_kernel (tools/ws_pk_probe.py)
+#endif
+
 }  // namespace dpenv
 
 using namespace dpenv;
+
+#ifdef DPENV_WS_SELFCHECK
+#define DPENV_DIAG_LAUNCHERS
+#include "dpenv_diag.inc"
+#endif
 
 static size_t policy_lds_bytes(const PolicyArgs& pa)
 {

@@ -120,14 +120,18 @@ def test_variant_constants_match_reference_fixtures():
         assert k['num_actions'] == int(d['meta'][3])
 
 
-def test_no_packed_fp32_in_the_kernels_that_share_a_simd_with_mfma():
-    """On MI355X an env wave's packed-fp32 results (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) lost lanes 48-63 now and
-    then while the network wave of the same pair ran MFMAs on that SIMD (tools/ws_race_check.py).
-    The library is therefore built with -fno-slp-vectorize; this compiles the policy translation unit with the
-    Makefile's flags and checks that no packed fp32 arithmetic comes out of the compiler."""
+def test_no_packed_fp32_in_any_translation_unit():
+    """MI355X hardware interaction (stand-alone reproducer tools/pk_opsel_mfma_hazard.hip):
+    ``v_pk_fma_f32 ... op_sel:[0,1,0]`` / ``[0,0,1]`` - a packed fp32 FMA whose LOW result takes the HIGH register of src1 or
+    src2, which is what the SLP vectoriser makes of ``acc += c * pair.hi`` - now and then returns src2.lo in lanes 48-63 while
+    another wave on the same SIMD has VALU work in the shadow of its MFMAs.  It is between two waves, so no wait-state rule of
+    the compiler covers it.  The library is therefore built without packed fp32 arithmetic at all (-fno-slp-vectorize): this
+    compiles ALL THREE translation units with the Makefile's flags and checks the ISA for (a) that exact operand form and
+    (b) any packed fp32 arithmetic."""
     import re
     import shutil
     import subprocess
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     if not os.path.exists(hipcc):
         pytest.skip('no hipcc')
@@ -135,8 +139,25 @@ def test_no_packed_fp32_in_the_kernels_that_share_a_simd_with_mfma():
     mk = open(os.path.join(csrc, 'Makefile')).read()
     flags = re.search(r'^CXXFLAGS \?= (.*)$', mk, re.M).group(1).replace('$(BLOCK)', '64').split()
     assert '-fno-slp-vectorize' in flags
-    asm = subprocess.run([hipcc, '--offload-arch=gfx950'] + flags + ['--cuda-device-only', '-S', '-o', '-',
-                          os.path.join(csrc, 'dpenv_policy.hip')], check=True, capture_output=True, text=True).stdout
-    assert 'v_mfma_f32_32x32x16_f16' in asm
-    packed = sorted(set(re.findall(r'\bv_pk_\w+', asm)))
-    assert all(p.endswith('_f16') for p in packed), packed
+    units = re.search(r'^SRC := (.*)$', mk, re.M).group(1).split()
+    assert sorted(units) == ['dpenv_api.hip', 'dpenv_kernels.hip', 'dpenv_policy.hip']
+
+    def isa(unit):
+        return subprocess.run([hipcc, '--offload-arch=gfx950'] + flags + ['--cuda-device-only', '-S', '-o', '-', os.path.join(csrc, unit)],
+                              check=True, capture_output=True, text=True).stdout
+
+    with ThreadPoolExecutor(3) as ex:
+        asm = dict(zip(units, ex.map(isa, units)))
+    assert 'v_mfma_f32_32x32x16_f16' in asm['dpenv_policy.hip'] and 'step_kernel' in asm['dpenv_kernels.hip']
+    # (a) the exact form: a packed f32 instruction whose op_sel (the LOW result's operand select) picks the high half of src1 / src2
+    swz = re.compile(r'^\s*(v_pk_\w+_f32)\b.*\bop_sel:\[\d,(?:1(?:,\d)?|\d,1)\]', re.M)
+    for unit, txt in asm.items():
+        assert not swz.search(txt), (unit, swz.search(txt).group(0))
+        # (b) no packed fp32 arithmetic at all; the f16 forms of the network's activation packing are fine
+        packed = sorted(set(re.findall(r'\bv_pk_\w+', txt)))
+        assert all(q.endswith('_f16') for q in packed), (unit, packed)
+    # the pattern itself must be what the check looks for: the reproducer's instruction text matches, the safe form does not
+    assert swz.search('\tv_pk_fma_f32 v[46:47], v[124:125], v[38:39], v[46:47] op_sel:[0,1,0]')
+    assert swz.search('\tv_pk_fma_f32 v[0:1], v[2:3], v[2:3], v[4:5] op_sel:[0,0,1]')
+    assert not swz.search('\tv_pk_fma_f32 v[46:47], v[38:39], v[124:125], v[46:47] op_sel:[1,0,0]')
+    assert not swz.search('\tv_pk_fma_f32 v[46:47], v[54:55], v[38:39], v[46:47] op_sel_hi:[1,0,1]')

@@ -7,7 +7,8 @@ n, T = 2000 + 11, 45
 kw = dict(auto_reset=True, max_ep_len=40, seed=8)
 ref = None
 nbad = 0
-for rep in range(150):
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+for rep in range(reps):
     env, _ = H.make_pair('final_cont', n, **kw)
     ac = make_ac(9, 7, (80, 80, 80), seed=2, device=env.device).upload(env)
     g = torch.Generator(device=env.device).manual_seed(1)
@@ -22,9 +23,9 @@ for rep in range(150):
         d = (o['rew'] != ref['rew']).nonzero()
         t0, e0 = int(d[0, 0]), int(d[0, 1])
         envs = sorted(set(d[d[:, 0] == t0][:, 1].tolist()))
-        print('rep', rep, 'rew first differs at t', t0, 'envs', envs)
+        print('rep', rep, 'rew first differs at t', t0, 'envs', envs, 'lanes', sorted(set(e % 64 for e in envs)))
         print('  done[t0-1] of env', int(ref['done'][t0 - 1, e0]), 'obs[t0] equal', bool(torch.equal(o['obs'][t0], ref['obs'][t0])), 'act[t0] equal', bool(torch.equal(o['act'][t0], ref['act'][t0])))
         if t0 + 1 < T:
             print('  obs[t0+1] bad', o['obs'][t0 + 1, e0].tolist()); print('  obs[t0+1] ref', ref['obs'][t0 + 1, e0].tolist())
         print('  rew bad', float(o['rew'][t0, e0]), 'ref', float(ref['rew'][t0, e0]))
-print('bad runs', nbad, 'of 149')
+print('bad runs', nbad, 'of', reps - 1)

@@ -14,8 +14,11 @@ env.step of every env = one launch of step_kernel.  Envs shard across ranks with
 (weak scaling: 65 536 envs per GPU); the episode-boundary trajectory all-gather of config 4 is timed as a
 separate, clearly labelled leg and is NOT part of `value`.
 
-The step loop is captured into a HIP graph in chunks of 50 steps (the gcd of the box sequence's segment
-lengths) so that host launch overhead does not sit between kernels.
+The step loop is captured into a HIP graph so that host launch overhead does not sit between kernels: chunks of 50 steps
+(the gcd of the box sequence's segment lengths) when --steps is a multiple of 50, otherwise one graph of exactly --steps
+(<= 100) or of the largest divisor of --steps that is <= 50.  Exactly --warmup steps run untimed first.  The timed region is
+exactly --steps env steps, repeated `repeats` times back to back (reported; chosen so that the region lasts >= 10 ms, because a
+single 50-step graph is 0.3 ms and host replay / sync latency would otherwise be a tenth of it); ms_per_step = time / (steps x repeats).
 """
 import argparse
 import json
@@ -32,6 +35,9 @@ BOX_SWITCH_STEPS = (50, 300, 550, 700, 950)        # plot_pos.py:59 at dt = 0.2 
 BOX_REFS = ((5.0, 0.0, 0.0), (5.0, -5.0, 0.0), (5.0, -5.0, -45.0), (0.0, -5.0, -45.0), (0.0, 0.0, 0.0))   # plot_pos.py:55-57
 ALGO_BYTES_PER_ENV_STEP = 177                      # 88 B read + 89 B written
 HBM_PEAK_GBPS = 8000.0                             # MI355X_MICROARCH.md: 8.0 TB/s spec
+ALGO_FLOPS_PER_ENV_STEP = 20 * 80 + 400            # ~80 flop per plant sub-step (semi-implicit Euler, 20 x 10 ms) + ~400 decode / trig / reward
+VALU_PEAK_TFLOPS = 157.3                           # MI355X_MICROARCH.md: peak fp32 vector
+MIN_TIMED_MS = 10.0
 
 
 def parse():
@@ -43,7 +49,9 @@ def parse():
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of HIP-graph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fused', action='store_true', help='skip the fused-rollout leg')
-    ap.add_argument('--cpu-seconds', type=float, default=12.0, help='budget of the CPU baseline leg')
+    ap.add_argument('--cpu-seconds', type=float, default=14.0, help='budget of the CPU baseline leg (half 1 thread, half all cores)')
+    ap.add_argument('--policy-form', default='auto', choices=['auto', 'one_wave', 'two_wave'], help='launch form of the closed-loop legs')
+    ap.add_argument('--repeats', type=int, default=0, help='repeats of the timed --steps region (0 = enough for %g ms)' % MIN_TIMED_MS)
     ap.add_argument('--gather', type=int, default=-1, help='time the config-4 trajectory all-gather (default: on if gpus > 1)')
     ap.add_argument('--hold-plant', action='store_true', help='diagnostic: skip the plant sub-steps (INVALID as a result)')
     ap.add_argument('--backend', default='nccl', help="'nccl' (= RCCL; default) or 'gloo' (rehearsal only)")
@@ -53,13 +61,13 @@ def parse():
 
 
 def cpu_baseline(n_envs, budget_s):
-    """The oracle (CPU port of the same step, fp32, OpenMP over envs) on the host cores of this box, on a
-    bounded sample of the same workload: n_envs envs x S steps, S sized to the time budget."""
+    """The oracle (CPU port of the same step, fp32) on the host cores of this box, on a bounded sample of the same workload:
+    n_envs envs x S steps, S sized to the time budget - once on ONE thread and once with OpenMP over envs on the cores this
+    process may use (both, with the core count stated)."""
     import numpy as np
     from oracle import oracle as O
-    # a GPU box gives each GPU a 16-core CPU share; more threads than that only oversubscribes
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    threads = O.set_threads(min(avail, 16))
+    nproc = os.cpu_count() or 1
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else nproc
     orc = O.Oracle(O.make_config(terminate=0, max_ep_len=0), np.float32)
     rng = np.random.RandomState(0)
     st, ctr = orc.new_state(n_envs)
@@ -68,17 +76,26 @@ def cpu_baseline(n_envs, budget_s):
     obs = np.zeros((n_envs, 9), np.float32)
     rew = np.zeros(n_envs, np.float32)
     done = np.zeros(n_envs, np.uint8)
-    for _ in range(2):
-        orc.step_into(st, ctr, act, obs, rew, done)      # warm-up, page-in, thread pool start
-    steps = 0
-    t0 = time.perf_counter()
-    while steps < 3 or (time.perf_counter() - t0 < budget_s and steps < 100000):
-        orc.step_into(st, ctr, act, obs, rew, done)
-        steps += 1
-    dt = time.perf_counter() - t0
-    return {'value': n_envs * steps / dt, 'unit': 'env-steps/s', 'cores': threads, 'kind': 'port',
-            'sample': '%d envs x %d steps of the same final/ext/cont_ang step (oracle/dpenv_oracle.c, fp32, '
-                      'OpenMP over envs, %.1f s)' % (n_envs, steps, dt)}
+
+    def leg(threads, budget):
+        used = O.set_threads(threads)
+        for _ in range(2):
+            orc.step_into(st, ctr, act, obs, rew, done)      # warm-up, page-in, thread pool start
+        steps = 0
+        t0 = time.perf_counter()
+        while steps < 2 or (time.perf_counter() - t0 < budget and steps < 100000):
+            orc.step_into(st, ctr, act, obs, rew, done)
+            steps += 1
+        dt = time.perf_counter() - t0
+        return used, steps, dt, n_envs * steps / dt
+
+    # a GPU box gives each GPU a 16-core CPU share; more threads than that only oversubscribes
+    c1, s1, d1, v1 = leg(1, budget_s * 0.5)
+    cn, sn, dn, vn = leg(min(avail, 16), budget_s * 0.5)
+    return {'value': vn, 'unit': 'env-steps/s', 'cores': cn, 'kind': 'port',
+            'value_1thread': v1, 'nproc': nproc, 'cores_available_to_this_process': avail,
+            'sample': '%d envs of the same final/ext/cont_ang step (oracle/dpenv_oracle.c, fp32): %d steps on 1 thread (%.1f s), '
+                      '%d steps with OpenMP over envs on %d threads (%.1f s)' % (n_envs, s1, d1, sn, cn, dn)}
 
 
 def main():
@@ -96,20 +113,18 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    # a fresh checkout (built artefacts are git-ignored): rank 0 alone decides and builds, BEFORE it joins the process group
+    # (the Makefile links to a temporary name and renames); every rank then passes the same barrier whatever it saw on disk
+    if rank == 0 and not os.path.exists(os.path.join(ROOT, 'ml4ca_amd', 'lib', 'libdpenv.so')):
+        import __graft_entry__
+        __graft_entry__.build()
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(args.backend)
-
-    if not os.path.exists(os.path.join(ROOT, 'ml4ca_amd', 'lib', 'libdpenv.so')):
-        # a fresh checkout (built artefacts are git-ignored): build once, rank 0 first
-        if rank == 0:
-            import __graft_entry__
-            __graft_entry__.build()
-        if world > 1:
-            dist.barrier()
+        dist.barrier()
     import ml4ca_amd
     n = args.envs
     env = ml4ca_amd.BatchedRevoltEnv(n, variant='final', extended_state=True, cont_ang=True, device=dev,
@@ -117,8 +132,17 @@ def main():
                                      hold_plant=args.hold_plant)
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
+    K = max(1, args.steps)
+    W = max(0, args.warmup)
+    # steps per captured graph: 50 (the box schedule's granule) when it divides K, else K itself (small) or its largest divisor <= 50
+    if K % CHUNK == 0:
+        C = CHUNK
+    elif K <= 100:
+        C = K
+    else:
+        C = max(d for d in range(1, CHUNK + 1) if K % d == 0)
     # synthetic inputs, resident in HBM before the timed region
-    actions = torch.randn((CHUNK, n, 7), generator=g, device=dev) * 0.6065
+    actions = torch.randn((max(C, CHUNK), n, 7), generator=g, device=dev) * 0.6065
     # testing-style start (simtools.py:81-88 radius/heading) with the setpoint at the start pose: the box is relative
     init = torch.zeros((6, n), device=dev)
     init[0:2] = (torch.rand((2, n), generator=g, device=dev) - 0.5) * 4.0
@@ -132,10 +156,11 @@ def main():
     rew = torch.empty(n, device=dev)
     done = torch.empty(n, dtype=torch.uint8, device=dev)
 
-    def chunk():
+    def chunk(c=None):
         # first step of a chunk (re-)applies the setpoint in force: a no-op unless the sequence switched
+        c = C if c is None else c
         env.step(actions[0], new_ref=ref_buf, out=(obs, rew, done))
-        for k in range(1, CHUNK):
+        for k in range(1, c):
             env.step(actions[k], out=(obs, rew, done))
 
     graph = None
@@ -152,30 +177,47 @@ def main():
 
     state = {'t': 0}
 
+    def apply_schedule():
+        """setpoint in force at env step t of the 1250-step box sequence (switches take effect at the next chunk start)"""
+        t = state['t'] % 1250
+        k = sum(1 for sw in BOX_SWITCH_STEPS if sw <= t)
+        ref_buf.copy_(start if k == 0 else refs[k - 1])
+
     def run_steps(k):
-        """advance k env steps (k multiple of CHUNK), switching setpoints on the box schedule"""
-        for _ in range(k // CHUNK):
-            t = state['t'] % 1250
-            if t == 0:
-                ref_buf.copy_(start)
-            if t in BOX_SWITCH_STEPS:
-                ref_buf.copy_(refs[BOX_SWITCH_STEPS.index(t)])
+        """advance exactly k env steps: whole chunks by graph replay, a remainder (warm-up only) by eager launches"""
+        for _ in range(k // C):
+            apply_schedule()
             if graph is not None:
                 graph.replay()
             else:
                 chunk()
-            state['t'] += CHUNK
+            state['t'] += C
+        if k % C:
+            apply_schedule()
+            chunk(k % C)
+            state['t'] += k % C
 
-    K = max(CHUNK, (args.steps // CHUNK) * CHUNK)
-    W = max(0, ((args.warmup + CHUNK - 1) // CHUNK) * CHUNK) if args.warmup > 0 else 0
     run_steps(W)
+    # how often to repeat the K-step region so that it lasts >= MIN_TIMED_MS: from one untimed pass (also a warm-up of the graph)
+    cal0, cal1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    cal0.record()
+    run_steps(K)
+    cal1.record()
+    torch.cuda.synchronize(dev)
+    R = args.repeats if args.repeats > 0 else max(1, int(-(-MIN_TIMED_MS // max(cal0.elapsed_time(cal1), 1e-3))))
+    if world > 1:
+        rt = torch.tensor([R], device=dev, dtype=torch.int64)
+        dist.all_reduce(rt, op=dist.ReduceOp.MAX)      # every rank times the same amount of work
+        R = int(rt[0])
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     ev0.record()
-    run_steps(K)
+    for _ in range(R):
+        run_steps(K)
     ev1.record()
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -186,7 +228,11 @@ def main():
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     wall = float(tt[0])
+    KR = K * R                                          # env steps inside the timed region
     assert bool(torch.isfinite(obs).all()) and bool(torch.isfinite(rew).all()), 'non-finite outputs'
+    # the other legs run whole 50-step launches: at least 250 steps each, more when --steps asks for more
+    KL = max(5 * CHUNK, (K // CHUNK) * CHUNK)
+    WL = CHUNK
 
     # ---- fused-rollout leg (dpenv_rollout): same workload, CHUNK env steps per launch, state in registers -----
     fused = None
@@ -204,14 +250,14 @@ def main():
                     ref_buf.copy_(start)
                 if t in BOX_SWITCH_STEPS:
                     ref_buf.copy_(refs[BOX_SWITCH_STEPS.index(t)])
-                env.rollout(actions, switch_steps=(0,), refs=refs1, out=(fobs, frew, fdone))
+                env.rollout(actions[:CHUNK], switch_steps=(0,), refs=refs1, out=(fobs, frew, fdone))
 
-        run_fused(max(W, CHUNK))
+        run_fused(WL)
         fe0, fe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(dev)
         tf0 = time.perf_counter()
         fe0.record()
-        run_fused(K)
+        run_fused(KL)
         fe1.record()
         torch.cuda.synchronize(dev)
         fwall = time.perf_counter() - tf0
@@ -219,41 +265,52 @@ def main():
         assert bool(torch.isfinite(fobs).all())
         fused = {'what': 'dpenv_rollout: %d env steps per launch, state resident in registers; open-loop action block; '
                          'same workload; NOT the headline value' % CHUNK,
-                 'env_steps_per_s': n * K / fwall, 'us_per_step': fwall / K * 1e6, 'launch_us_events': fms * 1e3 / (K // CHUNK),
+                 'steps': KL, 'env_steps_per_s': n * KL / fwall, 'us_per_step': fwall / KL * 1e6, 'launch_us_events': fms * 1e3 / (KL // CHUNK),
                  'bytes_per_env_step_moved': 28 + 36 + 4 + 1,
-                 'GBps_at_177B_accounting': ALGO_BYTES_PER_ENV_STEP * n * K / (fms * 1e-3) / 1e9,
-                 'frac_of_8TBps_at_177B_accounting': ALGO_BYTES_PER_ENV_STEP * n * K / (fms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+                 'GBps_at_177B_accounting': ALGO_BYTES_PER_ENV_STEP * n * KL / (fms * 1e-3) / 1e9,
+                 'frac_of_8TBps_at_177B_accounting': ALGO_BYTES_PER_ENV_STEP * n * KL / (fms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                 'valu_TFLOPs_at_%d_flop_per_env_step' % ALGO_FLOPS_PER_ENV_STEP: ALGO_FLOPS_PER_ENV_STEP * n * KL / (fms * 1e-3) / 1e12}
 
-    # ---- closed-loop leg (dpenv_policy_rollout): actor-critic 9-80-80-80-7 / -1 evaluated in-kernel on MFMA ----
+    # ---- closed-loop legs (dpenv_policy_rollout): actor-critic 9-80-80-80-7 / -1 evaluated in-kernel on MFMA, exploration noise
+    #      drawn in the kernel (core.py:85), both network arithmetics ---------------------------------------------------------
     closed = None
     if not args.no_fused:
         from ml4ca_amd.policy import ActorCritic, policy_rollout
-        ac = ActorCritic(9, 7, (80, 80, 80), seed=0, device=dev).upload(env)
-        noise = torch.randn((CHUNK, n, 7), generator=g, device=dev)
-        env.reset(init=init, new_ref=start.clone())
-        pout = policy_rollout(env, CHUNK, noise=noise)
+        ac = ActorCritic(9, 7, (80, 80, 80), seed=0, device=dev)
+        flops = 2 * 2 * (9 * 80 + 80 * 80 * 2 + 80 * 7) * n       # actor + critic MACs x 2, per step (critic out 1 ~ 7)
+        closed = {'what': 'dpenv_policy_rollout: %d steps per launch of actor (9-80-80-80-7) -> sample (in-kernel Philox noise) -> env.step -> '
+                          'critic, PPO rows (o,a,r,v,logp,done,boot) written in-kernel; fp32 env; NOT the headline value' % CHUNK}
+        for prec in ('f16', 'f32'):
+            ac.upload(env, precision=prec, launch_form=args.policy_form if prec == 'f16' else 'auto')
+            env.reset(init=init, new_ref=start.clone())
+            pout = policy_rollout(env, CHUNK, sample=True)
 
-        def run_closed(k):
-            for c in range(k // CHUNK):
-                policy_rollout(env, CHUNK, noise=noise, out=pout)
+            def run_closed(k):
+                for c in range(k // CHUNK):
+                    policy_rollout(env, CHUNK, sample=True, out=pout)
 
-        run_closed(max(W, CHUNK))
-        ce0, ce1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize(dev)
-        tc0 = time.perf_counter()
-        ce0.record()
-        run_closed(K)
-        ce1.record()
-        torch.cuda.synchronize(dev)
-        cwall = time.perf_counter() - tc0
-        assert bool(torch.isfinite(pout['obs']).all()) and bool(torch.isfinite(pout['logp']).all())
+            kc = KL if prec == 'f16' else max(CHUNK, KL // 2)
+            run_closed(WL)
+            torch.cuda.synchronize(dev)
+            tc0 = time.perf_counter()
+            run_closed(kc)
+            torch.cuda.synchronize(dev)
+            cwall = time.perf_counter() - tc0
+            assert bool(torch.isfinite(pout['obs']).all()) and bool(torch.isfinite(pout['logp']).all())
+            closed['policy_dtype_' + prec] = {
+                'policy_dtype': 'f16 weights/activations, f32 accumulate (fast mode, ~5e-4 of the output scale from fp32)' if prec == 'f16'
+                else 'split-f16 hi+lo, three MFMAs per product (DPENV_POLICY_F32: within 1e-5 of an fp32 evaluation, the parity mode)',
+                'launch_form': ('two waves per 64 envs' if args.policy_form in ('auto', 'two_wave') else 'one wave per 64 envs') if prec == 'f16' else 'one wave per 64 envs',
+                'steps': kc, 'env_steps_per_s': n * kc / cwall, 'us_per_step': cwall / kc * 1e6, 'policy_TFLOPs': flops * kc / cwall / 1e12}
+        closed['us_per_step'] = closed['policy_dtype_f16']['us_per_step']
         # reference point: the same policy as separate torch kernels (fp32) + one env.step launch per step
+        noise1 = torch.randn((n, 7), generator=g, device=dev)
 
         def torch_loop(k):
             o = obs
             for _ in range(k):
                 mu, v = ac.forward_ref(o)
-                a_ = mu + torch.exp(ac.log_std) * noise[0]
+                a_ = mu + torch.exp(ac.log_std) * noise1
                 lp = ac.logp_ref(a_, mu)
                 o, r_, d_, _ = env.step(a_.contiguous())
             return o
@@ -265,101 +322,117 @@ def main():
         torch_loop(200)
         torch.cuda.synchronize(dev)
         twall = time.perf_counter() - tt0
-        flops = 2 * 2 * (9 * 80 + 80 * 80 * 2 + 80 * 7) * n       # actor + critic MACs x 2, per step (critic out 1 ~ 7)
-        closed = {'what': 'dpenv_policy_rollout: %d steps per launch of actor (9-80-80-80-7) -> sample -> env.step -> critic, '
-                          'PPO rows (o,a,r,v,logp,done,boot) written in-kernel; f16 MFMA policy, fp32 env' % CHUNK,
-                  'env_steps_per_s': n * K / cwall, 'us_per_step': cwall / K * 1e6,
-                  'policy_TFLOPs': flops * K / cwall / 1e12,
-                  'unfused_torch_fp32_policy_plus_step_kernel': {'env_steps_per_s': n * 200 / twall, 'us_per_step': twall / 200 * 1e6},
-                  'speedup_vs_unfused': (twall / 200) / (cwall / K)}
+        closed['unfused_torch_fp32_policy_plus_step_kernel'] = {'env_steps_per_s': n * 200 / twall, 'us_per_step': twall / 200 * 1e6}
+        closed['speedup_vs_unfused'] = {p_: (twall / 200) / (closed['policy_dtype_' + p_]['us_per_step'] * 1e-6) for p_ in ('f16', 'f32')}
 
     # ---- config-5 leg (BASELINE.json configs[4]): drifting current, bf16 observation rows, full PPO rollout block
-    #      (T = 400 = one episode, auto-reset) + GAE scan + advantage normalisation, all on device ------------------
+    #      (T = 400 = one episode, auto-reset) + GAE scan + advantage normalisation, all on device; every epoch re-packs the
+    #      (device-resident) weights and draws fresh exploration noise in the kernel, as a PPO epoch must ---------------------
     cfg5 = None
     if not args.no_fused:
         from ml4ca_amd import rollout as RO
         env5 = ml4ca_amd.BatchedRevoltEnv(n, variant='final', extended_state=True, cont_ang=True, device=dev, auto_reset=True,
                                           seed=2, env_id_base=rank * n, obs_dtype='bfloat16', current=True, current_drift=True)
         env5.set_current(torch.full((n,), 0.2, device=dev), torch.full((n,), 135.0 * deg, device=dev))
-        ac.upload(env5)
         T5 = 400
         buf5 = RO.RolloutBuffer(T5, env5)
-        noise5 = torch.randn((T5, n, 7), generator=g, device=dev)
         env5.reset()
+        cfg5 = {'what': 'BASELINE.json configs[4]: %d envs, Gauss-Markov current (0.2 m/s, 135 deg), bf16 obs rows; per epoch: weight '
+                        're-pack from device tensors (one kernel, no sync) + one launch of T = 400 policy-in-the-loop steps with auto-reset and '
+                        'in-kernel exploration noise + GAE(0.99, 0.97) with statistics + advantage normalisation' % n}
+        for prec in ('f16', 'f32'):
+            def epoch5():
+                ac.upload(env5, precision=prec, launch_form=args.policy_form if prec == 'f16' else 'auto')
+                buf5.collect(env5, sample=True)
+                buf5.finish()
+                return buf5.get()
 
-        def epoch5():
-            buf5.collect(env5, noise=noise5)
+            epoch5()
+            ge0, ge1, ge2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            torch.cuda.synchronize(dev)
+            t50 = time.perf_counter()
+            reps5 = 3 if prec == 'f16' else 2
+            for _ in range(reps5):
+                o5, a5, adv5, ret5, lp5 = epoch5()
+            torch.cuda.synchronize(dev)
+            w5 = (time.perf_counter() - t50) / reps5
+            # GAE + normalisation alone, on the block just produced
+            ge0.record()
             buf5.finish()
-            return buf5.get()
-
-        epoch5()
-        torch.cuda.synchronize(dev)
-        t50 = time.perf_counter()
-        reps5 = 3
-        for _ in range(reps5):
-            o5, a5, adv5, ret5, lp5 = epoch5()
-        torch.cuda.synchronize(dev)
-        w5 = (time.perf_counter() - t50) / reps5
-        assert bool(torch.isfinite(adv5).all()) and o5.dtype == torch.bfloat16
-        cfg5 = {'what': 'BASELINE.json configs[4]: %d envs, Gauss-Markov current (0.2 m/s, 135 deg), bf16 obs rows, one launch of '
-                        'T = 400 policy-in-the-loop steps with auto-reset + GAE(0.99, 0.97) + advantage normalisation' % n,
-                'env_steps_per_s': n * T5 / w5, 'ms_per_epoch': w5 * 1e3, 'us_per_step': w5 / T5 * 1e6}
-        del env5, buf5, noise5
+            ge1.record()
+            RO.normalize_advantages(buf5.adv, stats=buf5.stats)
+            ge2.record()
+            torch.cuda.synchronize(dev)
+            assert bool(torch.isfinite(adv5).all()) and o5.dtype == torch.bfloat16
+            cfg5['policy_dtype_' + prec] = {'env_steps_per_s': n * T5 / w5, 'ms_per_epoch': w5 * 1e3, 'us_per_step': w5 / T5 * 1e6,
+                                            'gae_with_stats_ms': ge0.elapsed_time(ge1), 'normalise_ms': ge1.elapsed_time(ge2),
+                                            'gae_GBps_at_21B_per_env_step': 21 * n * T5 / (ge0.elapsed_time(ge1) * 1e-3) / 1e9}
+        cfg5['us_per_step'] = cfg5['policy_dtype_f16']['us_per_step']
+        del env5, buf5
 
     # ---- config-4 leg: episode-boundary all-gather of [T=400, 32768, 19] f32 trajectory blocks ------------
     gather = None
     do_gather = (args.gather == 1) or (args.gather < 0 and world > 1)
     if do_gather and world > 1:
         T, nl = 400, 32768
-        traj = torch.randn((T, nl, 19), device=dev)
-        out = torch.empty((world, T, nl, 19), device=dev)
-        from ml4ca_amd.dist import gather_trajectories
-        gather_trajectories(traj, out=out)
+        from ml4ca_amd.dist import gather_rollout
+        traj = {'obs': torch.randn((T, nl, 9), device=dev), 'act': torch.randn((T, nl, 7), device=dev), 'rew': torch.randn((T, nl), device=dev),
+                'val': torch.randn((T, nl), device=dev), 'logp': torch.randn((T, nl), device=dev)}
+        out = gather_rollout(traj)
         torch.cuda.synchronize(dev)
         dist.barrier()
         t1 = time.perf_counter()
         reps = 3
         for _ in range(reps):
-            gather_trajectories(traj, out=out)
+            gather_rollout(traj, out=out)
         torch.cuda.synchronize(dev)
         gt = torch.tensor([(time.perf_counter() - t1) / reps], device=dev, dtype=torch.float64)
         dist.all_reduce(gt, op=dist.ReduceOp.MAX)
         gsec = float(gt[0])
-        shard = traj.numel() * 4
-        gather = {'what': 'all_gather_into_tensor of [400, 32768, 19] f32 per rank (config 4), not in `value`',
+        shard = sum(v.numel() for v in traj.values()) * 4
+        gather = {'what': 'config 4: all-gather of a [400, 32768] rollout per rank - the five blocks obs 9 | act 7 | rew | val | logp '
+                          '(19 floats per env-step) gathered in place, no packed staging copy; not in `value`',
                   'ms': gsec * 1e3, 'shard_MB': shard / 1e6,
                   'recv_GBps_per_rank': shard * (world - 1) / gsec / 1e9,
-                  'env_steps_per_s_step_plus_gather': world * nl * T / (T * (wall / K) * nl / n + gsec)}
+                  'env_steps_per_s_step_plus_gather': world * nl * T / (T * (wall / KR) * nl / n + gsec)}
         del out, traj
 
     if rank == 0:
         total_envs = n * world
         per_launch_bytes = ALGO_BYTES_PER_ENV_STEP * n
-        kern_s = ev_ms * 1e-3 / K                      # HIP events around the K graph-replayed launches
+        kern_s = ev_ms * 1e-3 / KR                     # HIP events (on the launch stream) around the KR graph-replayed launches
         achieved = per_launch_bytes / kern_s / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         try:
             tj = json.load(open(args.traffic_json))
             if tj.get('n_envs') == n:
                 traffic = tj.get('hbm_bytes_per_launch')
+                traffic_source = '%s: rocprofv3 --pmc passes of this command run by the builder (%s), NOT measured in this run' % (
+                    os.path.relpath(args.traffic_json, ROOT), tj.get('tag', 'see profiles/'))
         except Exception:
             pass
+        valu_tflops = ALGO_FLOPS_PER_ENV_STEP * n / kern_s / 1e12
         res = {
-            'metric': 'env-steps/sec at 65536 parallel envs' + (' [DIAGNOSTIC hold_plant: INVALID]' if args.hold_plant else ''), 'value': total_envs * K / wall, 'unit': 'env-steps/s',
-            'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': wall / K * 1e3, 'higher_is_better': True,
+            'metric': 'env-steps/sec at 65536 parallel envs' + (' [DIAGNOSTIC hold_plant: INVALID]' if args.hold_plant else ''), 'value': total_envs * KR / wall, 'unit': 'env-steps/s',
+            'n_gpus': world, 'steps': K, 'warmup': W, 'repeats': R, 'ms_per_step': wall / KR * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'BASELINE.json configs[2]: %d parallel envs per GPU, final/ext/cont_ang, 4-corner box '
                                    'setpoint sequence (switch steps 50/300/550/700/950 of 1250), terminate off, fp32' % n,
                        'envs_per_gpu': n, 'total_envs': total_envs, 'integrator': 'semi-implicit Euler 20 x 10 ms',
-                       'launch': 'eager' if graph is None else 'hipGraph replay, %d steps per graph' % CHUNK,
+                       'launch': 'eager' if graph is None else 'hipGraph replay, %d steps per graph' % C,
+                       'timed_region': '%d steps x %d repeats back to back (%.1f ms)' % (K, R, wall * 1e3),
                        'sharding': 'independent env shards, no data-path collective',
                        'backend': args.backend if world > 1 else None},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
+                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic, 'traffic_source': traffic_source,
                          'kernel': 'dpenv::step_kernel<4,true,false>', 'algorithmic_bytes_per_launch': per_launch_bytes,
                          'avg_launch_us': kern_s * 1e6,
                          'note': 'avg_launch_us = HIP-event time over the timed region / launches (includes the ~1.5 us '
                                  'kernel-boundary gap); 177 B/env-step x %d envs' % n},
+            'roofline_valu': {'bound': 'valu_fp32', 'achieved': valu_tflops, 'peak': VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                              'frac': valu_tflops / VALU_PEAK_TFLOPS, 'flops_per_env_step': ALGO_FLOPS_PER_ENV_STEP,
+                              'note': 'SURVEY 8(d) secondary figure: algorithmic fp32 flops (20 semi-implicit Euler sub-steps x ~80 + ~400 decode/'
+                                      'trig/reward) x envs / avg launch time, against the 157.3 TF vector peak'},
             'reference_context': {'published_derived_env_steps_per_s': 34.3,
                                   'source': 'BASELINE.md: 2.4M interactions / 69930 s, 1 env, laptop + Cybersea'},
         }

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DPENV_ABI_VERSION 1
+#define DPENV_ABI_VERSION 2
 
 typedef struct dpenv_s* dpenv_handle;
 typedef void* dpenv_stream; /* hipStream_t; NULL = the null stream */
@@ -114,7 +114,10 @@ typedef struct dpenv_config {
     float current_tau;       /* correlation time [s], 100 */
     float current_sigma_v;   /* stationary std of V_c [m/s], 0.02 */
     float current_sigma_beta;/* stationary std of beta_c [rad], 5 deg */
-    int32_t reserved[2];
+    int32_t reset_acts;      /* 1: an episode starts with previous thrust clip(100 * N(0, 0.1)) instead of zero (the reference's
+                                reset_acts constructor flag, customEnv.py:30,179-188); drawn in the kernel by every kind of reset,
+                                Philox keyed (seed; global env id, episode) like the pose sample */
+    int32_t reserved;
 } dpenv_config;
 
 /* Optional outputs / inputs of one step beyond the Gym tuple.  All device pointers, any may be NULL. */
@@ -191,20 +194,49 @@ int dpenv_rollout(dpenv_handle h, const dpenv_rollout_io* io, dpenv_stream s);
  * 80-107; shipped model 9-80-80-80-7 + 9-80-80-80-1, leaky_relu 0.2, config.json) evaluated inside the rollout
  * launch on the matrix cores (f16 weights/activations, f32 accumulate), so that one launch produces T rows of the
  * trajectory buffer (o, a, r, v, logp) of ppo.py:298 for every env. */
+enum { DPENV_ACT_LEAKY_RELU = 0, DPENV_ACT_TANH = 1 };
 typedef struct dpenv_mlp {
     int32_t n_layers;        /* dense layers = hidden layers + 1, in [2, 5] */
     int32_t sizes[6];        /* n_layers + 1 widths, e.g. {9, 80, 80, 80, 7}; hidden widths equal and <= 96 */
-    const float* W[5];       /* HOST pointers, W[l][in][out] row-major (tf.layers.dense kernel layout) */
-    const float* b[5];       /* HOST pointers, b[l][out] */
+    const float* W[5];       /* W[l][in][out] row-major (tf.layers.dense kernel layout); host or device, see dpenv_policy_desc */
+    const float* b[5];       /* b[l][out] */
 } dpenv_mlp;
-/* pi: obs_dim -> act_dim, v: obs_dim -> 1 (same hidden shape); log_std: host float[act_dim]; leak: hidden
+/* Arithmetic of the in-kernel networks.  F16: f16 weights and activations, f32 accumulation - the fast mode, within ~5e-4 of
+ * the output scale of an fp32 evaluation.  F32: "fp32-faithful" split-f16 arithmetic (W = Wh + Wl, x = xh + xl, three MFMAs per
+ * product, activations in f32): mu, v, logp within 1e-5 of an fp32 evaluation of core.py:29-33,80-107 - the mode parity with
+ * the reference's fp32 TF1 networks is claimed on; about half the speed of F16 in the closed loop, one-wave launch form only. */
+enum { DPENV_POLICY_F16 = 0, DPENV_POLICY_F32 = 1 };
+/* Launch form of dpenv_policy_rollout.  TWO_WAVE: every 64 envs get an env wave and a network wave (512-thread workgroups,
+ * pair-level LDS hand-over); ONE_WAVE: one wave does both.  Both write identical rows.  AUTO picks TWO_WAVE where it exists
+ * (F16) and its LDS footprint (networks + 50 KiB of mailboxes) fits, else ONE_WAVE. */
+enum { DPENV_LAUNCH_AUTO = 0, DPENV_LAUNCH_ONE_WAVE = 1, DPENV_LAUNCH_TWO_WAVE = 2 };
+typedef struct dpenv_policy_desc {
+    uint32_t struct_size;
+    const dpenv_mlp* pi;     /* obs_dim -> act_dim */
+    const dpenv_mlp* v;      /* obs_dim -> 1, same hidden shape */
+    const float* log_std;    /* float[act_dim] (core.py:83) */
+    int32_t activation;      /* DPENV_ACT_* */
+    float leak;              /* leaky-relu slope in [0, 1] */
+    int32_t precision;       /* DPENV_POLICY_* */
+    int32_t launch_form;     /* DPENV_LAUNCH_* */
+    int32_t device_pointers; /* 0: W, b, log_std are HOST pointers (copied on the stream, then packed on the device);
+                                1: they are DEVICE pointers (e.g. the optimiser's own parameter tensors): packed by one kernel
+                                on the stream - no host copy, no synchronisation, graph-capturable.  Re-upload after every
+                                PPO update (ppo.py:260-280) costs one small launch. */
+    int32_t reserved;
+} dpenv_policy_desc;
+/* Pack the networks into the image the rollout kernels stage into LDS.  Stream-ordered: launches issued on `s` afterwards see
+ * the new weights, launches issued before keep the old ones.  Fails with DPENV_EINVAL if the requested launch form cannot
+ * hold the networks in the 160 KiB LDS. */
+int dpenv_set_policy_desc(dpenv_handle h, const dpenv_policy_desc* d, dpenv_stream s);
+/* Convenience forms (host pointers, F16, AUTO, null stream):
+ * pi: obs_dim -> act_dim, v: obs_dim -> 1 (same hidden shape); log_std: host float[act_dim]; leak: hidden
  * leaky-relu slope (0.2 = tf.nn.leaky_relu default; 0 = relu).  Packs and uploads; may be called again after
  * every PPO update. */
 int dpenv_set_policy(dpenv_handle h, const dpenv_mlp* pi, const dpenv_mlp* v, const float* log_std, float leak);
 /* The same with the hidden activation named: the reference's --activation {leaky, relu, tanh} (train.py:24,31;
  * spinup core.py:29-33 takes any activation, tanh being Spinning Up's default).  relu = DPENV_ACT_LEAKY_RELU with
  * leak 0; leak is ignored for DPENV_ACT_TANH. */
-enum { DPENV_ACT_LEAKY_RELU = 0, DPENV_ACT_TANH = 1 };
 int dpenv_set_policy_ex(dpenv_handle h, const dpenv_mlp* pi, const dpenv_mlp* v, const float* log_std, int32_t activation,
                         float leak);
 /* mu_out [n][act_dim], v_out [n] for obs [n][obs_dim] (all device, row-major): the deterministic policy of
@@ -214,7 +246,7 @@ int dpenv_policy_forward(dpenv_handle h, const float* obs, float* mu_out, float*
 typedef struct dpenv_policy_rollout_io {
     uint32_t struct_size;
     int32_t T;
-    const float* noise;      /* [T][n][act_dim] N(0,1) draws (a = mu + exp(log_std) * noise, core.py:85); NULL: a = mu */
+    const float* noise;      /* [T][n][act_dim] N(0,1) draws (a = mu + exp(log_std) * noise, core.py:85); NULL: see `sample` */
     void* obs;               /* [T][n][obs_dim]  policy input of step t; f32 or bf16 per config.obs_dtype (the actor
                                 always sees the full-precision observation, only the stored row is rounded) */
     float* act;              /* [T][n][act_dim] */
@@ -229,10 +261,15 @@ typedef struct dpenv_policy_rollout_io {
     int32_t n_switch;
     int32_t switch_step[DPENV_MAX_SWITCH];
     const float* refs;       /* [n_switch][3][n] */
+    int32_t sample;          /* with noise == NULL: 0 = deterministic policy a = mu (test_policy.py:90); 1 = the exploration noise is
+                                drawn INSIDE the kernel like the reference's tf.random_normal (core.py:85): Philox4x32-10 +
+                                Box-Muller keyed (config.seed; global env id, number of actions that env has sampled so far), so a
+                                trajectory does not depend on the rank count or launch geometry and no [T][n][act_dim] noise block
+                                is generated, stored or read (28 B per env-step).  Ignored when noise != NULL. */
+    int32_t reserved;
 } dpenv_policy_rollout_io;
-/* Requires AOS layouts.  Launch form: by default every 64 envs get an env wave and a network wave (512-thread
- * workgroups); the environment variable DPENV_POLICY_WS=0 selects the one-wave-per-64-envs kernel instead.  Both forms
- * write identical rows. */
+/* Requires AOS layouts.  Vessel classes, drifting current, auto-reset (with reset_acts) and bf16 observation rows all work
+ * here as in dpenv_step.  Launch form and arithmetic: dpenv_policy_desc. */
 int dpenv_policy_rollout(dpenv_handle h, const dpenv_policy_rollout_io* io, dpenv_stream s);
 
 /* Parity/test access to the library-owned state in the canonical format above. */
@@ -249,11 +286,24 @@ int dpenv_thrust_map(const float* params, const float* n_pct, const float* alpha
  * boot[t][i] if boot != NULL, else 0 at inner ends and last_val[i] (NULL = 0) at the final row. */
 int dpenv_gae(const float* rew, const float* val, const uint8_t* end, const float* boot, const float* last_val,
               int32_t T, int32_t n, float gamma, float lam, float* adv_out, float* ret_out, dpenv_stream s);
-/* Advantage normalisation (TrajectoryBuffer.get, ppo.py:99-103 + mpi_tools.py:71-92) as three stream-ordered
- * device passes so that a multi-rank caller can all-reduce the partial sums in between
- * (mpi_statistics_scalar does exactly two all-reduces): sum -> [mean = sum/count] -> sum of squared
- * deviations -> [std = sqrt(sumsq/count)] -> adv = (adv - mean) / (std + 1e-8).
- * sum_out, sumsq_out, mean, std are device float scalars. */
+/* The same scan, and in the same pass the statistics the normalisation needs: stats_out[0] = sum of adv, stats_out[1] = sum of
+ * adv^2 over the block (device doubles; accumulated in double in a fixed order, so two runs give the same bits).  workspace:
+ * dpenv_gae_workspace_bytes(n) bytes of device memory (per-workgroup partials), needed when stats_out is given.
+ * A lane owns four adjacent env columns when n % 4 == 0 and the blocks are 16-byte aligned (16-byte row accesses), and rows
+ * are fetched two 4-row groups ahead of the recurrence: the scan is bound by HBM (17 B per env-step, 21 B with boot). */
+int64_t dpenv_gae_workspace_bytes(int32_t n);
+int dpenv_gae_stats(const float* rew, const float* val, const uint8_t* end, const float* boot, const float* last_val,
+                    int32_t T, int32_t n, float gamma, float lam, float* adv_out, float* ret_out, void* workspace,
+                    double* stats_out, dpenv_stream s);
+/* Advantage normalisation (TrajectoryBuffer.get, ppo.py:99-103 + mpi_tools.py:71-92):
+ * adv = (adv - mean) / (std + 1e-8), mean and population std over ALL ranks' samples.
+ * One-pass form: all-reduce (sum) the two doubles of dpenv_gae_stats and the sample count over the ranks, then
+ *   dpenv_adv_apply_stats(adv, count, stats, total_count): mean = stats[0] / total_count, std = sqrt(stats[1] / total_count - mean^2).
+ * Three-pass form (the reference's own order, two all-reduces): sum -> [mean = sum/count] -> sum of squared deviations ->
+ * [std = sqrt(sumsq/count)] -> apply; sum_out, sumsq_out, mean, std are device float scalars.  The two reductions are
+ * deterministic (double partials added in a fixed order) and share one scratch buffer per device: do not run them
+ * concurrently on two streams of one device. */
+int dpenv_adv_apply_stats(float* adv, int64_t count, const double* stats, double total_count, dpenv_stream s);
 int dpenv_adv_sum(const float* adv, int64_t count, float* sum_out, dpenv_stream s);
 int dpenv_adv_sumsq(const float* adv, int64_t count, const float* mean, float* sumsq_out, dpenv_stream s);
 int dpenv_adv_apply(float* adv, int64_t count, const float* mean, const float* std, dpenv_stream s);

@@ -16,9 +16,11 @@ AOS, SOA = 0, 1
 WRAP_REFERENCE, WRAP_RADIANS = 0, 1
 F32, BF16 = 0, 1
 ACT_LEAKY_RELU, ACT_TANH = 0, 1
+POLICY_F16, POLICY_F32 = 0, 1
+LAUNCH_AUTO, LAUNCH_ONE_WAVE, LAUNCH_TWO_WAVE = 0, 1, 2
 DONE_TERMINAL, DONE_TIMELIMIT, DONE_FAULT = 1, 2, 4
 NSTATE, NPARAM, MAX_CLASSES = 15, 32, 64
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # canonical state rows (dpenv.h DPENV_S_*)
 S = dict(N=0, E=1, PSI=2, U=3, V=4, R=5, REF_N=6, REF_E=7, REF_PSI=8,
@@ -37,7 +39,7 @@ class Config(C.Structure):
                 ('obs_layout', C.c_int32), ('obs_dtype', C.c_int32), ('current_enabled', C.c_int32),
                 ('seed', C.c_uint64), ('env_id_base', C.c_int64), ('reset_fraction', C.c_float),
                 ('hold_plant', C.c_int32), ('current_drift', C.c_int32), ('current_tau', C.c_float),
-                ('current_sigma_v', C.c_float), ('current_sigma_beta', C.c_float), ('reserved', C.c_int32 * 2)]
+                ('current_sigma_v', C.c_float), ('current_sigma_beta', C.c_float), ('reset_acts', C.c_int32), ('reserved', C.c_int32)]
 
 
 class StepIO(C.Structure):
@@ -59,7 +61,14 @@ class PolicyRolloutIO(C.Structure):
     _fields_ = [('struct_size', C.c_uint32), ('T', C.c_int32), ('noise', C.c_void_p), ('obs', C.c_void_p),
                 ('act', C.c_void_p), ('reward', C.c_void_p), ('value', C.c_void_p), ('logp', C.c_void_p),
                 ('done', C.c_void_p), ('boot', C.c_void_p), ('last_obs', C.c_void_p), ('last_value', C.c_void_p),
-                ('n_switch', C.c_int32), ('switch_step', C.c_int32 * 8), ('refs', C.c_void_p)]
+                ('n_switch', C.c_int32), ('switch_step', C.c_int32 * 8), ('refs', C.c_void_p), ('sample', C.c_int32),
+                ('reserved', C.c_int32)]
+
+
+class PolicyDesc(C.Structure):
+    _fields_ = [('struct_size', C.c_uint32), ('pi', C.POINTER(Mlp)), ('v', C.POINTER(Mlp)), ('log_std', C.c_void_p),
+                ('activation', C.c_int32), ('leak', C.c_float), ('precision', C.c_int32), ('launch_form', C.c_int32),
+                ('device_pointers', C.c_int32), ('reserved', C.c_int32)]
 
 
 # every symbol include/dpenv.h declares: name -> (restype, argtypes)
@@ -83,12 +92,16 @@ SYMBOLS = {
     'dpenv_rollout': (C.c_int, [_VP, C.POINTER(RolloutIO), _VP]),
     'dpenv_set_policy': (C.c_int, [_VP, C.POINTER(Mlp), C.POINTER(Mlp), C.POINTER(C.c_float), _F]),
     'dpenv_set_policy_ex': (C.c_int, [_VP, C.POINTER(Mlp), C.POINTER(Mlp), C.POINTER(C.c_float), C.c_int32, _F]),
+    'dpenv_set_policy_desc': (C.c_int, [_VP, C.POINTER(PolicyDesc), _VP]),
     'dpenv_policy_forward': (C.c_int, [_VP, _VP, _VP, _VP, _I32, _VP]),
     'dpenv_policy_rollout': (C.c_int, [_VP, C.POINTER(PolicyRolloutIO), _VP]),
     'dpenv_get_state': (C.c_int, [_VP, _VP, _VP, _VP]),
     'dpenv_set_state': (C.c_int, [_VP, _VP, _VP, _VP]),
     'dpenv_thrust_map': (C.c_int, [C.POINTER(C.c_float), _VP, _VP, _VP, _I32, _VP]),
     'dpenv_gae': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _F, _F, _VP, _VP, _VP]),
+    'dpenv_gae_workspace_bytes': (C.c_int64, [_I32]),
+    'dpenv_gae_stats': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _F, _F, _VP, _VP, _VP, _VP, _VP]),
+    'dpenv_adv_apply_stats': (C.c_int, [_VP, _I64, _VP, C.c_double, _VP]),
     'dpenv_adv_sum': (C.c_int, [_VP, _I64, _VP, _VP]),
     'dpenv_adv_sumsq': (C.c_int, [_VP, _I64, _VP, _VP, _VP]),
     'dpenv_adv_apply': (C.c_int, [_VP, _I64, _VP, _VP, _VP]),

@@ -33,8 +33,13 @@ struct dpenv_s {
     int32_t* class_id;
     bool classes_assigned;
     bool current_set;
+    uint32_t* noise_ctr;
     PolicyArgs pol;         // persistent part (weights, std) of the policy kernel arguments
-    uint4* pol_frags;
+    void* pol_buf;          // fragments | bias tiles | constants, as the kernels stage them
+    size_t pol_buf_bytes;
+    float* pol_raw;         // device staging of raw fp32 weights for the host-pointer form of set_policy
+    size_t pol_raw_bytes;
+    int pol_form;           // DPENV_LAUNCH_* requested
     bool has_policy;
     int device;
     std::string err;
@@ -103,6 +108,7 @@ extern "C" int dpenv_default_config(dpenv_config* c)
     c->current_tau = 100.0f;                           // SURVEY 8(d) config 5 (build-defined)
     c->current_sigma_v = 0.02f;
     c->current_sigma_beta = 5.0f * 3.14159265358979f / 180.0f;
+    c->reset_acts = 0;             // customEnv.py:30 reset_acts=False
     return DPENV_OK;
 }
 
@@ -233,7 +239,9 @@ extern "C" int dpenv_create(const dpenv_config* cfg, const float* vessel_params,
     h->device = dev;
     h->classes_assigned = false;
     h->current_set = false;
-    h->pol_frags = nullptr;
+    h->pol_buf = nullptr; h->pol_buf_bytes = 0;
+    h->pol_raw = nullptr; h->pol_raw_bytes = 0;
+    h->pol_form = DPENV_LAUNCH_AUTO;
     h->has_policy = false;
     std::memset(&h->pol, 0, sizeof h->pol);
 
@@ -263,6 +271,7 @@ extern "C" int dpenv_create(const dpenv_config* cfg, const float* vessel_params,
     const size_t o_b0 = off; off += npad * 4;
     const size_t o_dc = off; off += npad * 4;
     const size_t o_ci = off; off += npad * 4;
+    const size_t o_nc = off; off += npad * 4;
     const size_t o_ct = off; off += align_up(sizeof(VesselDev) * MAX_CLASSES, 256);
     h->blob_bytes = off;
     void* blob = nullptr;
@@ -289,6 +298,7 @@ extern "C" int dpenv_create(const dpenv_config* cfg, const float* vessel_params,
     h->cur_vc0 = (float*)(b + o_v0); h->cur_beta0 = (float*)(b + o_b0);
     h->drift_ctr = (uint32_t*)(b + o_dc);
     h->class_id = (int32_t*)(b + o_ci);
+    h->noise_ctr = (uint32_t*)(b + o_nc);
     a.class_tab = (const float*)(b + o_ct);
     a.n_classes = n_classes;
     a.v0 = tab[0];
@@ -315,6 +325,8 @@ extern "C" int dpenv_create(const dpenv_config* cfg, const float* vessel_params,
     a.seed_hi = (uint32_t)(cfg->seed >> 32);
     a.env_id_base = cfg->env_id_base;
     a.reset_fraction = cfg->reset_fraction;
+    a.reset_acts = cfg->reset_acts ? 1 : 0;
+    a.noise_ctr = h->noise_ctr;
     *out = h;
     return DPENV_OK;
 }
@@ -324,7 +336,8 @@ extern "C" int dpenv_destroy(dpenv_handle h)
     if (!h) return DPENV_EINVAL;
     DeviceGuard dev_guard(h->device);
     if (h->blob) (void)hipFree(h->blob);
-    if (h->pol_frags) (void)hipFree(h->pol_frags);
+    if (h->pol_buf) (void)hipFree(h->pol_buf);
+    if (h->pol_raw) (void)hipFree(h->pol_raw);
     delete h;
     return DPENV_OK;
 }
@@ -456,40 +469,7 @@ extern "C" int dpenv_rollout(dpenv_handle h, const dpenv_rollout_io* io, dpenv_s
 }
 
 // ---- actor-critic ------------------------------------------------------------------------------------------
-static uint16_t float_to_half(float f)
-{
-    // IEEE binary32 -> binary16, round to nearest even
-    uint32_t x;
-    std::memcpy(&x, &f, 4);
-    const uint32_t sign = (x >> 16) & 0x8000u;
-    const int32_t e = (int32_t)((x >> 23) & 0xff) - 127 + 15;
-    uint32_t m = x & 0x7fffffu;
-    if (((x >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7c00u | (m ? 0x200u : 0u));
-    if (e >= 31) return (uint16_t)(sign | 0x7c00u);
-    if (e <= 0) {
-        if (e < -10) return (uint16_t)sign;
-        m |= 0x800000u;
-        const int shift = 14 - e;
-        uint32_t hm = m >> shift;
-        const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
-        if (rem > half || (rem == half && (hm & 1u))) hm++;
-        return (uint16_t)(sign | hm);
-    }
-    uint32_t hm = m >> 13;
-    const uint32_t rem = m & 0x1fffu;
-    uint32_t out = sign | ((uint32_t)e << 10) | hm;
-    if (rem > 0x1000u || (rem == 0x1000u && (hm & 1u))) out++;
-    return (uint16_t)out;
-}
-
-// Pack one MLP into MFMA A-operand fragments (see dpenv_policy.hip).  Fragment f, lane l = (r = l & 31, h = l >> 5),
-// element j holds W^T[out row 32 mo + r][input slot k(f, h, j)]:
-//   first layer : k = 8 h + j                                  (slots 0..in-1 = inputs, slot 15 = bias)
-//   later layers: k = 32 mt + 16 s + 8 (j >> 2) + 4 h + (j & 3) (the accumulator-as-operand order), KS = ceil(H / 16)
-//                 k-steps; their biases go into `bias` as accumulator-layout tiles: block b, half h, register r16
-//                 -> b[out row 32 mo + 8 (r16 >> 2) + 4 h + (r16 & 3)]
-static int pack_net(const dpenv_mlp* m, int in_dim, int out_dim, std::vector<uint16_t>& out, std::vector<float>& bias, int* ks_out,
-                    std::string* why)
+static int check_net(const dpenv_mlp* m, int in_dim, int out_dim, std::string* why)
 {
     const int nl = m->n_layers;
     if (nl < 2 || nl > 5) { *why = "n_layers must be in [2, 5]"; return DPENV_EINVAL; }
@@ -498,105 +478,128 @@ static int pack_net(const dpenv_mlp* m, int in_dim, int out_dim, std::vector<uin
     if (in_dim > 15 || out_dim > 8 || H < 1 || H > 96) { *why = "limits: obs_dim <= 15, out <= 8, hidden width <= 96"; return DPENV_EINVAL; }
     for (int l = 1; l < nl; ++l) if (m->sizes[l] != H) { *why = "hidden widths must be equal"; return DPENV_EINVAL; }
     for (int l = 0; l < nl; ++l) if (!m->W[l] || !m->b[l]) { *why = "NULL weight pointer"; return DPENV_EINVAL; }
-    const int n_hidden = nl - 1;
-    const int KS = H <= 80 ? 5 : 6;
-    const int nfrag = 3 + 3 * KS * (n_hidden - 1) + KS;
-    const int nblk = 3 * (n_hidden - 1) + 1;
-    *ks_out = KS;
-    out.assign((size_t)nfrag * 64 * 8, 0);
-    bias.assign((size_t)nblk * 32, 0.0f);
-    auto put = [&](int f, int lane, int j, float v) { out[((size_t)f * 64 + lane) * 8 + j] = float_to_half(v); };
-    for (int lane = 0; lane < 64; ++lane) {
-        const int r = lane & 31, hh = lane >> 5;
-        for (int j = 0; j < 8; ++j) {
-            for (int mo = 0; mo < 3; ++mo) {                       // first layer
-                const int k = 8 * hh + j, row = 32 * mo + r;
-                float v = 0.0f;
-                if (row < H) v = (k < in_dim) ? m->W[0][(size_t)k * H + row] : (k == 15 ? m->b[0][row] : 0.0f);
-                put(mo, lane, j, v);
-            }
-            for (int ks = 0; ks < KS; ++ks) {
-                const int mt = ks >> 1, s2 = ks & 1;
-                const int f = 32 * mt + 16 * s2 + 8 * (j >> 2) + 4 * hh + (j & 3);
-                for (int l = 1; l < n_hidden; ++l)                 // hidden -> hidden
-                    for (int mo = 0; mo < 3; ++mo) {
-                        const int row = 32 * mo + r;
-                        put(3 + 3 * KS * (l - 1) + mo * KS + ks, lane, j, (row < H && f < H) ? m->W[l][(size_t)f * H + row] : 0.0f);
-                    }
-                put(3 + 3 * KS * (n_hidden - 1) + ks, lane, j, (r < out_dim && f < H) ? m->W[nl - 1][(size_t)f * out_dim + r] : 0.0f);   // output layer
-            }
-        }
-    }
-    for (int hh = 0; hh < 2; ++hh)
-        for (int r16 = 0; r16 < 16; ++r16) {
-            const int rr = 8 * (r16 >> 2) + 4 * hh + (r16 & 3);
-            for (int l = 1; l < n_hidden; ++l)
-                for (int mo = 0; mo < 3; ++mo) {
-                    const int row = 32 * mo + rr;
-                    bias[((size_t)(3 * (l - 1) + mo)) * 32 + hh * 16 + r16] = row < H ? m->b[l][row] : 0.0f;
-                }
-            bias[((size_t)(3 * (n_hidden - 1))) * 32 + hh * 16 + r16] = rr < out_dim ? m->b[nl - 1][rr] : 0.0f;
-        }
-    return nfrag;
+    return DPENV_OK;
 }
 
-extern "C" int dpenv_set_policy(dpenv_handle h, const dpenv_mlp* pi, const dpenv_mlp* v, const float* log_std, float leak)
+extern "C" int dpenv_set_policy_desc(dpenv_handle h, const dpenv_policy_desc* d, dpenv_stream s)
 {
-    return dpenv_set_policy_ex(h, pi, v, log_std, DPENV_ACT_LEAKY_RELU, leak);
+    if (!h) return DPENV_EINVAL;
+    if (!d || d->struct_size != sizeof(dpenv_policy_desc)) return fail(h, DPENV_EINVAL, "dpenv_policy_desc ABI mismatch");
+    if (d->activation != DPENV_ACT_LEAKY_RELU && d->activation != DPENV_ACT_TANH)
+        return fail(h, DPENV_EINVAL, "activation must be DPENV_ACT_LEAKY_RELU or DPENV_ACT_TANH");
+    if (d->precision != DPENV_POLICY_F16 && d->precision != DPENV_POLICY_F32) return fail(h, DPENV_EINVAL, "bad precision");
+    if (d->launch_form < DPENV_LAUNCH_AUTO || d->launch_form > DPENV_LAUNCH_TWO_WAVE) return fail(h, DPENV_EINVAL, "bad launch_form");
+    if (d->activation == DPENV_ACT_LEAKY_RELU && !(d->leak >= 0.0f && d->leak <= 1.0f))
+        return fail(h, DPENV_EINVAL, "leaky-relu slope must be in [0, 1] (evaluated as max(x, leak x))");
+    DeviceGuard dev_guard(h->device);
+    const dpenv_mlp* pi = d->pi;
+    const dpenv_mlp* v = d->v;
+    if (!pi || !v || !d->log_std) return fail(h, DPENV_EINVAL, "dpenv_set_policy: NULL argument");
+    if (pi->n_layers != v->n_layers || pi->sizes[1] != v->sizes[1])
+        return fail(h, DPENV_EINVAL, "actor and critic must have the same hidden shape");
+    const int od = dpenv_obs_dim(&h->cfg), ad = dpenv_act_dim(&h->cfg);
+    std::string why;
+    if (check_net(pi, od, ad, &why) != DPENV_OK) return fail(h, DPENV_EINVAL, "actor: %s", why.c_str());
+    if (check_net(v, od, 1, &why) != DPENV_OK) return fail(h, DPENV_EINVAL, "critic: %s", why.c_str());
+    const int nl = pi->n_layers, n_hidden = nl - 1, H = pi->sizes[1];
+    const int ks = H <= 80 ? 5 : 6;
+    const int nfrag = 3 + 3 * ks * (n_hidden - 1) + ks;
+    const int nblk = 3 * (n_hidden - 1) + 1;
+    const int split = d->precision == DPENV_POLICY_F32;
+    const size_t bytes_frags = (size_t)2 * nfrag * 64 * 16 * (1 + split), bytes_bias = (size_t)2 * nblk * 32 * sizeof(float);
+    // the launch form decides the LDS footprint: refuse here what the rollout could not launch
+    const size_t lds_image = bytes_frags + bytes_bias, lds_max = 160 * 1024;
+    const bool fits_two = !split && lds_image + POLICY_WS_MAILBOX_BYTES <= lds_max;
+    const bool fits_one = lds_image + (split ? 0 : POLICY_STAGING_BYTES) <= lds_max;
+    if (!fits_one) return fail(h, DPENV_EINVAL, "networks do not fit the 160 KiB LDS (%zu bytes of fragments and biases)", lds_image);
+    if (d->launch_form == DPENV_LAUNCH_TWO_WAVE && !fits_two)
+        return fail(h, DPENV_EINVAL, split ? "DPENV_POLICY_F32 has no two-wave form (its weight image fills the LDS)"
+                                           : "networks + the two-wave form's mailboxes exceed the 160 KiB LDS: use DPENV_LAUNCH_ONE_WAVE");
+    const size_t need = bytes_frags + bytes_bias + 24 * sizeof(float);
+    if (h->pol_buf && h->pol_buf_bytes < need) {
+        // growing the image: a launch that still reads the old one may be in flight
+        HIP_TRY(h, hipDeviceSynchronize());
+        (void)hipFree(h->pol_buf); h->pol_buf = nullptr;
+    }
+    if (!h->pol_buf) {
+        if (hipMalloc(&h->pol_buf, need) != hipSuccess) return fail(h, DPENV_ENOMEM, "hipMalloc of the policy image failed");
+        h->pol_buf_bytes = need;
+    }
+    PackNet pn[2];
+    const float* ls_dev = d->log_std;
+    if (!d->device_pointers) {
+        // host weights: stage them raw in device memory (stream-ordered copies), then pack on the device like the other form
+        size_t raw = 8;
+        for (int k = 0; k < 2; ++k) {
+            const dpenv_mlp* m = k ? v : pi;
+            for (int l = 0; l < nl; ++l) raw += (size_t)m->sizes[l] * m->sizes[l + 1] + m->sizes[l + 1];
+        }
+        if (h->pol_raw && h->pol_raw_bytes < raw * sizeof(float)) { HIP_TRY(h, hipDeviceSynchronize()); (void)hipFree(h->pol_raw); h->pol_raw = nullptr; }
+        if (!h->pol_raw) {
+            void* p = nullptr;
+            if (hipMalloc(&p, raw * sizeof(float)) != hipSuccess) return fail(h, DPENV_ENOMEM, "hipMalloc of the weight staging failed");
+            h->pol_raw = (float*)p; h->pol_raw_bytes = raw * sizeof(float);
+        }
+        float* cursor = h->pol_raw;
+        HIP_TRY(h, hipMemcpyAsync(cursor, d->log_std, sizeof(float) * ad, hipMemcpyHostToDevice, (hipStream_t)s));
+        ls_dev = cursor; cursor += 8;
+        for (int k = 0; k < 2; ++k) {
+            const dpenv_mlp* m = k ? v : pi;
+            for (int l = 0; l < nl; ++l) {
+                const size_t nw = (size_t)m->sizes[l] * m->sizes[l + 1], nb = m->sizes[l + 1];
+                HIP_TRY(h, hipMemcpyAsync(cursor, m->W[l], nw * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)s));
+                pn[k].W[l] = cursor; cursor += nw;
+                HIP_TRY(h, hipMemcpyAsync(cursor, m->b[l], nb * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)s));
+                pn[k].b[l] = cursor; cursor += nb;
+            }
+        }
+    } else {
+        for (int k = 0; k < 2; ++k) {
+            const dpenv_mlp* m = k ? v : pi;
+            for (int l = 0; l < nl; ++l) { pn[k].W[l] = m->W[l]; pn[k].b[l] = m->b[l]; }
+        }
+    }
+    for (int k = 0; k < 2; ++k) {
+        pn[k].n_layers = nl; pn[k].in_dim = od; pn[k].H = H; pn[k].out_dim = k ? 1 : ad;
+        for (int l = nl; l < 5; ++l) { pn[k].W[l] = nullptr; pn[k].b[l] = nullptr; }
+    }
+    char* base = (char*)h->pol_buf;
+    float* bias = (float*)(base + bytes_frags);
+    float* consts = (float*)(base + bytes_frags + bytes_bias);
+    HIP_TRY(h, dpenv_dev_launch_pack_policy(&pn[0], &pn[1], ls_dev, ad, ks, nfrag, nblk, split, base, bias, consts, (hipStream_t)s));
+    PolicyArgs& pa = h->pol;
+    std::memset(&pa, 0, sizeof pa);
+    pa.frags = (const uint4*)base;
+    pa.bias = bias;
+    pa.consts = consts;
+    pa.nfrag = nfrag;
+    pa.nblk = nblk;
+    pa.ks = ks;
+    pa.act = d->activation;
+    pa.split = split;
+    pa.n_hidden = n_hidden;
+    pa.leak = d->leak;
+    // AUTO: the two-wave form where it exists and fits (the faster one), else one wave per 64 envs
+    pa.ws = d->launch_form == DPENV_LAUNCH_TWO_WAVE ? 1 : (d->launch_form == DPENV_LAUNCH_ONE_WAVE ? 0 : (fits_two ? 1 : 0));
+    h->pol_form = d->launch_form;
+    h->has_policy = true;
+    return DPENV_OK;
 }
 
 extern "C" int dpenv_set_policy_ex(dpenv_handle h, const dpenv_mlp* pi, const dpenv_mlp* v, const float* log_std, int32_t activation,
                                    float leak)
 {
-    if (!h) return DPENV_EINVAL;
-    if (activation != DPENV_ACT_LEAKY_RELU && activation != DPENV_ACT_TANH)
-        return fail(h, DPENV_EINVAL, "dpenv_set_policy_ex: activation must be DPENV_ACT_LEAKY_RELU or DPENV_ACT_TANH");
-    DeviceGuard dev_guard(h->device);
-    if (!pi || !v || !log_std) return fail(h, DPENV_EINVAL, "dpenv_set_policy: NULL argument");
-    if (pi->n_layers != v->n_layers || pi->sizes[1] != v->sizes[1])
-        return fail(h, DPENV_EINVAL, "actor and critic must have the same hidden shape");
-    const int od = dpenv_obs_dim(&h->cfg), ad = dpenv_act_dim(&h->cfg);
-    std::vector<uint16_t> fp, fv;
-    std::vector<float> bp, bv;
-    std::string why;
-    int ks = 0, ks2 = 0;
-    const int nf = pack_net(pi, od, ad, fp, bp, &ks, &why);
-    if (nf < 0) return fail(h, DPENV_EINVAL, "actor: %s", why.c_str());
-    const int nf2 = pack_net(v, od, 1, fv, bv, &ks2, &why);
-    if (nf2 < 0) return fail(h, DPENV_EINVAL, "critic: %s", why.c_str());
-    const size_t bytes_net = (size_t)nf * 64 * 16, bytes_bias = bp.size() * sizeof(float);
-    if (2 * (bytes_net + bytes_bias) + 4 * 64 * 9 * 4 > 160 * 1024) return fail(h, DPENV_EINVAL, "networks do not fit the 160 KiB LDS");
-    if (h->pol_frags && h->pol.nfrag != nf) { (void)hipFree(h->pol_frags); h->pol_frags = nullptr; }
-    if (!h->pol_frags) {
-        void* p = nullptr;
-        if (hipMalloc(&p, 2 * (bytes_net + bytes_bias)) != hipSuccess) return fail(h, DPENV_ENOMEM, "hipMalloc of the policy fragments failed");
-        h->pol_frags = (uint4*)p;
-    }
-    // not on the step path: make sure no launch that still reads the previous weights is in flight on any stream
-    HIP_TRY(h, hipDeviceSynchronize());
-    char* base = (char*)h->pol_frags;
-    HIP_TRY(h, hipMemcpy(base, fp.data(), bytes_net, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(base + bytes_net, fv.data(), bytes_net, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(base + 2 * bytes_net, bp.data(), bytes_bias, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(base + 2 * bytes_net + bytes_bias, bv.data(), bytes_bias, hipMemcpyHostToDevice));
-    PolicyArgs& pa = h->pol;
-    std::memset(&pa, 0, sizeof pa);
-    pa.frags = h->pol_frags;
-    pa.bias = (const float*)(base + 2 * bytes_net);
-    pa.nfrag = nf;
-    pa.nblk = (int)(bp.size() / 32);
-    pa.ks = ks;
-    pa.act = activation;
-    pa.n_hidden = pi->n_layers - 1;
-    pa.leak = leak;
-    for (int k = 0; k < 8; ++k) {
-        const float ls = k < ad ? log_std[k] : 0.0f;
-        pa.std[k] = expf(ls);
-        pa.inv_std_eps[k] = 1.0f / (expf(ls) + 1e-8f);                       // core.py:45, EPS = 1e-8
-        pa.logp_const[k] = k < ad ? (-ls - 0.5f * logf(2.0f * 3.14159265358979323846f)) : 0.0f;
-    }
-    h->has_policy = true;
-    return DPENV_OK;
+    dpenv_policy_desc d;
+    std::memset(&d, 0, sizeof d);
+    d.struct_size = (uint32_t)sizeof d;
+    d.pi = pi; d.v = v; d.log_std = log_std; d.activation = activation; d.leak = leak;
+    d.precision = DPENV_POLICY_F16; d.launch_form = DPENV_LAUNCH_AUTO; d.device_pointers = 0;
+    return dpenv_set_policy_desc(h, &d, nullptr);
+}
+
+extern "C" int dpenv_set_policy(dpenv_handle h, const dpenv_mlp* pi, const dpenv_mlp* v, const float* log_std, float leak)
+{
+    return dpenv_set_policy_ex(h, pi, v, log_std, DPENV_ACT_LEAKY_RELU, leak);
 }
 
 extern "C" int dpenv_policy_forward(dpenv_handle h, const float* obs, float* mu_out, float* v_out, int32_t n, dpenv_stream s)
@@ -605,8 +608,12 @@ extern "C" int dpenv_policy_forward(dpenv_handle h, const float* obs, float* mu_
     DeviceGuard dev_guard(h->device);
     if (!h->has_policy) return fail(h, DPENV_EINVAL, "dpenv_set_policy has not been called");
     if (!obs || !mu_out || !v_out || n <= 0) return fail(h, DPENV_EINVAL, "dpenv_policy_forward: bad argument");
-    HIP_TRY(h, dpenv_dev_launch_policy_forward(&h->pol, dpenv_obs_dim(&h->cfg), dpenv_act_dim(&h->cfg), obs, mu_out, v_out, n,
-                                               (hipStream_t)s));
+    if (h->pol.split)
+        HIP_TRY(h, dpenv_dev_launch_policy_forward_x(&h->pol, dpenv_obs_dim(&h->cfg), dpenv_act_dim(&h->cfg), obs, mu_out, v_out, n,
+                                                     (hipStream_t)s));
+    else
+        HIP_TRY(h, dpenv_dev_launch_policy_forward(&h->pol, dpenv_obs_dim(&h->cfg), dpenv_act_dim(&h->cfg), obs, mu_out, v_out, n,
+                                                   (hipStream_t)s));
     return DPENV_OK;
 }
 
@@ -635,7 +642,8 @@ extern "C" int dpenv_policy_rollout(dpenv_handle h, const dpenv_policy_rollout_i
         return fail(h, DPENV_EINVAL, "T > 0 and every output block are required");
     if (h->cfg.action_layout != DPENV_AOS || h->cfg.obs_layout != DPENV_AOS)
         return fail(h, DPENV_EINVAL, "policy rollout needs AOS layouts");
-    if (h->n_classes > 1) return fail(h, DPENV_EINVAL, "policy rollout supports one vessel class");
+    if (h->n_classes > 1 && !h->classes_assigned)
+        return fail(h, DPENV_EINVAL, "n_classes > 1 but dpenv_set_vessel_class was never called");
     if (io->n_switch < 0 || io->n_switch > DPENV_MAX_SWITCH || (io->n_switch > 0 && !io->refs))
         return fail(h, DPENV_EINVAL, "bad setpoint schedule");
     for (int k = 0; k < io->n_switch; ++k)
@@ -647,16 +655,13 @@ extern "C" int dpenv_policy_rollout(dpenv_handle h, const dpenv_policy_rollout_i
     pa.T = io->T; pa.noise = io->noise; pa.obs_out = io->obs; pa.act_out = io->act; pa.rew = io->reward; pa.val = io->value;
     pa.logp = io->logp; pa.done = io->done; pa.boot = io->boot; pa.last_obs = io->last_obs; pa.last_val = io->last_value;
     pa.n_switch = io->n_switch; pa.refs = io->refs;
-    {
-        // launch form: DPENV_POLICY_WS=0/1 overrides; default = the wave-specialised form
-        const char* e = getenv("DPENV_POLICY_WS");
-        pa.ws = e ? (e[0] != '0') : 1;
-    }
+    pa.sample = io->sample ? 1 : 0;
     for (int k = 0; k < io->n_switch; ++k) pa.switch_step[k] = io->switch_step[k];
 #ifdef DPENV_WS_SELFCHECK
     pa.dbg = g_selfcheck_buf;
 #endif
-    HIP_TRY(h, dpenv_dev_launch_policy_rollout(&a, &pa, h->mode, h->cfg.extended_state, (hipStream_t)s));
+    if (pa.split) HIP_TRY(h, dpenv_dev_launch_policy_rollout_x(&a, &pa, h->mode, h->cfg.extended_state, (hipStream_t)s));
+    else HIP_TRY(h, dpenv_dev_launch_policy_rollout(&a, &pa, h->mode, h->cfg.extended_state, (hipStream_t)s));
     return DPENV_OK;
 }
 
@@ -689,13 +694,24 @@ extern "C" int dpenv_thrust_map(const float* params, const float* n_pct, const f
     return DPENV_OK;
 }
 
-extern "C" int dpenv_gae(const float* rew, const float* val, const uint8_t* end, const float* boot, const float* last_val,
-                         int32_t T, int32_t n, float gamma, float lam, float* adv_out, float* ret_out, dpenv_stream s)
+extern "C" int64_t dpenv_gae_workspace_bytes(int32_t n) { return n > 0 ? dpenv_dev_gae_workspace_bytes(n) : 0; }
+
+extern "C" int dpenv_gae_stats(const float* rew, const float* val, const uint8_t* end, const float* boot, const float* last_val,
+                               int32_t T, int32_t n, float gamma, float lam, float* adv_out, float* ret_out, void* workspace,
+                               double* stats_out, dpenv_stream s)
 {
     if (!rew || !val || !adv_out || !ret_out || T <= 0 || n <= 0)
         return fail(nullptr, DPENV_EINVAL, "dpenv_gae: bad argument");
-    HIP_TRY(nullptr, dpenv_dev_launch_gae(rew, val, end, boot, last_val, T, n, gamma, lam, adv_out, ret_out, (hipStream_t)s));
+    if (stats_out && !workspace) return fail(nullptr, DPENV_EINVAL, "dpenv_gae_stats: statistics need the workspace (dpenv_gae_workspace_bytes)");
+    HIP_TRY(nullptr, dpenv_dev_launch_gae(rew, val, end, boot, last_val, T, n, gamma, lam, adv_out, ret_out, (double*)workspace,
+                                          stats_out, (hipStream_t)s));
     return DPENV_OK;
+}
+
+extern "C" int dpenv_gae(const float* rew, const float* val, const uint8_t* end, const float* boot, const float* last_val,
+                         int32_t T, int32_t n, float gamma, float lam, float* adv_out, float* ret_out, dpenv_stream s)
+{
+    return dpenv_gae_stats(rew, val, end, boot, last_val, T, n, gamma, lam, adv_out, ret_out, nullptr, nullptr, s);
 }
 
 extern "C" int dpenv_adv_sum(const float* adv, int64_t count, float* sum_out, dpenv_stream s)
@@ -715,6 +731,13 @@ extern "C" int dpenv_adv_sumsq(const float* adv, int64_t count, const float* mea
 extern "C" int dpenv_adv_apply(float* adv, int64_t count, const float* mean, const float* std, dpenv_stream s)
 {
     if (!adv || !mean || !std || count <= 0) return fail(nullptr, DPENV_EINVAL, "dpenv_adv_apply: bad argument");
-    HIP_TRY(nullptr, dpenv_dev_launch_adv_apply(adv, count, mean, std, (hipStream_t)s));
+    HIP_TRY(nullptr, dpenv_dev_launch_adv_apply(adv, count, mean, std, nullptr, 0.0, (hipStream_t)s));
+    return DPENV_OK;
+}
+
+extern "C" int dpenv_adv_apply_stats(float* adv, int64_t count, const double* stats, double total_count, dpenv_stream s)
+{
+    if (!adv || !stats || count <= 0 || !(total_count >= 1.0)) return fail(nullptr, DPENV_EINVAL, "dpenv_adv_apply_stats: bad argument");
+    HIP_TRY(nullptr, dpenv_dev_launch_adv_apply(adv, count, nullptr, nullptr, stats, total_count, (hipStream_t)s));
     return DPENV_OK;
 }

@@ -79,6 +79,8 @@ struct StepArgs {
     uint32_t seed_lo, seed_hi;
     int64_t env_id_base;
     float reset_fraction;
+    int32_t reset_acts;       // customEnv.py:179-188: previous thrust drawn at reset
+    uint32_t* noise_ctr;      // per-env count of exploration-noise draws made so far (in-kernel sampling)
 };
 
 // fused T-step rollout (dpenv_rollout)
@@ -93,20 +95,22 @@ struct RolloutArgs {
     const float* refs;        // [n_switch][3][n]
 };
 
-// actor-critic evaluated in-kernel (dpenv_policy.hip)
+// actor-critic evaluated in-kernel (dpenv_policy.hip, dpenv_policy_x.hip)
 struct PolicyArgs {
-    const uint4* frags;       // [2][nfrag][64] x 16 B: MFMA A-operand fragments (f16), actor then critic
+    const uint4* frags;       // LDS image, first part: [2 nets][nfrag][64] x 16 B MFMA A-operand fragments (f16), actor then critic;
+                              // split arithmetic: followed by the same for the LOW parts of the weights (W = hi + lo)
     const float* bias;        // [2][nblk][32] f32: bias tiles of the row-blocks after the first layer, accumulator layout
+    const float* consts;      // [24] f32 written by the packing kernel: exp(log_std) (core.py:84) | 1 / (exp(log_std) + 1e-8)
+                              // (core.py:45) | -log_std - 0.5 log(2 pi) (core.py:45), 8 slots each
     int32_t nfrag;            // fragments per net = 3 + 3 ks (n_hidden - 1) + ks
     int32_t nblk;             // bias blocks per net = 3 (n_hidden - 1) + 1
     int32_t ks;               // k-steps of 16 hidden features: 5 (width <= 80) or 6 (width <= 96)
     int32_t act;              // hidden activation: 0 leaky-relu(leak), 1 tanh
     int32_t ws;               // rollout launch form: 1 = two waves per 64 envs (policy_rollout_ws_kernel)
+    int32_t split;            // 1 = split-f16 arithmetic (DPENV_POLICY_F32): weights and activations as hi + lo f16 pairs
     int32_t n_hidden;
     float leak;               // leaky-relu slope (0.2)
-    float std[8];             // exp(log_std)                        (core.py:84)
-    float inv_std_eps[8];     // 1 / (exp(log_std) + 1e-8)           (core.py:45)
-    float logp_const[8];      // -log_std - 0.5 log(2 pi)            (core.py:45)
+    int32_t sample;           // 1: noise == NULL means "draw the exploration noise in the kernel" (policy_noise), not "a = mu"
     // rollout I/O
     int32_t T;
     const float* noise;       // [T][n][A] standard normal draws, NULL = deterministic (a = mu)
@@ -125,9 +129,25 @@ struct PolicyArgs {
     uint32_t* dbg;            // diagnostic builds only (DPENV_WS_SELFCHECK): event records, NULL otherwise
 };
 
+// device-side weight packing (pack_policy_kernel): one dense network, DEVICE pointers
+struct PackNet {
+    const float* W[5];        // W[l][in][out] row-major (tf.layers.dense kernel layout)
+    const float* b[5];
+    int32_t n_layers, in_dim, H, out_dim;
+};
+
+constexpr int POLICY_WS_MAILBOX_BYTES = 4 * (64 * 9 * 5 + 64 * 4 + 64) * 4;   // two-wave form: four groups of mailboxes
+constexpr int POLICY_STAGING_BYTES = 4 * 64 * 9 * 4;                           // one-wave form: four wave-private row areas
+
 }  // namespace dpenv
 
 extern "C" {
+hipError_t dpenv_dev_launch_pack_policy(const dpenv::PackNet* pi, const dpenv::PackNet* v, const float* log_std, int adim, int ks,
+                                        int nfrag, int nblk, int split, void* frags, float* bias, float* consts, hipStream_t s);
+hipError_t dpenv_dev_launch_policy_forward_x(const dpenv::PolicyArgs* pa, int od, int adim, const float* obs, float* mu,
+                                             float* v, int n, hipStream_t s);
+hipError_t dpenv_dev_launch_policy_rollout_x(const dpenv::StepArgs* a, const dpenv::PolicyArgs* pa, int mode, int ext,
+                                             hipStream_t s);
 hipError_t dpenv_dev_launch_policy_forward(const dpenv::PolicyArgs* pa, int od, int adim, const float* obs, float* mu,
                                            float* v, int n, hipStream_t s);
 hipError_t dpenv_dev_launch_policy_rollout(const dpenv::StepArgs* a, const dpenv::PolicyArgs* pa, int mode, int ext,
@@ -141,11 +161,13 @@ hipError_t dpenv_dev_launch_get_state(const dpenv::StepArgs* a, float* st, int32
 hipError_t dpenv_dev_launch_set_state(const dpenv::StepArgs* a, const float* st, const int32_t* ctr, hipStream_t s);
 hipError_t dpenv_dev_launch_thrust_map(const dpenv::VesselDev* vd, const float* n_pct, const float* alpha, float* tau,
                                        int n, hipStream_t s);
+int64_t dpenv_dev_gae_workspace_bytes(int n);
 hipError_t dpenv_dev_launch_gae(const float* rew, const float* val, const uint8_t* end, const float* boot,
                                 const float* last_val, int T, int n, float gamma, float lam, float* adv, float* ret,
-                                hipStream_t s);
+                                double* workspace, double* stats, hipStream_t s);
 hipError_t dpenv_dev_launch_sum(const float* x, int64_t count, const float* mean, float* out, hipStream_t s);
-hipError_t dpenv_dev_launch_adv_apply(float* x, int64_t count, const float* mean, const float* std, hipStream_t s);
+hipError_t dpenv_dev_launch_adv_apply(float* x, int64_t count, const float* mean, const float* std, const double* stats,
+                                      double total_count, hipStream_t s);
 }
 
 #endif

@@ -176,6 +176,16 @@ __device__ __forceinline__ Vessel vessel_from_lds(const float* tab, int ncls, in
     return v;
 }
 
+// T-step kernels load a lane's class block ONCE per launch straight from the [class][param] table in HBM (29 dwords per
+// lane per launch; the table is a few KiB and L2-resident): for them the register file is the staging area.
+__device__ __forceinline__ Vessel vessel_from_table(const float* tab, int cls)
+{
+    VesselDev d;
+#pragma unroll
+    for (int k = 0; k < VD_COUNT; ++k) d.p[k] = tab[cls * VD_COUNT + k];
+    return vessel_from_args(d);
+}
+
 // SupervisedTau.py:42-83: tau = B(alpha) F, F_i = K_i n_i |n_i|
 // sc != nullptr: sin/cos of the port and starboard azimuths are already known (sc = {sin_p, cos_p, sin_s, cos_s})
 __device__ __forceinline__ void thrust_map(const Vessel& ve, const float n[3], const float al[3], float& tx, float& ty,
@@ -263,20 +273,63 @@ __device__ __forceinline__ void current_components(Current& c)
     c.vcN = c.vc * cb; c.vcE = c.vc * sb;
 }
 
+// Two standard normals from two Philox words (Box-Muller): u1 in (0, 1), u2 in [0, 1), both 24-bit.
+__device__ __forceinline__ void box_muller(uint32_t wa, uint32_t wb, float& z0, float& z1)
+{
+    const float u1 = ((float)(wa >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0, 1)
+    const float u2 = (float)(wb >> 8) * (1.0f / 16777216.0f);            // [0, 1)
+    const float rad = sqrt_hw(-2.0f * logf(u1));
+    float s2, c2;
+    sincos_lean(2.0f * kPi * u2, s2, c2);
+    z0 = rad * c2; z1 = rad * s2;
+}
+
 __device__ __forceinline__ void current_drift_step(const StepArgs& a, Current& c, float vc0, float beta0, int64_t gid)
 {
     uint32_t w[4];
     philox4x32_10((uint32_t)((uint64_t)gid & 0xffffffffu), (uint32_t)((uint64_t)gid >> 32), c.ctr, 0xC0000000u, a.seed_lo,
                   a.seed_hi, w);
     c.ctr += 1u;
-    const float u1 = ((float)(w[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0, 1)
-    const float u2 = (float)(w[1] >> 8) * (1.0f / 16777216.0f);            // [0, 1)
-    const float rad = sqrt_hw(-2.0f * logf(u1));
-    float s2, c2;
-    sincos_lean(2.0f * kPi * u2, s2, c2);
-    c.vc = fmaf(a.drift_sv, rad * c2, fmaf(a.drift_a, vc0 - c.vc, c.vc));
-    c.beta = fmaf(a.drift_sb, rad * s2, fmaf(a.drift_a, beta0 - c.beta, c.beta));
+    float zc, zs;
+    box_muller(w[0], w[1], zc, zs);
+    c.vc = fmaf(a.drift_sv, zc, fmaf(a.drift_a, vc0 - c.vc, c.vc));
+    c.beta = fmaf(a.drift_sb, zs, fmaf(a.drift_a, beta0 - c.beta, c.beta));
     current_components(c);
+}
+
+// Exploration noise of the policy (core.py:85 tf.random_normal inside the graph): A standard normals for draw `ctr` of env
+// `gid`, Philox keyed by the seed with counter (global env id, per-env draw index, tag 0xA0000000 | block) -> a function of
+// the env and of how many actions it has sampled so far, not of the rank count or of the launch geometry.
+template <int A>
+__device__ __forceinline__ void policy_noise(const StepArgs& a, int64_t gid, uint32_t ctr, float xi[A])
+{
+    const uint32_t g0 = (uint32_t)((uint64_t)gid & 0xffffffffu), g1 = (uint32_t)((uint64_t)gid >> 32);
+    float z[8];
+    uint32_t w[4];
+    philox4x32_10(g0, g1, ctr, 0xA0000000u, a.seed_lo, a.seed_hi, w);
+    box_muller(w[0], w[1], z[0], z[1]);
+    box_muller(w[2], w[3], z[2], z[3]);
+    if (A > 4) {
+        philox4x32_10(g0, g1, ctr, 0xA0000001u, a.seed_lo, a.seed_hi, w);
+        box_muller(w[0], w[1], z[4], z[5]);
+        box_muller(w[2], w[3], z[6], z[7]);
+    }
+#pragma unroll
+    for (int k = 0; k < A; ++k) xi[k] = z[k];
+}
+
+// customEnv.py:179-188 (reset_acts): the episode starts with previous thrust clip(scale(N(0, 0.1))) instead of zero - thrust
+// only, azimuths keep their defaults.  Draw keyed (seed; global env id, episode, tag 2) next to the pose / velocity draws.
+__device__ __forceinline__ void sample_reset_thrust(const StepArgs& a, int64_t gid, uint32_t episode, float pt[3])
+{
+    uint32_t w[4];
+    philox4x32_10((uint32_t)((uint64_t)gid & 0xffffffffu), (uint32_t)((uint64_t)gid >> 32), episode, 2u, a.seed_lo, a.seed_hi, w);
+    float z0, z1, z2, z3;
+    box_muller(w[0], w[1], z0, z1);
+    box_muller(w[2], w[3], z2, z3);
+    pt[0] = clipf((0.1f * z0) * 100.0f, 100.0f);          // np.random.normal(0, 0.1) then scale_and_clip (ENV:181-182,215-225)
+    pt[1] = clipf((0.1f * z1) * 100.0f, 100.0f);
+    pt[2] = clipf((0.1f * z2) * 100.0f, 100.0f);
 }
 
 __device__ __forceinline__ uint16_t f2bf(float x)
@@ -577,6 +630,7 @@ __device__ __forceinline__ void env_auto_reset(const StepArgs& a, Env& s, int64_
     sample_reset<MODE>(a, gid, episode, eta, nu);
     s.N = eta[0]; s.E = eta[1]; s.psi = eta[2]; s.u = nu[0]; s.v = nu[1]; s.r = nu[2];
     s.pt[0] = s.pt[1] = s.pt[2] = 0.0f;                         // ENV:190
+    if (a.reset_acts) sample_reset_thrust(a, gid, episode, s.pt);   // ENV:179-188
     default_angles<MODE>(s.ang[0], s.ang[1], s.ang[2]);         // ENV:173-177,192
     s.steps = 0;
     bool same;

@@ -272,20 +272,22 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(const StepArgs a, const ui
     float4 s0 = a.S0[il], s1 = a.S1[il], s2 = a.S2[il], rf = a.RF[il];
     const bool sel = live && (mask == nullptr || mask[il] != 0);
     if (sel) {
-        float eta[3], nu[3];
+        float eta[3], nu[3], pt[3] = {0.0f, 0.0f, 0.0f};
+        // the episode counter advances with every reset that consumes random numbers (sampled pose, or drawn thrust)
+        const uint32_t ep = (uint32_t)a.episode[i];
+        if (!init || a.reset_acts) a.episode[i] = (int)(ep + 1u);
         if (init) {
             // explicit **init (ENV:141,152,159-161); the 50 held sub-steps (ENV:164-167) keep it in place
             for (int k = 0; k < 3; ++k) { eta[k] = init[(int64_t)k * n + i]; nu[k] = init[(int64_t)(3 + k) * n + i]; }
         } else {
-            const uint32_t ep = (uint32_t)a.episode[i];
-            a.episode[i] = (int)(ep + 1u);
             sample_reset<MODE>(a, a.env_id_base + i, ep, eta, nu);
         }
+        if (a.reset_acts) sample_reset_thrust(a, a.env_id_base + i, ep, pt);   // ENV:179-188
         float ab, ap, as;
         default_angles<MODE>(ab, ap, as);
         s0 = make_float4(eta[0], eta[1], eta[2], nu[0]);
         s1 = make_float4(nu[1], nu[2], ap, as);
-        s2 = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(0));
+        s2 = make_float4(pt[0], pt[1], pt[2], __int_as_float(0));
         rf.w = ab;
         if (ref) { rf.x = ref[i]; rf.y = ref[(int64_t)n + i]; rf.z = ref[2 * (int64_t)n + i]; }
         a.S0[i] = s0; a.S1[i] = s1; a.S2[i] = s2; a.RF[i] = rf;
@@ -347,64 +349,208 @@ __global__ __launch_bounds__(BLOCK) void thrust_map_kernel(const VesselDev vd, c
     tau[i] = tx; tau[(int64_t)n + i] = ty; tau[2 * (int64_t)n + i] = tn;
 }
 
-// ---- GAE-lambda reverse scan, one lane per env column (ppo.py:65-91, core.py:48-63) ---------------
-__global__ __launch_bounds__(BLOCK) void gae_kernel(const float* rew, const float* val, const uint8_t* end,
-                                                    const float* boot, const float* last_val, int T, int n, float gamma,
-                                                    float lam, float* adv, float* ret)
-{
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    float acc = 0.0f, g = 0.0f, vnext = 0.0f;
-    const float gl = gamma * lam;
-    for (int t = T - 1; t >= 0; --t) {
-        const int64_t k = (int64_t)t * n + i;
-        const bool is_end = (t == T - 1) || (end != nullptr && end[k] != 0);
-        if (is_end) {
-            const float lv = boot ? boot[k] : ((t == T - 1 && last_val) ? last_val[i] : 0.0f);
-            acc = 0.0f; g = lv; vnext = lv;
-        }
-        const float rk = rew[k], vk = val[k];
-        const float delta = rk + gamma * vnext - vk;
-        acc = delta + gl * acc;
-        g = rk + gamma * g;
-        adv[k] = acc; ret[k] = g;
-        vnext = vk;
-    }
-}
+// ---- GAE-lambda reverse scan (ppo.py:65-91, core.py:48-63) + advantage statistics (ppo.py:99-103, mpi_tools.py:71-92) ----
+// A lane owns V adjacent env columns (V = 4: every row access is a 16-byte load / store, 1 KiB per wave-instruction) and walks
+// them from t = T-1 down to 0.  The recurrence is serial in t, but none of the LOADS depends on it: rows are fetched U at a
+// time into one of two register buffers while the other is being consumed, so 2 U rows of every column are in flight and
+// the scan runs at memory speed instead of one HBM latency per row (round 1: 0.13 of the HBM roof).  The same pass sums adv and
+// adv^2 per lane in double; a fixed-order wave reduction leaves one partial pair per workgroup and gae_finalize_kernel adds
+// them in index order, so the statistics are bit-reproducible (no float atomics).
+constexpr int GAE_U = 4;
 
-// ---- advantage statistics (ppo.py:99-103, mpi_tools.py:71-92) --------------------------------------
-__device__ __forceinline__ float block_sum(float x, float* red)
+template <int V> struct GaeVec;
+template <> struct GaeVec<4> { typedef float4 F; typedef uint32_t E; };
+template <> struct GaeVec<1> { typedef float F; typedef uint8_t E; };
+
+template <int V> struct GaeRow {
+    typename GaeVec<V>::F r, v, b;
+    typename GaeVec<V>::E e;
+};
+
+__device__ __forceinline__ float gae_get(const float4& x, int k) { return k == 0 ? x.x : (k == 1 ? x.y : (k == 2 ? x.z : x.w)); }
+__device__ __forceinline__ float gae_get(const float& x, int) { return x; }
+__device__ __forceinline__ void gae_set(float4& x, int k, float v) { if (k == 0) x.x = v; else if (k == 1) x.y = v; else if (k == 2) x.z = v; else x.w = v; }
+__device__ __forceinline__ void gae_set(float& x, int, float v) { x = v; }
+__device__ __forceinline__ uint32_t gae_end(uint32_t e, int k) { return (e >> (8 * k)) & 0xffu; }
+__device__ __forceinline__ uint32_t gae_end(uint8_t e, int) { return e; }
+
+__device__ __forceinline__ double wave_sum_fixed(double x)
 {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) red[wave] = x;
-    __syncthreads();
-    float s = 0.0f;
-    if (threadIdx.x == 0)
-        for (int w = 0; w < BLOCK / 64; ++w) s += red[w];
-    return s;
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);      // same pairing every run
+    return x;
 }
 
-__global__ __launch_bounds__(BLOCK) void sum_kernel(const float* x, int64_t count, const float* mean, float* out)
+template <int V>
+__global__ __launch_bounds__(64) void gae_kernel(const float* __restrict__ rew, const float* __restrict__ val,
+                                                 const uint8_t* __restrict__ end, const float* __restrict__ boot,
+                                                 const float* __restrict__ last_val, int T, int n, float gamma, float lam,
+                                                 float* __restrict__ adv, float* __restrict__ ret, double* __restrict__ partials)
 {
-    __shared__ float red[BLOCK / 64];
-    const float m = mean ? mean[0] : 0.0f;
-    float s = 0.0f;
-    for (int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x; k < count; k += (int64_t)gridDim.x * BLOCK) {
-        const float d = x[k] - m;
-        s += mean ? d * d : d;
+    typedef typename GaeVec<V>::F F;
+    typedef typename GaeVec<V>::E E;
+    const int c0 = (blockIdx.x * 64 + threadIdx.x) * V;
+    const bool live = c0 < n;
+    const int cl = live ? c0 : 0;                      // dead lanes shadow column 0 and never store
+    const float gl = gamma * lam;
+    float acc[V], g[V], vnext[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { acc[k] = 0.0f; g[k] = 0.0f; vnext[k] = 0.0f; }
+    double s1 = 0.0, s2 = 0.0;
+    F lv;
+#pragma unroll
+    for (int k = 0; k < V; ++k) gae_set(lv, k, 0.0f);
+    if (last_val) lv = *(const F*)(last_val + cl);
+
+    GaeRow<V> A[GAE_U], B[GAE_U];
+    auto load = [&](GaeRow<V> (&buf)[GAE_U], int j) {
+#pragma unroll
+        for (int u = 0; u < GAE_U; ++u) {
+            int t = T - 1 - j * GAE_U - u;
+            t = t < 0 ? 0 : t;                         // past the start: re-read row 0 (never consumed)
+            const int64_t k = (int64_t)t * n + cl;
+            buf[u].r = *(const F*)(rew + k);
+            buf[u].v = *(const F*)(val + k);
+            if (boot) buf[u].b = *(const F*)(boot + k);
+            if (end) buf[u].e = *(const E*)(end + k); else buf[u].e = 0;
+        }
+    };
+    auto consume = [&](const GaeRow<V> (&buf)[GAE_U], int j) {
+#pragma unroll
+        for (int u = 0; u < GAE_U; ++u) {
+            const int t = T - 1 - j * GAE_U - u;
+            if (t < 0) break;
+            F a_out, r_out;
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const bool is_end = (t == T - 1) || (gae_end(buf[u].e, k) != 0u);
+                if (is_end) {
+                    const float l = boot ? gae_get(buf[u].b, k) : ((t == T - 1) ? gae_get(lv, k) : 0.0f);
+                    acc[k] = 0.0f; g[k] = l; vnext[k] = l;
+                }
+                const float rk = gae_get(buf[u].r, k), vk = gae_get(buf[u].v, k);
+                const float delta = rk + gamma * vnext[k] - vk;
+                acc[k] = delta + gl * acc[k];
+                g[k] = rk + gamma * g[k];
+                vnext[k] = vk;
+                gae_set(a_out, k, acc[k]);
+                gae_set(r_out, k, g[k]);
+                s1 += (double)acc[k];
+                s2 += (double)acc[k] * (double)acc[k];
+            }
+            if (live) {
+                const int64_t k = (int64_t)t * n + c0;
+                *(F*)(adv + k) = a_out;
+                *(F*)(ret + k) = r_out;
+            }
+        }
+    };
+    const int nb = (T + GAE_U - 1) / GAE_U;
+    load(A, 0);
+    for (int j = 0; j < nb; j += 2) {
+        load(B, j + 1);
+        consume(A, j);
+        load(A, j + 2);
+        consume(B, j + 1);
     }
-    s = block_sum(s, red);
-    if (threadIdx.x == 0) atomicAdd(out, s);
+    if (partials) {
+        if (!live) { s1 = 0.0; s2 = 0.0; }
+        s1 = wave_sum_fixed(s1);
+        s2 = wave_sum_fixed(s2);
+        if (threadIdx.x == 0) { partials[2 * blockIdx.x] = s1; partials[2 * blockIdx.x + 1] = s2; }
+    }
 }
 
-__global__ __launch_bounds__(BLOCK) void adv_apply_kernel(float* x, int64_t count, const float* mean, const float* std)
+// partial pairs -> {sum, sum of squares} in a fixed order: thread k adds partials k, k + 256, ... then a fixed tree over LDS
+__global__ __launch_bounds__(256) void gae_finalize_kernel(const double* __restrict__ partials, int nparts, double* __restrict__ out)
 {
-    const float m = mean[0], inv = 1.0f / (std[0] + 1e-8f);
-    for (int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x; k < count; k += (int64_t)gridDim.x * BLOCK)
+    __shared__ double red[2][256];
+    double a = 0.0, b = 0.0;
+    for (int k = threadIdx.x; k < nparts; k += 256) { a += partials[2 * k]; b += partials[2 * k + 1]; }
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) { red[0][threadIdx.x] += red[0][threadIdx.x + w]; red[1][threadIdx.x] += red[1][threadIdx.x + w]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = red[0][0]; out[1] = red[1][0]; }
+}
+
+// per-workgroup partial sums of (x - m) or (x - m)^2, float4 grid-stride reads, double accumulation, fixed order
+constexpr int SUMB = 256;
+__global__ __launch_bounds__(SUMB) void sum_partial_kernel(const float* __restrict__ x, int64_t count, const float* mean, int squared,
+                                                           double* __restrict__ partials)
+{
+    __shared__ double red[SUMB / 64];
+    const float m = mean ? mean[0] : 0.0f;
+    double s = 0.0;
+    const int64_t nvec = ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) ? count / 4 : 0;
+    for (int64_t k = (int64_t)blockIdx.x * SUMB + threadIdx.x; k < nvec; k += (int64_t)gridDim.x * SUMB) {
+        const float4 q = ((const float4*)x)[k];
+        const float d0 = q.x - m, d1 = q.y - m, d2 = q.z - m, d3 = q.w - m;
+        s += squared ? ((double)(d0 * d0) + (double)(d1 * d1) + (double)(d2 * d2) + (double)(d3 * d3))
+                     : ((double)d0 + (double)d1 + (double)d2 + (double)d3);
+    }
+    for (int64_t k = nvec * 4 + (int64_t)blockIdx.x * SUMB + threadIdx.x; k < count; k += (int64_t)gridDim.x * SUMB) {
+        const float d = x[k] - m;
+        s += squared ? (double)(d * d) : (double)d;
+    }
+    s = wave_sum_fixed(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < SUMB / 64; ++w) t += red[w];
+        partials[2 * blockIdx.x] = t; partials[2 * blockIdx.x + 1] = 0.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void sum_finalize_kernel(const double* __restrict__ partials, int nparts, float* __restrict__ out)
+{
+    __shared__ double red[256];
+    double a = 0.0;
+    for (int k = threadIdx.x; k < nparts; k += 256) a += partials[2 * k];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)red[0];
+}
+
+// adv <- (adv - mean) / (std + 1e-8)   (ppo.py:103).  STATS: mean and std from {sum, sum of squares} and the global count,
+// computed per thread in double (mean = s1 / N, std = sqrt(s2 / N - mean^2)); otherwise from device float scalars.
+template <bool STATS>
+__global__ __launch_bounds__(SUMB) void adv_apply_kernel(float* __restrict__ x, int64_t count, const float* mean, const float* std,
+                                                         const double* stats, double total_count)
+{
+    float m, inv;
+    if (STATS) {
+        const double mu = stats[0] / total_count;
+        double var = stats[1] / total_count - mu * mu;
+        var = var > 0.0 ? var : 0.0;
+        m = (float)mu;
+        inv = 1.0f / ((float)sqrt(var) + 1e-8f);
+    } else {
+        m = mean[0];
+        inv = 1.0f / (std[0] + 1e-8f);
+    }
+    const int64_t nvec = ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) ? count / 4 : 0;
+    for (int64_t k = (int64_t)blockIdx.x * SUMB + threadIdx.x; k < nvec; k += (int64_t)gridDim.x * SUMB) {
+        float4 q = ((float4*)x)[k];
+        q.x = (q.x - m) * inv; q.y = (q.y - m) * inv; q.z = (q.z - m) * inv; q.w = (q.w - m) * inv;
+        ((float4*)x)[k] = q;
+    }
+    for (int64_t k = nvec * 4 + (int64_t)blockIdx.x * SUMB + threadIdx.x; k < count; k += (int64_t)gridDim.x * SUMB)
         x[k] = (x[k] - m) * inv;
 }
+
+// scratch of the legacy three-pass entry points (dpenv_adv_sum / dpenv_adv_sumsq): per-workgroup partials.  One buffer per
+// device code object: those two calls must not run concurrently on two streams of one device (dpenv.h says so);
+// dpenv_gae_stats takes an explicit workspace instead.
+constexpr int SUM_MAXGRID = 2048;
+__device__ double g_sum_partials[2 * SUM_MAXGRID];
 
 }  // namespace dpenv
 
@@ -508,34 +654,54 @@ extern "C" hipError_t dpenv_dev_launch_thrust_map(const VesselDev* vd, const flo
     return hipGetLastError();
 }
 
+extern "C" int64_t dpenv_dev_gae_workspace_bytes(int n)
+{
+    return (((int64_t)n + 63) / 64) * 2 * (int64_t)sizeof(double);      // sized for the scalar form (one lane per column)
+}
+
 extern "C" hipError_t dpenv_dev_launch_gae(const float* rew, const float* val, const uint8_t* end, const float* boot,
                                            const float* last_val, int T, int n, float gamma, float lam, float* adv,
-                                           float* ret, hipStream_t s)
+                                           float* ret, double* workspace, double* stats, hipStream_t s)
 {
-    hipLaunchKernelGGL(gae_kernel, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, rew, val, end, boot, last_val, T, n,
-                       gamma, lam, adv, ret);
+    // 16-byte rows need n % 4 == 0 and 16-byte aligned bases (torch allocations are); anything else takes the scalar form
+    const uintptr_t al = reinterpret_cast<uintptr_t>(rew) | reinterpret_cast<uintptr_t>(val) | reinterpret_cast<uintptr_t>(adv) |
+                         reinterpret_cast<uintptr_t>(ret) | reinterpret_cast<uintptr_t>(boot) | reinterpret_cast<uintptr_t>(last_val);
+    const bool vec = (n % 4 == 0) && ((al & 15u) == 0) && ((reinterpret_cast<uintptr_t>(end) & 3u) == 0);
+    const int lanes = vec ? n / 4 : n;
+    const int grid = (lanes + 63) / 64;
+    double* parts = stats ? workspace : nullptr;
+    if (vec) hipLaunchKernelGGL(gae_kernel<4>, dim3(grid), dim3(64), 0, s, rew, val, end, boot, last_val, T, n, gamma, lam, adv, ret, parts);
+    else hipLaunchKernelGGL(gae_kernel<1>, dim3(grid), dim3(64), 0, s, rew, val, end, boot, last_val, T, n, gamma, lam, adv, ret, parts);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !stats) return e;
+    // the vector and the scalar form size their grids differently; the workspace is sized for the larger (scalar) one
+    hipLaunchKernelGGL(gae_finalize_kernel, dim3(1), dim3(256), 0, s, (const double*)parts, grid, stats);
     return hipGetLastError();
 }
 
 static int reduce_grid(int64_t count)
 {
-    int64_t g = (count + BLOCK - 1) / BLOCK;
-    if (g > 2048) g = 2048;   // 256 CUs x 8 blocks: grid-stride the rest
+    int64_t g = (count / 4 + SUMB - 1) / SUMB;
+    if (g > SUM_MAXGRID) g = SUM_MAXGRID;   // 256 CUs x 8 blocks: grid-stride the rest
     if (g < 1) g = 1;
     return (int)g;
 }
 
 extern "C" hipError_t dpenv_dev_launch_sum(const float* x, int64_t count, const float* mean, float* out, hipStream_t s)
 {
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(float), s);
+    double* parts = nullptr;
+    hipError_t e = hipGetSymbolAddress((void**)&parts, HIP_SYMBOL(g_sum_partials));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sum_kernel, dim3(reduce_grid(count)), dim3(BLOCK), 0, s, x, count, mean, out);
+    const int grid = reduce_grid(count);
+    hipLaunchKernelGGL(sum_partial_kernel, dim3(grid), dim3(SUMB), 0, s, x, count, mean, mean != nullptr ? 1 : 0, parts);
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 0, s, (const double*)parts, grid, out);
     return hipGetLastError();
 }
 
 extern "C" hipError_t dpenv_dev_launch_adv_apply(float* x, int64_t count, const float* mean, const float* std,
-                                                 hipStream_t s)
+                                                 const double* stats, double total_count, hipStream_t s)
 {
-    hipLaunchKernelGGL(adv_apply_kernel, dim3(reduce_grid(count)), dim3(BLOCK), 0, s, x, count, mean, std);
+    if (stats) hipLaunchKernelGGL(adv_apply_kernel<true>, dim3(reduce_grid(count)), dim3(SUMB), 0, s, x, count, mean, std, stats, total_count);
+    else hipLaunchKernelGGL(adv_apply_kernel<false>, dim3(reduce_grid(count)), dim3(SUMB), 0, s, x, count, mean, std, stats, total_count);
     return hipGetLastError();
 }

@@ -1,0 +1,565 @@
+// dpenv_policy_dev.h - device code shared by the policy translation units of libdpenv.so:
+//   dpenv_policy.hip    f16 network arithmetic (fast mode): forward pass, one-wave and two-wave closed-loop rollouts
+//   dpenv_policy_x.hip  split-f16 ("fp32-faithful") network arithmetic: forward pass and one-wave closed-loop rollout
+// See dpenv_policy.hip for the mapping of the MLP to the matrix cores.
+#ifndef DPENV_POLICY_DEV_H
+#define DPENV_POLICY_DEV_H
+#include "dpenv_env_dev.h"
+
+namespace dpenv {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+#ifndef DPENV_JOINT_EVAL
+#define DPENV_JOINT_EVAL 1          // actor + critic of one observation as one interleaved routine (mlp_eval2)
+#endif
+
+constexpr int PBLOCK = 256;          // 4 waves share one LDS image of the weights
+constexpr int PWAVES = PBLOCK / 64;
+
+__device__ __forceinline__ half8 ldfrag(const uint4* W, int f, int lane)
+{
+    const uint4 q = W[f * 64 + lane];
+    return __builtin_bit_cast(half8, q);
+}
+
+// bias tile of one 32-row block in accumulator layout: register r of a lane in half h holds output row
+// 8 (r >> 2) + 4 h + (r & 3); all lanes of a half read the same 64 bytes (LDS broadcast)
+__device__ __forceinline__ float16v ldbias(const float* B, int blk, int lane)
+{
+    const float4* p = (const float4*)(B + blk * 32 + (lane >> 5) * 16);
+    const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+    const float16v r = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+    return r;
+}
+
+// hidden activation + f32 -> f16 of registers 8s .. 8s+7 of an accumulator tile = the B fragment of k-step s.
+// ACT_LEAKY: leaky-relu of slope `leak` (0 = relu), the reference's default ('leaky', train.py:24,31); ACT_TANH: its
+// '--activation tanh' option (Spinning Up's own default), evaluated in f32 as 1 - 2 / (exp(2x) + 1).
+constexpr int ACT_LEAKY = 0, ACT_TANH = 1;
+
+template <int ACT>
+__device__ __forceinline__ half8 act_pack(const float16v& acc, int s, _Float16 leak)
+{
+    half8 r;
+    const half2v lk = {leak, leak};
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        if (ACT == ACT_TANH) {
+            float t[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float e = __builtin_amdgcn_exp2f(acc[8 * s + j + q] * 2.8853900817779268f);      // exp(2x)
+                t[q] = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+            }
+            const float2v tf = {t[0], t[1]};
+            const half2v h = __builtin_convertvector(tf, half2v);
+            r[j] = h[0]; r[j + 1] = h[1];
+        } else {
+            // v_cvt_pk_f16_f32 (gfx950: round-to-nearest-even, unlike v_cvt_pkrtz), then packed f16 mul + max:
+            // 1.5 instructions per activation
+            const float2v af = {acc[8 * s + j], acc[8 * s + j + 1]};
+            half2v h = __builtin_convertvector(af, half2v);
+            h = __builtin_elementwise_max(h, h * lk);
+            r[j] = h[0]; r[j + 1] = h[1];
+        }
+    }
+    return r;
+}
+
+// issue order hint for one pipeline stage: the LDS reads of the block after next first (KS weight fragments + 4 for the
+// bias tile), then N x (1 MFMA, 4 VALU) - the MFMAs of the block being multiplied against the packing of the block
+// before it
+template <int KS>
+__device__ __forceinline__ void interleave_stage()
+{
+    __builtin_amdgcn_sched_group_barrier(0x100, KS + 4, 0);
+#pragma unroll
+    for (int k = 0; k < 2 * KS; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);          // a stage draws only on its own instructions
+}
+
+// Evaluate one MLP for the 64 envs of this wave.  in0 / in1: first-layer B fragments of env tiles 0-31 / 32-63.
+// out[j], j < 8: output row j of the lane's OWN env.
+//
+// Register discipline: a layer's output is never held as a whole f32 tile set.  Each 32-row block (two
+// accumulator tiles, one per env tile) is activated and packed to f16 as soon as its MFMAs are issued, straight
+// into the next layer's B fragments; weight fragments are fetched from LDS one row-block ahead.  That keeps the
+// evaluation under the 256 architectural VGPRs, so the accumulators stay out of the AGPR half (every AGPR value
+// a VALU instruction needs costs a v_accvgpr_read).
+// KA = KS + 16 ACT: k-steps of 16 hidden features (5 or 6) and the hidden activation, as one template parameter
+template <int KA>
+__device__ __forceinline__ void mlp_eval(const uint4* W, const float* B, int n_hidden, half8 in0, half8 in1, _Float16 leak, float out[8])
+{
+    constexpr int KS = KA & 15, ACT = KA >> 4;
+    const int lane = threadIdx.x & 63;
+    const float16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    half8 b[KS][2], bn[KS][2], w[KS];
+    // first layer: one k-step, three row-blocks
+#pragma unroll
+    for (int mo = 0; mo < 3; ++mo) w[mo] = ldfrag(W, mo, lane);
+#pragma unroll
+    for (int mo = 0; mo < 3; ++mo) {
+        const float16v c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[mo], in0, zero, 0, 0, 0);
+        const float16v c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[mo], in1, zero, 0, 0, 0);
+        b[2 * mo][0] = act_pack<ACT>(c0, 0, leak); b[2 * mo][1] = act_pack<ACT>(c1, 0, leak);
+        if (2 * mo + 1 < KS) { b[2 * mo + 1][0] = act_pack<ACT>(c0, 1, leak); b[2 * mo + 1][1] = act_pack<ACT>(c1, 1, leak); }
+    }
+    // hidden -> hidden layers, software-pipelined over the three row-blocks: the MFMAs of block mo+1 are issued between
+    // the activation/packing VALU of block mo (the blocks of one layer are independent; only the last block's packing
+    // is exposed before the next layer can start)
+    int fbase = 3, bblk = 0;
+    half8 wn[KS];
+    for (int l = 1; l < n_hidden; ++l) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) w[ks] = ldfrag(W, fbase + ks, lane);
+        float16v cb = ldbias(B, bblk, lane);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(W, fbase + KS + ks, lane);
+        float16v cbn = ldbias(B, bblk + 1, lane);
+        float16v p0 = cb, p1 = cb;                                          // block 0
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            p0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks][0], p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks][1], p1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mo = 1; mo < 3; ++mo) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) w[ks] = wn[ks];
+            cb = cbn;
+            if (mo < 2) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(W, fbase + 2 * KS + ks, lane);
+                cbn = ldbias(B, bblk + 2, lane);
+            }
+            float16v c0 = cb, c1 = cb;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks][0], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks][1], c1, 0, 0, 0);
+            }
+            bn[2 * (mo - 1)][0] = act_pack<ACT>(p0, 0, leak); bn[2 * (mo - 1)][1] = act_pack<ACT>(p1, 0, leak);
+            bn[2 * (mo - 1) + 1][0] = act_pack<ACT>(p0, 1, leak); bn[2 * (mo - 1) + 1][1] = act_pack<ACT>(p1, 1, leak);
+            interleave_stage<KS>();
+            p0 = c0; p1 = c1;
+        }
+        bn[4][0] = act_pack<ACT>(p0, 0, leak); bn[4][1] = act_pack<ACT>(p1, 0, leak);
+        if (5 < KS) { bn[KS - 1][0] = act_pack<ACT>(p0, 1, leak); bn[KS - 1][1] = act_pack<ACT>(p1, 1, leak); }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { b[ks][0] = bn[ks][0]; b[ks][1] = bn[ks][1]; }
+        fbase += 3 * KS;
+        bblk += 3;
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) w[ks] = ldfrag(W, fbase + ks, lane);
+    const float16v cb = ldbias(B, bblk, lane);
+    float16v c0 = cb, c1 = cb;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks][0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks][1], c1, 0, 0, 0);
+    }
+    // rows 0..3 sit in registers 0..3 of lane half 0, rows 4..7 in registers 0..3 of lane half 1, for the 32 envs
+    // of each tile: one permlane32 swap per register brings every env's 8 rows home to its own lane
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(c0[j]), __float_as_uint(c1[j]), false, false);
+        out[j] = __uint_as_float(r[0]);
+        out[4 + j] = __uint_as_float(r[1]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Actor AND critic of the same observation as one interleaved routine.
+//
+// Evaluated one after the other (mlp_eval twice) every row-block is "12 MFMAs, wait for them, ~48 VALU of
+// leaky-relu + f16 packing" - the activation needs the tile the matrix pipe has just been given, so MFMA and VALU
+// never overlap and a lone wave per SIMD pays for both in full (PMC: matrix pipe 27 % busy, VALU issue the rest).
+// The two networks are independent, so their row-blocks are alternated P0 V0 P1 V1 P2 V2 per layer and software-
+// pipelined across that sequence: while the matrix pipe works through the MFMAs of block i+1 the wave issues the
+// activation/packing VALU of block i (sched_group_barrier: 1 MFMA, 4 VALU, ...).  Across a layer boundary the pending
+// block is the critic's last one, which the actor's first block of the next layer does not depend on.
+// Same MFMA chains and same packing as mlp_eval: results are bit-identical to two separate evaluations.
+// ---------------------------------------------------------------------------------------------
+struct Acc2 {
+    float16v c0, c1;
+};
+
+template <int KS>
+__device__ __forceinline__ Acc2 mfma_block(const half8 (&w)[KS], const half8 (&b)[KS][2], const float16v& cinit)
+{
+    Acc2 r = {cinit, cinit};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        r.c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks][0], r.c0, 0, 0, 0);
+        r.c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks][1], r.c1, 0, 0, 0);
+    }
+    return r;
+}
+
+template <int KA>
+__device__ __forceinline__ void pack_block(const Acc2& a, half8 (&dst)[KA & 15][2], int mo, _Float16 leak)
+{
+    constexpr int KS = KA & 15, ACT = KA >> 4;
+    dst[2 * mo][0] = act_pack<ACT>(a.c0, 0, leak); dst[2 * mo][1] = act_pack<ACT>(a.c1, 0, leak);
+    if (2 * mo + 1 < KS) { dst[2 * mo + 1][0] = act_pack<ACT>(a.c0, 1, leak); dst[2 * mo + 1][1] = act_pack<ACT>(a.c1, 1, leak); }
+}
+
+template <int KA>
+__device__ __forceinline__ void mlp_eval2(const uint4* Wp, const uint4* Wv, const float* Bp, const float* Bv, int n_hidden,
+                                          half8 in0, half8 in1, _Float16 leak, float outp[8], float outv[8])
+{
+    constexpr int KS = KA & 15;
+    const int lane = threadIdx.x & 63;
+    half8 bP[KS][2], bV[KS][2], nP[KS][2], nV[KS][2], w[KS], wn[KS];
+    Acc2 pend;                                   // the block whose activation/packing is still to be issued
+    // ---- first layer: one k-step per block (2 MFMAs against ~48 VALU): VALU-bound whatever the order -------------
+    {
+        half8 wp[3], wv[3];
+#pragma unroll
+        for (int mo = 0; mo < 3; ++mo) { wp[mo] = ldfrag(Wp, mo, lane); wv[mo] = ldfrag(Wv, mo, lane); }
+        const float16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        auto first = [&](const half8& wf) {
+            Acc2 r;
+            r.c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, in0, zero, 0, 0, 0);
+            r.c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, in1, zero, 0, 0, 0);
+            return r;
+        };
+        Acc2 a = first(wp[0]);
+#pragma unroll
+        for (int mo = 0; mo < 3; ++mo) {
+            Acc2 v = first(wv[mo]);
+            pack_block<KA>(a, bP, mo, leak);
+            if (mo < 2) a = first(wp[mo + 1]);
+            if (mo < 2) pack_block<KA>(v, bV, mo, leak); else pend = v;
+        }
+    }
+    // bV[4] (and bV[5]) are still pending in `pend`
+    int fbase = 3, bblk = 0;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) w[ks] = ldfrag(Wp, fbase + ks, lane);
+    float16v cb = ldbias(Bp, bblk, lane), cbn;
+    for (int l = 1; l < n_hidden; ++l) {
+        // stage P0: needs bP only; the critic's last block of the layer before is packed underneath it
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(Wv, fbase + ks, lane);
+        cbn = ldbias(Bv, bblk, lane);
+        Acc2 cur = mfma_block<KS>(w, bP, cb);
+        pack_block<KA>(pend, bV, 2, leak);
+        interleave_stage<KS>();
+        Acc2 prev = cur;
+#pragma unroll
+        for (int mo = 0; mo < 3; ++mo) {
+            // stage V_mo under the packing of P_mo
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) w[ks] = wn[ks];
+            cb = cbn;
+            if (mo < 2) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(Wp, fbase + (mo + 1) * KS + ks, lane);
+                cbn = ldbias(Bp, bblk + mo + 1, lane);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(Wp, fbase + 3 * KS + ks, lane);   // next layer's (or the output's) P0
+                cbn = ldbias(Bp, bblk + 3, lane);
+            }
+            cur = mfma_block<KS>(w, bV, cb);
+            pack_block<KA>(prev, nP, mo, leak);
+            interleave_stage<KS>();
+            prev = cur;
+            if (mo < 2) {
+                // stage P_{mo+1} under the packing of V_mo
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) w[ks] = wn[ks];
+                cb = cbn;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(Wv, fbase + (mo + 1) * KS + ks, lane);
+                cbn = ldbias(Bv, bblk + mo + 1, lane);
+                cur = mfma_block<KS>(w, bP, cb);
+                pack_block<KA>(prev, nV, mo, leak);
+                interleave_stage<KS>();
+                prev = cur;
+            }
+        }
+        pend = prev;                              // V2 of this layer
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { bP[ks][0] = nP[ks][0]; bP[ks][1] = nP[ks][1]; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { bV[ks][0] = nV[ks][0]; bV[ks][1] = nV[ks][1]; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) w[ks] = wn[ks];
+        cb = cbn;
+        fbase += 3 * KS;
+        bblk += 3;
+    }
+    // ---- output layer: one row-block per network --------------------------------------------------------------
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(Wv, fbase + ks, lane);
+    cbn = ldbias(Bv, bblk, lane);
+    const Acc2 op = mfma_block<KS>(w, bP, cb);
+    pack_block<KA>(pend, bV, 2, leak);
+    interleave_stage<KS>();
+    const Acc2 ov = mfma_block<KS>(wn, bV, cbn);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(op.c0[j]), __float_as_uint(op.c1[j]), false, false);
+        outp[j] = __uint_as_float(r[0]);
+        outp[4 + j] = __uint_as_float(r[1]);
+        const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(ov.c0[j]), __float_as_uint(ov.c1[j]), false, false);
+        outv[j] = __uint_as_float(q[0]);
+        outv[4 + j] = __uint_as_float(q[1]);
+    }
+}
+
+// first-layer B fragments from the per-lane observation row: input slot k < OD = obs[k], slot 15 = 1 (bias)
+template <int OD>
+__device__ __forceinline__ void obs_to_frags(const float o[9], half8& in0, half8& in1)
+{
+    // The f32 observation is what gets rounded to f16, whichever kernel produced it: without the barrier the compiler
+    // folds the last FMA of an observation element computed in this kernel into v_fma_mixlo_f16 (ONE rounding), while a
+    // row that came through memory or an LDS mailbox is rounded twice - about one env in a thousand then sees a
+    // different f16 input, and the launch forms of the rollout stop being bit-identical.
+    float x[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        x[k] = o[k];
+        if (k < OD) asm volatile("" : "+v"(x[k]));
+    }
+    half8 P, Q;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) P[k] = (_Float16)(k < OD ? x[k] : 0.0f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) Q[k] = (_Float16)((8 + k) < OD ? x[(8 + k) < 9 ? (8 + k) : 8] : 0.0f);
+    Q[7] = (_Float16)1.0f;
+    const uint4 p = __builtin_bit_cast(uint4, P), q = __builtin_bit_cast(uint4, Q);
+    uint4 a, b;
+    auto r0 = __builtin_amdgcn_permlane32_swap(p.x, q.x, false, false); a.x = r0[0]; b.x = r0[1];
+    auto r1 = __builtin_amdgcn_permlane32_swap(p.y, q.y, false, false); a.y = r1[0]; b.y = r1[1];
+    auto r2 = __builtin_amdgcn_permlane32_swap(p.z, q.z, false, false); a.z = r2[0]; b.z = r2[1];
+    auto r3 = __builtin_amdgcn_permlane32_swap(p.w, q.w, false, false); a.w = r3[0]; b.w = r3[1];
+    in0 = __builtin_bit_cast(half8, a);   // envs 0..31: lanes 0..31 carry slots 0..7, lanes 32..63 slots 8..15
+    in1 = __builtin_bit_cast(half8, b);   // envs 32..63
+}
+
+// a = mu + std * xi (core.py:85) and its log-likelihood (gaussian_likelihood, core.py:42-46); c = consts of PolicyArgs in registers
+template <int A>
+struct PolicyConsts {
+    float std[A], inv_std_eps[A], logp_const[A];
+};
+
+template <int A>
+__device__ __forceinline__ PolicyConsts<A> load_policy_consts(const PolicyArgs& pa)
+{
+    PolicyConsts<A> c;
+#pragma unroll
+    for (int k = 0; k < A; ++k) { c.std[k] = pa.consts[k]; c.inv_std_eps[k] = pa.consts[8 + k]; c.logp_const[k] = pa.consts[16 + k]; }
+    return c;
+}
+
+template <int A>
+__device__ __forceinline__ float sample_action(const PolicyConsts<A>& c, const float mu[A], const float xi[A], float act[A])
+{
+    float logp = 0.0f;
+#pragma unroll
+    for (int k = 0; k < A; ++k) {
+        act[k] = fmaf(c.std[k], xi[k], mu[k]);
+        const float z = (act[k] - mu[k]) * c.inv_std_eps[k];
+        logp += fmaf(-0.5f * z, z, c.logp_const[k]);
+    }
+    return logp;
+}
+
+template <int A>
+__device__ __forceinline__ float mean_action(const PolicyConsts<A>& c, const float mu[A], float act[A])
+{
+    float logp = 0.0f;
+#pragma unroll
+    for (int k = 0; k < A; ++k) { act[k] = mu[k]; logp += c.logp_const[k]; }
+    return logp;
+}
+
+// this lane's vessel: its class block from the table in HBM, or the single class of the kernel arguments; either way in
+// vector registers for the whole launch
+__device__ __forceinline__ Vessel launch_vessel(const StepArgs& a, int il)
+{
+    Vessel ve = (a.n_classes > 1) ? vessel_from_table(a.class_tab, a.class_id[il]) : vessel_from_args(a.v0);
+    pin_vessel_in_vgprs(ve);
+    return ve;
+}
+
+// LDS image: [2][nfrag][64] weight fragments (16 B each) | [2][nblk][32] bias floats | wave-private row staging
+template <int THREADS>
+__device__ __forceinline__ void stage_weights_n(uint4* lds, const PolicyArgs& pa)
+{
+    const int total = 2 * pa.nfrag * 64 * (1 + pa.split);
+    for (int k = threadIdx.x; k < total; k += THREADS) lds[k] = pa.frags[k];
+    float* lb = (float*)(lds + total);
+    for (int k = threadIdx.x; k < 2 * pa.nblk * 32; k += THREADS) lb[k] = pa.bias[k];
+    __syncthreads();
+}
+__device__ __forceinline__ void stage_weights(uint4* lds, const PolicyArgs& pa) { stage_weights_n<PBLOCK>(lds, pa); }
+
+__device__ __forceinline__ int policy_lds_io_offset_floats(const PolicyArgs& pa)      // after fragments and biases
+{
+    return 2 * pa.nfrag * 64 * 4 * (1 + pa.split) + 2 * pa.nblk * 32;
+}
+
+// wave-private AoS row I/O through LDS for a 64-env slice of a 256-thread workgroup
+template <int W>
+__device__ __forceinline__ void wave_store_rows(float* lds_w, void* dst, int64_t row0_elems, int64_t rem, const float* v, int lane,
+                                                bool bf16 = false)
+{
+    lds_order<64>();
+#pragma unroll
+    for (int k = 0; k < W; ++k) lds_w[lane * W + k] = v[k];
+    lds_order<64>();
+    store_rows<W, 64>(dst, row0_elems, rem, bf16, lds_w, lane);
+}
+
+template <int W>
+__device__ __forceinline__ void wave_rows_from_regs(float* lds_w, const float pre[W], float row[W], int lane)
+{
+    lds_order<64>();
+#pragma unroll
+    for (int j = 0; j < W; ++j) lds_w[j * 64 + lane] = pre[j];
+    lds_order<64>();
+#pragma unroll
+    for (int k = 0; k < W; ++k) row[k] = lds_w[lane * W + k];
+}
+
+
+// =============================================================================================
+//  Split-f16 ("fp32-faithful") evaluation - DPENV_POLICY_F32.
+//
+//  The reference's networks are fp32 (core.py:29-33,80-107).  The matrix cores' fp32 MFMA runs at 1/16 of the f16 rate, so the
+//  exact mode keeps the f16 instruction and splits both operands instead: W = Wh + Wl and x = xh + xl with
+//  xh = f16(x), xl = f16(x - xh) (22 significand bits together), and  W x ~= Wh xh + Wh xl + Wl xh  - three MFMAs per
+//  product, f32 accumulation, the dropped Wl xl term is 2^-22 relative.  Activations (leaky-relu / tanh) are evaluated in
+//  f32 on the accumulator and split again.  Result: within ~1e-6 of an fp32 evaluation (tests: 1e-5 of the output scale),
+//  at 3x the matrix work and ~3x the packing work of the f16 mode.  Same fragment layout as the f16 mode: the LDS image
+//  carries a second set of fragments for Wl.
+// =============================================================================================
+template <int ACT>
+__device__ __forceinline__ void act_split(const float16v& acc, int s, float leak, half8& hi, half8& lo)
+{
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = acc[8 * s + j];
+        float h;
+        if (ACT == ACT_TANH) {
+            const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);      // exp(2x)
+            h = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+        } else {
+            h = fmaxf(x, leak * x);                                               // leaky-relu, 0 <= leak <= 1
+        }
+        const _Float16 hh = (_Float16)h;
+        hi[j] = hh;
+        lo[j] = (_Float16)(h - (float)hh);
+    }
+}
+
+__device__ __forceinline__ float16v mfma3(const half8& wh, const half8& wl, const half8& bh, const half8& bl, float16v c)
+{
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh, c, 0, 0, 0);
+    return c;
+}
+
+struct SplitIn {
+    half8 h0, h1, l0, l1;      // first-layer B fragments of env tiles 0-31 / 32-63, high and low parts
+};
+
+template <int OD>
+__device__ __forceinline__ void obs_to_frags_x(const float o[9], SplitIn& in)
+{
+    half8 Ph, Qh, Pl, Ql;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const float x = (k < OD) ? o[k < 9 ? k : 8] : 0.0f;
+        const _Float16 h = (_Float16)x;
+        const _Float16 l = (_Float16)(x - (float)h);
+        if (k < 8) { Ph[k] = h; Pl[k] = l; } else { Qh[k - 8] = h; Ql[k - 8] = l; }
+    }
+    Qh[7] = (_Float16)1.0f;        // slot 15: the bias input; its low part stays 0
+    auto swap4 = [](const half8& P, const half8& Q, half8& a, half8& b) {
+        const uint4 p = __builtin_bit_cast(uint4, P), q = __builtin_bit_cast(uint4, Q);
+        uint4 x, y;
+        auto r0 = __builtin_amdgcn_permlane32_swap(p.x, q.x, false, false); x.x = r0[0]; y.x = r0[1];
+        auto r1 = __builtin_amdgcn_permlane32_swap(p.y, q.y, false, false); x.y = r1[0]; y.y = r1[1];
+        auto r2 = __builtin_amdgcn_permlane32_swap(p.z, q.z, false, false); x.z = r2[0]; y.z = r2[1];
+        auto r3 = __builtin_amdgcn_permlane32_swap(p.w, q.w, false, false); x.w = r3[0]; y.w = r3[1];
+        a = __builtin_bit_cast(half8, x); b = __builtin_bit_cast(half8, y);
+    };
+    swap4(Ph, Qh, in.h0, in.h1);
+    swap4(Pl, Ql, in.l0, in.l1);
+}
+
+template <int KA>
+__device__ __forceinline__ void mlp_eval_x(const uint4* Wh, const uint4* Wl, const float* B, int n_hidden, const SplitIn& in, float leak,
+                                           float out[8])
+{
+    constexpr int KS = KA & 15, ACT = KA >> 4;
+    const int lane = threadIdx.x & 63;
+    const float16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    half8 bh[KS][2], bl[KS][2], nh[KS][2], nl[KS][2];
+#pragma unroll
+    for (int mo = 0; mo < 3; ++mo) {
+        const half8 wh = ldfrag(Wh, mo, lane), wl = ldfrag(Wl, mo, lane);
+        const float16v c0 = mfma3(wh, wl, in.h0, in.l0, zero), c1 = mfma3(wh, wl, in.h1, in.l1, zero);
+        act_split<ACT>(c0, 0, leak, bh[2 * mo][0], bl[2 * mo][0]);
+        act_split<ACT>(c1, 0, leak, bh[2 * mo][1], bl[2 * mo][1]);
+        if (2 * mo + 1 < KS) {
+            act_split<ACT>(c0, 1, leak, bh[2 * mo + 1][0], bl[2 * mo + 1][0]);
+            act_split<ACT>(c1, 1, leak, bh[2 * mo + 1][1], bl[2 * mo + 1][1]);
+        }
+    }
+    int fbase = 3, bblk = 0;
+    for (int l = 1; l < n_hidden; ++l) {
+#pragma unroll
+        for (int mo = 0; mo < 3; ++mo) {
+            float16v c0 = ldbias(B, bblk + mo, lane), c1 = c0;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const half8 wh = ldfrag(Wh, fbase + mo * KS + ks, lane), wl = ldfrag(Wl, fbase + mo * KS + ks, lane);
+                c0 = mfma3(wh, wl, bh[ks][0], bl[ks][0], c0);
+                c1 = mfma3(wh, wl, bh[ks][1], bl[ks][1], c1);
+            }
+            act_split<ACT>(c0, 0, leak, nh[2 * mo][0], nl[2 * mo][0]);
+            act_split<ACT>(c1, 0, leak, nh[2 * mo][1], nl[2 * mo][1]);
+            if (2 * mo + 1 < KS) {
+                act_split<ACT>(c0, 1, leak, nh[2 * mo + 1][0], nl[2 * mo + 1][0]);
+                act_split<ACT>(c1, 1, leak, nh[2 * mo + 1][1], nl[2 * mo + 1][1]);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { bh[ks][0] = nh[ks][0]; bh[ks][1] = nh[ks][1]; bl[ks][0] = nl[ks][0]; bl[ks][1] = nl[ks][1]; }
+        fbase += 3 * KS;
+        bblk += 3;
+    }
+    float16v c0 = ldbias(B, bblk, lane), c1 = c0;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const half8 wh = ldfrag(Wh, fbase + ks, lane), wl = ldfrag(Wl, fbase + ks, lane);
+        c0 = mfma3(wh, wl, bh[ks][0], bl[ks][0], c0);
+        c1 = mfma3(wh, wl, bh[ks][1], bl[ks][1], c1);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(c0[j]), __float_as_uint(c1[j]), false, false);
+        out[j] = __uint_as_float(r[0]);
+        out[4 + j] = __uint_as_float(r[1]);
+    }
+}
+
+}  // namespace dpenv
+
+#endif

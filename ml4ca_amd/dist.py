@@ -4,7 +4,7 @@ The reference's only parallelism is data-parallel env ownership per MPI rank (sp
 ppo.py:226) with gradient all-reduce / parameter broadcast per optimiser step (spinup/utils/mpi_tf.py).
 Here envs never interact, so a rank owns a contiguous block of global env ids and steps it locally; the
 single exchange step is the all-gather of trajectory blocks at episode boundaries (BASELINE.json config 4),
-plus the two scalar all-reduces of the advantage statistics (rollout.normalize_advantages).
+plus the 24-byte all-reduce of the advantage statistics (rollout.combine_stats / normalize_advantages).
 Backend: "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
 """
 
@@ -43,10 +43,30 @@ def gather_trajectories(block, group=None, out=None, async_op=False):
     return (out, work) if async_op else out
 
 
+def gather_rollout(blocks, group=None, out=None, async_op=False):
+    """Episode-boundary exchange of a rollout (BASELINE.json config 4) WITHOUT a packed staging copy: every block of
+    ``RolloutBuffer.trajectory()`` ([T, n_local, ...]) is all-gathered from where the rollout kernel wrote it into
+    out[name] of shape [world, T, n_local, ...] (allocated when ``out`` is None; pass it back in to reuse it).  The five
+    collectives are issued back to back on the backend's stream; 19 floats per env-step cross xGMI in total, as with one
+    [T, n, 19] block, but nothing is concatenated first (that copy was 2 GB of extra HBM traffic at 65 536 x 400).
+    Returns out, or (out, [work, ...]) with async_op=True."""
+    out = {} if out is None else out
+    works = []
+    for name, blk in blocks.items():
+        res = gather_trajectories(blk, group=group, out=out.get(name), async_op=async_op)
+        if async_op:
+            out[name], w = res
+            works.append(w)
+        else:
+            out[name] = res
+    return (out, works) if async_op else out
+
+
 def to_global_env_order(gathered):
-    """[world, T, n_local, F] -> [T, world * n_local, F]: env axis in global id order."""
-    w, T, n, F = gathered.shape
-    return gathered.permute(1, 0, 2, 3).reshape(T, w * n, F)
+    """[world, T, n_local, ...] -> [T, world * n_local, ...]: env axis in global id order."""
+    w, T, n = gathered.shape[:3]
+    rest = tuple(gathered.shape[3:])
+    return gathered.movedim(0, 1).reshape((T, w * n) + rest)
 
 
 def average_gradients(params, group=None):

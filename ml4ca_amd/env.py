@@ -89,8 +89,6 @@ class BatchedRevoltEnv(object):
                  current_drift=False, current_tau=100.0, current_sigma_v=0.02, current_sigma_beta=5.0 * math.pi / 180.0,
                  n_steps=None, reset_acts=False):
         torch = _torch()
-        if reset_acts and auto_reset:
-            raise ValueError('reset_acts (ENV:179-188) is applied by reset(); the in-kernel auto-reset starts episodes with zero previous thrust')
         if not torch.cuda.is_available():
             raise RuntimeError('BatchedRevoltEnv needs a ROCm device: the env.step path is a HIP kernel and has no CPU fallback')
         self.lib = _lib.load()
@@ -102,7 +100,6 @@ class BatchedRevoltEnv(object):
         self.cont_ang = bool(cont_ang) and variant == 'final'
         self.testing = bool(testing)
         self.reset_actions = bool(reset_acts)                        # ENV:30,179-188
-        self._reset_gen = None
         self.n_envs = int(n_envs)
         self.num_actions = k['num_actions']
         self.num_states = 9 if extended_state else 6                 # ENV:44
@@ -148,6 +145,7 @@ class BatchedRevoltEnv(object):
         cfg.current_tau = float(current_tau)
         cfg.current_sigma_v = float(current_sigma_v)
         cfg.current_sigma_beta = float(current_sigma_beta)
+        cfg.reset_acts = int(self.reset_actions)                     # drawn inside the reset kernels, ENV:179-188
         self.cfg = cfg
         self.layout = layout
         self.auto_reset = bool(auto_reset)
@@ -229,24 +227,6 @@ class BatchedRevoltEnv(object):
         self._chk(obs, self.obs_shape, self.obs_torch_dtype, 'out')
         _lib.check(self.lib.dpenv_reset(self._h, self._ptr(mask), self._ptr(init), self._ptr(new_ref), self._ptr(obs),
                                         self._stream()), self._h)
-        if self.reset_actions:
-            # ENV:179-188: the episode starts with previous thrust clip(N(0, 0.1) * 100) instead of zero (thrust only)
-            if self._reset_gen is None:
-                self._reset_gen = torch.Generator(device=self.device)
-                self._reset_gen.manual_seed(int(self.cfg.seed) + 7919)
-            pt = (torch.randn((3, n), generator=self._reset_gen, device=self.device) * 10.0).clamp_(-100.0, 100.0)
-            st, _ = self.get_state()
-            rows = slice(_lib.S['PT_BOW'], _lib.S['PT_BOW'] + 3)
-            if mask is not None:
-                pt = torch.where(mask.bool()[None, :], pt, st[rows])
-            st[rows] = pt
-            self.set_state(st, None)
-            if self.extended_state:                                  # obs[6:9] = previous thrust / 100 (ENV:201-205)
-                o = (pt / 100.0).to(obs.dtype)
-                if self.layout == 'soa':
-                    obs[6:9] = o
-                else:
-                    obs[:, 6:9] = o.t()
         return obs
 
     def _next_obs(self):

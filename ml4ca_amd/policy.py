@@ -111,32 +111,55 @@ class ActorCritic(object):
         pre = -0.5 * (((act - mu) / (torch.exp(self.log_std) + 1e-8)) ** 2 + 2 * self.log_std + math.log(2 * math.pi))
         return pre.sum(dim=1)
 
-    def upload(self, env):
-        """Pack and upload to the env's library handle (dpenv_set_policy); call again after each PPO update."""
+    def upload(self, env, precision='f16', launch_form='auto'):
+        """Pack into the env's library handle (dpenv_set_policy_desc); call again after each PPO update.
+
+        precision: 'f16' (fast mode: f16 weights / activations, f32 accumulation) or 'f32' (split-f16 arithmetic within 1e-5 of an
+        fp32 evaluation - the reference's networks are fp32, core.py:29-33).  launch_form: 'auto' | 'one_wave' | 'two_wave'.
+        Parameters that live on the env's device are handed over as DEVICE pointers: one packing kernel on the current stream,
+        no host copy and no synchronisation; parameters elsewhere (CPU tensors) go through a host copy."""
+        torch = _torch()
         lib = env.lib
+        on_dev = all(p.is_cuda and p.device == env.device and p.dtype == torch.float32 and p.is_contiguous() for p in self.parameters())
+        keep = []
 
         def mk(Ws, bs):
             m = _lib.Mlp()
             m.n_layers = len(Ws)
             sizes = [Ws[0].shape[0]] + [w.shape[1] for w in Ws]
-            keep = []
             for i, sz in enumerate(sizes):
                 m.sizes[i] = int(sz)
             for i, (W, b) in enumerate(zip(Ws, bs)):
-                Wn = np.ascontiguousarray(W.detach().float().cpu().numpy())
-                bn = np.ascontiguousarray(b.detach().float().cpu().numpy())
-                keep += [Wn, bn]
-                m.W[i] = Wn.ctypes.data
-                m.b[i] = bn.ctypes.data
-            return m, keep
+                if on_dev:
+                    m.W[i], m.b[i] = W.data_ptr(), b.data_ptr()
+                else:
+                    Wn = np.ascontiguousarray(W.detach().float().cpu().numpy())
+                    bn = np.ascontiguousarray(b.detach().float().cpu().numpy())
+                    keep.extend([Wn, bn])
+                    m.W[i], m.b[i] = Wn.ctypes.data, bn.ctypes.data
+            return m
 
-        pi, k1 = mk(self.pi_W, self.pi_b)
-        v, k2 = mk(self.v_W, self.v_b)
-        ls = np.ascontiguousarray(self.log_std.detach().float().cpu().numpy())
-        act = _lib.ACT_TANH if self.activation == 'tanh' else _lib.ACT_LEAKY_RELU
-        _lib.check(lib.dpenv_set_policy_ex(env._h, C.byref(pi), C.byref(v), ls.ctypes.data_as(C.POINTER(C.c_float)),
-                                           C.c_int32(act), C.c_float(self.leak)), env._h)
+        pi, v = mk(self.pi_W, self.pi_b), mk(self.v_W, self.v_b)
+        d = _lib.PolicyDesc()
+        d.struct_size = C.sizeof(_lib.PolicyDesc)
+        d.pi, d.v = C.pointer(pi), C.pointer(v)
+        if on_dev:
+            d.log_std = self.log_std.data_ptr()
+        else:
+            ls = np.ascontiguousarray(self.log_std.detach().float().cpu().numpy())
+            keep.append(ls)
+            d.log_std = ls.ctypes.data
+        d.activation = _lib.ACT_TANH if self.activation == 'tanh' else _lib.ACT_LEAKY_RELU
+        d.leak = float(self.leak)
+        d.precision = {'f16': _lib.POLICY_F16, 'f32': _lib.POLICY_F32}[precision]
+        d.launch_form = {'auto': _lib.LAUNCH_AUTO, 'one_wave': _lib.LAUNCH_ONE_WAVE, 'two_wave': _lib.LAUNCH_TWO_WAVE}[launch_form]
+        d.device_pointers = 1 if on_dev else 0
+        with torch.cuda.device(env.device):
+            _lib.check(lib.dpenv_set_policy_desc(env._h, C.byref(d), env._stream()), env._h)
+            if not on_dev:
+                torch.cuda.current_stream(env.device).synchronize()      # the host arrays in `keep` must outlive the copies
         env._has_policy = True
+        self.precision = precision
         return self
 
 
@@ -151,11 +174,13 @@ def policy_forward(env, obs):
     return mu, v
 
 
-def policy_rollout(env, T, noise=None, switch_steps=(), refs=None, out=None):
+def policy_rollout(env, T, noise=None, switch_steps=(), refs=None, out=None, sample=None):
     """T steps of (actor -> sample -> env.step -> critic) in ONE launch: the rollout loop ppo.py:289-322 for every env.
 
-    noise: float32 [T, n, act_dim] standard-normal draws (a = mu + exp(log_std) * noise, core.py:85) or None for the
-    deterministic policy (test_policy.py:90).  Returns a dict of blocks: obs [T,n,od] (policy inputs), act [T,n,ad],
+    noise: float32 [T, n, act_dim] standard-normal draws (a = mu + exp(log_std) * noise, core.py:85), or None.  With noise None:
+    sample=True draws the exploration noise inside the kernel (Philox keyed by the seed, the global env id and the number of
+    actions the env has sampled so far - like tf.random_normal inside the reference's graph, core.py:85, but reproducible and
+    independent of the rank count); sample=False / None is the deterministic policy a = mu (test_policy.py:90).  Returns a dict of blocks: obs [T,n,od] (policy inputs), act [T,n,ad],
     rew, val, logp, boot [T,n], done [T,n] uint8, last_obs [n,od], last_val [n].  GAE: rollout.gae(rew, val, end=done, boot=boot)."""
     torch = _torch()
     n, od, ad = env.n_envs, env.num_states, env.num_actions
@@ -183,5 +208,6 @@ def policy_rollout(env, T, noise=None, switch_steps=(), refs=None, out=None):
     for j, st in enumerate(switch_steps):
         io.switch_step[j] = int(st)
     io.refs = refs.data_ptr() if k else None
+    io.sample = 1 if (sample and noise is None) else 0
     _lib.check(env.lib.dpenv_policy_rollout(env._h, C.byref(io), env._stream()), env._h)
     return out

@@ -32,12 +32,28 @@ def _req(t, shape, dtype, what):
         raise ValueError('%s must be a contiguous cuda %s tensor of shape %s' % (what, dtype, tuple(shape)))
 
 
-def gae(rew, val, end=None, boot=None, last_val=None, gamma=0.99, lam=0.97, out=None):
+_ws_cache = {}
+
+
+def _workspace(dev, n):
+    """Per-device scratch of dpenv_gae_stats (per-workgroup partial sums), grown on demand and reused."""
+    torch = _torch()
+    need = int(_lib.load().dpenv_gae_workspace_bytes(int(n)))
+    key = (dev.type, dev.index)
+    w = _ws_cache.get(key)
+    if w is None or w.numel() * 8 < need:
+        w = torch.empty((need + 7) // 8, dtype=torch.float64, device=dev)
+        _ws_cache[key] = w
+    return w
+
+
+def gae(rew, val, end=None, boot=None, last_val=None, gamma=0.99, lam=0.97, out=None, stats=None):
     """TrajectoryBuffer.finish_path (ppo.py:65-91) for every env column of a [T, n] rollout.
 
     A path ends after step t of env i where end[t, i] != 0, and always after T-1.  The value appended at a path
     end (ppo.py:82-83) is boot[t, i] if boot is given, else 0 at inner ends and last_val[i] (default 0) at T-1.
-    Returns (adv, ret), both [T, n] float32."""
+    Returns (adv, ret), both [T, n] float32.  stats: optional float64[2] cuda tensor that receives (sum adv, sum adv^2) from the
+    same pass (deterministic; feed it to normalize_advantages)."""
     torch = _torch()
     lib = _lib.load()
     T, n = rew.shape
@@ -49,20 +65,57 @@ def gae(rew, val, end=None, boot=None, last_val=None, gamma=0.99, lam=0.97, out=
     adv, ret = out if out is not None else (torch.empty_like(rew), torch.empty_like(rew))
     _req(adv, (T, n), torch.float32, 'adv')
     _req(ret, (T, n), torch.float32, 'ret')
+    _req(stats, (2,), torch.float64, 'stats')
     with torch.cuda.device(rew.device):
-        _lib.check(lib.dpenv_gae(_p(rew), _p(val), _p(end), _p(boot), _p(last_val), T, n, gamma, lam, _p(adv), _p(ret),
-                                 _s(rew)))
+        ws = _workspace(rew.device, n) if stats is not None else None
+        _lib.check(lib.dpenv_gae_stats(_p(rew), _p(val), _p(end), _p(boot), _p(last_val), T, n, gamma, lam, _p(adv), _p(ret),
+                                       _p(ws), _p(stats), _s(rew)))
     return adv, ret
 
 
-def normalize_advantages(adv, group=None):
+def combine_stats(stats, count, group=None):
+    """The all-reduce hook of the one-pass normalisation: (sum adv, sum adv^2) float64[2] of this rank and its sample count
+    -> the same over all ranks (mpi_statistics_scalar's two all-reduces, mpi_tools.py:83-87, as ONE 24-byte SUM all-reduce).
+    Pure torch + torch.distributed: runs on any backend (the gloo CPU test calls it).  Returns (stats_global, total_count)."""
+    torch = _torch()
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if not multi:
+        return stats, float(count)
+    buf = torch.empty(3, dtype=torch.float64, device=stats.device)
+    buf[0:2] = stats
+    buf[2] = float(count)
+    dist.all_reduce(buf, group=group)
+    return buf[0:2], buf[2]          # total_count stays a device scalar on GPUs: no host sync
+
+
+def normalize_advantages(adv, group=None, stats=None):
     """TrajectoryBuffer.get's normalisation (ppo.py:99-103): adv <- (adv - mean) / (std + 1e-8) with the
-    global mean / population std over all ranks (mpi_tools.py:71-92).  In place; returns (adv, mean, std)."""
+    global mean / population std over all ranks (mpi_tools.py:71-92).  In place; returns (adv, mean, std).
+
+    stats = the float64[2] tensor gae(..., stats=...) filled: one all-reduce, one apply pass, nothing read back to the host.
+    Without it the reference's own order runs: sum -> all-reduce -> mean -> sum of squared deviations -> all-reduce -> std ->
+    apply (three passes over adv; deterministic reductions)."""
     torch = _torch()
     lib = _lib.load()
     import torch.distributed as dist
     assert adv.dtype == torch.float32 and adv.is_contiguous() and adv.is_cuda
     count = adv.numel()
+    if stats is not None:
+        _req(stats, (2,), torch.float64, 'stats')
+        g, total = combine_stats(stats, count, group=group)
+        with torch.cuda.device(adv.device):
+            if isinstance(total, float):
+                _lib.check(lib.dpenv_adv_apply_stats(_p(adv), count, _p(g), total, _s(adv)))
+                mean = g[0] / total
+                std = torch.sqrt(torch.clamp(g[1] / total - mean * mean, min=0.0))
+            else:
+                # the count is a device scalar after the all-reduce: fold it into the statistics instead of reading it back
+                gn = (g / total).contiguous()                                  # (mean, E[adv^2])
+                _lib.check(lib.dpenv_adv_apply_stats(_p(adv), count, _p(gn), 1.0, _s(adv)))
+                mean = gn[0]
+                std = torch.sqrt(torch.clamp(gn[1] - mean * mean, min=0.0))
+        return adv, mean.float(), std.float()
     acc = torch.zeros(4, dtype=torch.float32, device=adv.device)   # sum, count, sumsq, -
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     with torch.cuda.device(adv.device):
@@ -79,11 +132,15 @@ def normalize_advantages(adv, group=None):
     return adv, mean[0], std[0]
 
 
+TRAJ_FIELDS = ('obs', 'act', 'rew', 'val', 'logp')      # the 9 + 7 + 1 + 1 + 1 = 19 floats per env-step of ppo.py:40-46
+
+
 class RolloutBuffer(object):
     """The reference's TrajectoryBuffer (ppo.py:21-105) for N envs at once: a [T, n_envs] block in HBM holding
     obs 9 + act 7 + rew + val + logp = 19 floats per env-step (ppo.py:40-46) plus done bits, bootstrap values,
     advantages and returns.  ``collect`` fills it with ONE launch (dpenv_policy_rollout: the loop ppo.py:289-322),
-    ``finish`` is finish_path for every path of every env, ``get`` is TrajectoryBuffer.get."""
+    ``finish`` is finish_path for every path of every env (and leaves the advantage statistics behind), ``get`` is
+    TrajectoryBuffer.get."""
 
     def __init__(self, T, env, gamma=0.99, lam=0.97):
         torch = _torch()
@@ -97,27 +154,29 @@ class RolloutBuffer(object):
                            last_obs=torch.zeros((n, od), dtype=env.obs_torch_dtype, device=dev), last_val=torch.zeros(n, dtype=f32, device=dev))
         self.adv = torch.zeros((T, n), dtype=f32, device=dev)
         self.ret = torch.zeros((T, n), dtype=f32, device=dev)
+        self.stats = torch.zeros(2, dtype=torch.float64, device=dev)
 
-    def collect(self, env, noise=None, switch_steps=(), refs=None):
+    def collect(self, env, noise=None, switch_steps=(), refs=None, sample=None):
         """Run T policy-in-the-loop steps from the env's current state into the block (the env must have a policy
-        uploaded, policy.ActorCritic.upload)."""
+        uploaded, policy.ActorCritic.upload).  sample: see policy.policy_rollout."""
         from .policy import policy_rollout
-        return policy_rollout(env, self.T, noise=noise, switch_steps=switch_steps, refs=refs, out=self.blocks)
+        return policy_rollout(env, self.T, noise=noise, switch_steps=switch_steps, refs=refs, out=self.blocks, sample=sample)
 
     def finish(self):
         """GAE-lambda advantages and rewards-to-go for every path in the block (ppo.py:65-91); paths end where done != 0
-        and at the end of the block, bootstrapped with the values the rollout kernel left in ``boot`` (ppo.py:311)."""
+        and at the end of the block, bootstrapped with the values the rollout kernel left in ``boot`` (ppo.py:311).  The same
+        pass leaves (sum adv, sum adv^2) in ``self.stats`` for ``get``."""
         b = self.blocks
-        return gae(b['rew'], b['val'], end=b['done'], boot=b['boot'], gamma=self.gamma, lam=self.lam, out=(self.adv, self.ret))
+        return gae(b['rew'], b['val'], end=b['done'], boot=b['boot'], gamma=self.gamma, lam=self.lam, out=(self.adv, self.ret),
+                   stats=self.stats)
 
     def get(self, group=None):
         """ppo.py:93-105: obs, act, normalised adv, ret, logp."""
-        normalize_advantages(self.adv, group=group)
+        normalize_advantages(self.adv, group=group, stats=self.stats)
         b = self.blocks
         return b['obs'], b['act'], self.adv, self.ret, b['logp']
 
-    def packed(self):
-        """[T, n, 19] float32 = obs 9 | act 7 | rew | val | logp: the block the episode-boundary all-gather moves."""
-        torch = _torch()
-        b = self.blocks
-        return torch.cat([b['obs'].float(), b['act'], b['rew'][..., None], b['val'][..., None], b['logp'][..., None]], dim=-1)
+    def trajectory(self):
+        """The five blocks of ppo.py:40-46 as they lie in HBM: {'obs': [T, n, 9], 'act': [T, n, 7], 'rew' / 'val' / 'logp': [T, n]}
+        (views, no copy).  dist.gather_rollout moves them between ranks in place - there is no packed [T, n, 19] staging copy."""
+        return {k: self.blocks[k] for k in TRAJ_FIELDS}

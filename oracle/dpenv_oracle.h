@@ -84,6 +84,7 @@ typedef struct dpo_config {
     double  current_tau;      /* s */
     double  current_sigma_v;  /* m/s */
     double  current_sigma_beta; /* rad */
+    int32_t reset_acts;       /* customEnv.py:30,179-188: previous thrust clip(100 N(0, 0.1)) at reset */
 } dpo_config;
 
 #define DPO_DECL(suffix, REAL)                                                                         \
@@ -103,6 +104,7 @@ typedef struct dpo_config {
     int  dpo_done_##suffix(const dpo_config* c, const REAL* obs);                                      \
     void dpo_sample_reset_##suffix(const dpo_config* c, int64_t env_gid, uint32_t episode,             \
                                    REAL eta[3], REAL nu[3]);                                           \
+    void dpo_policy_noise_##suffix(const dpo_config* c, int64_t env_gid, uint32_t draw, int32_t adim, REAL* xi); \
     void dpo_reset_##suffix(const dpo_config* c, int32_t n, REAL* state, int32_t* counters,            \
                             const uint8_t* mask, const REAL* init, const REAL* ref, REAL* obs);        \
     void dpo_step_##suffix(const dpo_config* c, const REAL* vessel, int32_t n, REAL* state,            \

@@ -341,23 +341,72 @@ void FN(dpo_sample_reset)(const dpo_config* c, int64_t gid, uint32_t episode, RE
     nu[2] = (b[5] * fv) * FN(u01_sym)(w1[1]);
 }
 
+/* Two standard normals from two Philox words (Box-Muller), u1 in (0, 1), u2 in [0, 1), both 24-bit: the build's normal
+ * generator (current drift, exploration noise, reset_acts). */
+static void FN(box_muller)(uint32_t wa, uint32_t wb, REAL* z0, REAL* z1)
+{
+    const REAL u1 = (R(wa >> 8) + R(0.5)) * R(1.0 / 16777216.0);
+    const REAL u2 = R(wb >> 8) * R(1.0 / 16777216.0);
+    const REAL rad = M_SQRT(R(-2) * M_LOG(u1));
+    const REAL ang = R(2) * PI_R * u2;
+    *z0 = rad * M_COS(ang);
+    *z1 = rad * M_SIN(ang);
+}
+
+/*
+ * Exploration noise of the policy: the reference samples pi = mu + N(0,1) exp(log_std) inside the TF graph (core.py:85) from an
+ * unseeded-by-design stream (quirk Q8), so only the distribution can match; the build draws xi for action number `draw` of env
+ * `gid` from Philox keyed by the seed with counter (global env id, draw, tag 0xA0000000 | block), four normals per block.
+ */
+void FN(dpo_policy_noise)(const dpo_config* c, int64_t gid, uint32_t draw, int32_t adim, REAL* xi)
+{
+    uint32_t key[2] = {(uint32_t)(c->seed & 0xffffffffu), (uint32_t)(c->seed >> 32)};
+    REAL z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < (adim > 4 ? 2 : 1); ++b) {
+        uint32_t ctr[4] = {(uint32_t)((uint64_t)gid & 0xffffffffu), (uint32_t)((uint64_t)gid >> 32), draw, 0xA0000000u | (uint32_t)b};
+        uint32_t w[4];
+        dpo_philox4x32_10(ctr, key, w);
+        FN(box_muller)(w[0], w[1], &z[4 * b], &z[4 * b + 1]);
+        FN(box_muller)(w[2], w[3], &z[4 * b + 2], &z[4 * b + 3]);
+    }
+    for (int k = 0; k < adim && k < 8; ++k) xi[k] = z[k];
+}
+
 static void FN(reset_one)(const dpo_config* c, int32_t n, int32_t i, REAL* state, int32_t* counters,
                           const REAL* init, const REAL* ref)
 {
-    REAL eta[3], nu[3], ang[3];
+    REAL eta[3], nu[3], ang[3], pt[3] = {R(0), R(0), R(0)};
+    /* the episode counter advances with every reset that consumes random numbers (sampled pose, or drawn thrust) */
+    const uint32_t ep = (uint32_t)counters[n + i];
+    if (!init || c->reset_acts) counters[n + i] += 1;
     if (init) {
         /* explicit **init (ENV:141,152,159-161) */
         for (int k = 0; k < 3; ++k) { eta[k] = init[k * n + i]; nu[k] = init[(3 + k) * n + i]; }
     } else {
-        FN(dpo_sample_reset)(c, c->env_id_base + i, (uint32_t)counters[n + i], eta, nu);
-        counters[n + i] += 1;
+        FN(dpo_sample_reset)(c, c->env_id_base + i, ep, eta, nu);
+    }
+    if (c->reset_acts) {
+        /* ENV:179-188: action[0:3] = np.random.normal(0, 0.1); scale_and_clip -> x 100, clip to +-100; thrust only.
+         * Draw keyed (seed; global env id, episode, tag 2) next to the pose / velocity draws (quirk Q8: distribution only). */
+        const int64_t gid = c->env_id_base + i;
+        uint32_t key[2] = {(uint32_t)(c->seed & 0xffffffffu), (uint32_t)(c->seed >> 32)};
+        uint32_t ctr[4] = {(uint32_t)((uint64_t)gid & 0xffffffffu), (uint32_t)((uint64_t)gid >> 32), ep, 2u};
+        uint32_t w[4];
+        REAL z[4];
+        dpo_philox4x32_10(ctr, key, w);
+        FN(box_muller)(w[0], w[1], &z[0], &z[1]);
+        FN(box_muller)(w[2], w[3], &z[2], &z[3]);
+        for (int k = 0; k < 3; ++k) {
+            REAL a = (R(0.1) * z[k]) * R(100);
+            pt[k] = a > R(100) ? R(100) : (a < R(-100) ? R(-100) : a);
+        }
     }
     /* the 50 held sub-steps with StateResetOn (ENV:164-167) leave the written state in place */
     for (int k = 0; k < 3; ++k) { state[(DPO_S_N + k) * n + i] = eta[k]; state[(DPO_S_U + k) * n + i] = nu[k]; }
     if (ref) for (int k = 0; k < 3; ++k) state[(DPO_S_REF_N + k) * n + i] = ref[k * n + i];
     FN(default_angles)(c, ang);
     for (int k = 0; k < 3; ++k) {
-        state[(DPO_S_PT_BOW + k) * n + i] = R(0);        /* ENV:190 */
+        state[(DPO_S_PT_BOW + k) * n + i] = pt[k];       /* ENV:190, or ENV:179-188 with reset_acts */
         state[(DPO_S_A_BOW + k) * n + i] = ang[k];       /* ENV:173-177,192 */
     }
     counters[i] = 0;
@@ -405,12 +454,10 @@ static void FN(current_drift)(const dpo_config* c, int64_t gid, uint32_t* ctr, R
     uint32_t w[4];
     dpo_philox4x32_10(ctrv, key, w);
     *ctr += 1u;
-    const REAL u1 = (R(w[0] >> 8) + R(0.5)) * R(1.0 / 16777216.0);
-    const REAL u2 = R(w[1] >> 8) * R(1.0 / 16777216.0);
-    const REAL rad = M_SQRT(R(-2) * M_LOG(u1));
-    const REAL ang = R(2) * PI_R * u2;
-    *vc = *vc + a * (vc0 - *vc) + sv * (rad * M_COS(ang));
-    *beta = *beta + a * (beta0 - *beta) + sb * (rad * M_SIN(ang));
+    REAL zc, zs;
+    FN(box_muller)(w[0], w[1], &zc, &zs);
+    *vc = *vc + a * (vc0 - *vc) + sv * zc;
+    *beta = *beta + a * (beta0 - *beta) + sb * zs;
 }
 
 void FN(dpo_step)(const dpo_config* c, const REAL* vessel, int32_t n, REAL* state, int32_t* counters,

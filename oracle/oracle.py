@@ -29,16 +29,16 @@ class Config(C.Structure):
                 ('terminate', C.c_int32), ('max_ep_len', C.c_int32), ('auto_reset', C.c_int32),
                 ('current_enabled', C.c_int32), ('seed', C.c_uint64), ('env_id_base', C.c_int64),
                 ('reset_fraction', C.c_double), ('current_drift', C.c_int32), ('current_tau', C.c_double),
-                ('current_sigma_v', C.c_double), ('current_sigma_beta', C.c_double)]
+                ('current_sigma_v', C.c_double), ('current_sigma_beta', C.c_double), ('reset_acts', C.c_int32)]
 
 
 def make_config(variant=FINAL, extended_state=1, cont_ang=1, n_substeps=20, substep_dt=0.01,
                 wrap_mode=WRAP_REFERENCE, terminate=1, max_ep_len=0, auto_reset=0, current_enabled=0,
                 seed=0, env_id_base=0, reset_fraction=0.8, current_drift=0, current_tau=100.0, current_sigma_v=0.02,
-                current_sigma_beta=5.0 * np.pi / 180.0):
+                current_sigma_beta=5.0 * np.pi / 180.0, reset_acts=0):
     return Config(variant, extended_state, cont_ang, n_substeps, substep_dt, wrap_mode, terminate,
                   max_ep_len, auto_reset, current_enabled, seed, env_id_base, reset_fraction,
-                  current_drift, current_tau, current_sigma_v, current_sigma_beta)
+                  current_drift, current_tau, current_sigma_v, current_sigma_beta, int(reset_acts))
 
 
 def build(force=False):
@@ -135,6 +135,19 @@ class Oracle(object):
         return e, v
 
     # ---- batched state machine -------------------------------------------------
+    def policy_noise(self, gids, draw, adim):
+        """Exploration noise xi [len(gids), adim] of action number `draw` (int or array) of the envs with global ids `gids`."""
+        gids = np.asarray(gids, np.int64).reshape(-1)
+        draws = np.broadcast_to(np.asarray(draw, np.uint32), gids.shape)
+        out = np.zeros((gids.size, adim), self.dtype)
+        fn = self._f('dpo_policy_noise')
+        fn.argtypes = [C.c_void_p, C.c_int64, C.c_uint32, C.c_int32, C.c_void_p]
+        row = np.zeros(8, self.dtype)
+        for j in range(gids.size):
+            fn(C.byref(self.cfg), int(gids[j]), int(draws[j]), adim, _p(row))
+            out[j] = row[:adim]
+        return out
+
     def new_state(self, n):
         return np.zeros((NSTATE, n), self.dtype), np.zeros((2, n), np.int32)
 

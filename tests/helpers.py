@@ -25,7 +25,8 @@ def make_pair(mode, n, ext=True, dtype=np.float32, device='cuda:0', **kw):
         max_ep_len=kw.get('max_ep_len', 800), hold_plant=kw.get('hold_plant', False),
         current_drift=kw.get('current_drift', False), current_tau=kw.get('current_tau', 100.0),
         current_sigma_v=kw.get('current_sigma_v', 0.02), current_sigma_beta=kw.get('current_sigma_beta', 5.0 * np.pi / 180.0),
-        n_steps=kw.get('n_steps'), testing=kw.get('testing', False), realtime=kw.get('realtime', False))
+        n_steps=kw.get('n_steps'), testing=kw.get('testing', False), realtime=kw.get('realtime', False),
+        reset_acts=kw.get('reset_acts', False))
     cfg = O.make_config(variant=ovar, extended_state=int(ext), cont_ang=ocont, n_substeps=env.n_steps,
                         wrap_mode=O.WRAP_RADIANS if kw.get('wrap_mode') == 'radians' else O.WRAP_REFERENCE,
                         terminate=int(kw.get('terminate', True)),
@@ -34,7 +35,7 @@ def make_pair(mode, n, ext=True, dtype=np.float32, device='cuda:0', **kw):
                         seed=kw.get('seed', 0), env_id_base=kw.get('env_id_base', 0),
                         reset_fraction=kw.get('reset_fraction', 0.8), current_drift=int(kw.get('current_drift', False)),
                         current_tau=kw.get('current_tau', 100.0), current_sigma_v=kw.get('current_sigma_v', 0.02),
-                        current_sigma_beta=kw.get('current_sigma_beta', 5.0 * np.pi / 180.0))
+                        current_sigma_beta=kw.get('current_sigma_beta', 5.0 * np.pi / 180.0), reset_acts=int(kw.get('reset_acts', False)))
     vessel = None
     if kw.get('vessel_params') is not None and np.asarray(kw['vessel_params']).ndim == 1:
         vessel = np.asarray(kw['vessel_params'], dtype)

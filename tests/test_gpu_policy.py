@@ -261,7 +261,9 @@ def test_policy_rollout_feeds_gae_and_ppo_buffer():
     buf.collect(env, noise=noise)
     buf.finish()
     o_, a_, adv_, ret_, lp_ = buf.get()
-    assert o_.shape == (T, n, 9) and a_.shape == (T, n, 7) and buf.packed().shape == (T, n, 19)
+    assert o_.shape == (T, n, 9) and a_.shape == (T, n, 7)
+    tr = buf.trajectory()
+    assert sum(int(np.prod(v.shape[2:])) for v in tr.values()) == 19 and all(v.shape[:2] == (T, n) for v in tr.values())
     assert abs(float(adv_.mean())) < 1e-4 and torch.isfinite(ret_).all()
 
 
@@ -457,62 +459,53 @@ def test_run_RL_policy_harness_with_the_trained_actor():
 
 def test_two_wave_rollout_equals_single_wave_rollout_repeatedly():
     """The default launch form puts an env wave and a network wave on every SIMD (policy_rollout_ws_kernel); with
-    DPENV_POLICY_WS=0 one wave does both.  Same chains of arithmetic: every row must be identical bit for bit, and must
-    stay so over repeated launches - the env wave once lost lanes 48-63 of packed-fp32 results now and then while the
-    network wave's MFMAs ran beside it (hence -fno-slp-vectorize; tools/ws_race_check.py)."""
-    import os
+    launch_form='one_wave' one wave does both.  Same chains of arithmetic: every row must be identical bit for bit, and must
+    stay so over repeated launches - built with packed fp32 the env wave once lost one term of its position sum in lanes 48-63
+    now and then beside the network wave's MFMAs (hence -fno-slp-vectorize)."""
     from ml4ca_amd.policy import policy_rollout
     torch = torch_()
     n, T = 2000 + 11, 45
     kw = dict(auto_reset=True, max_ep_len=40, seed=8, current=True, current_drift=True)
     outs = {}
-    old = os.environ.get('DPENV_POLICY_WS')
-    try:
-        for ws, reps in (('0', 1), ('1', 25)):
-            os.environ['DPENV_POLICY_WS'] = ws
-            for rep in range(reps):
-                env, _ = H.make_pair('final_cont', n, **kw)
-                make_ac(9, 7, (80, 80, 80), seed=2, device=env.device).upload(env)
-                g = torch.Generator(device=env.device).manual_seed(1)
-                env.set_current(torch.full((n,), 0.2, device=env.device), torch.full((n,), 2.3, device=env.device))
-                env.reset()
-                refs = torch.randn((2, 3, n), generator=g, device=env.device)
-                noise = torch.randn((T, n, 7), generator=g, device=env.device) if rep % 2 else None
-                out = policy_rollout(env, T, noise=noise, switch_steps=(3, 30), refs=refs)
-                st, ctr = env.get_state()
-                got = {k: v.clone() for k, v in out.items()}
-                got['state'], got['ctr'] = st, ctr
-                key = 'noise' if noise is not None else 'det'
-                if ws == '0' and key not in outs:
-                    outs[key] = got
-                    if 'noise' not in outs:          # the single-wave reference for the other input too
-                        noise2 = torch.randn((T, n, 7), generator=g, device=env.device)
-                        env_b, _ = H.make_pair('final_cont', n, **kw)
-                        make_ac(9, 7, (80, 80, 80), seed=2, device=env_b.device).upload(env_b)
-                        env_b.set_current(torch.full((n,), 0.2, device=env.device), torch.full((n,), 2.3, device=env.device))
-                        env_b.reset()
-                        ob = policy_rollout(env_b, T, noise=noise2, switch_steps=(3, 30), refs=refs)
-                        sb, cb = env_b.get_state()
-                        outs['noise'] = {k: v.clone() for k, v in ob.items()}
-                        outs['noise']['state'], outs['noise']['ctr'] = sb, cb
-                    continue
-                want = outs[key]
-                for k in want:
-                    assert torch.equal(got[k], want[k]), 'two-wave launch, repetition %d: %s differs' % (rep, k)
-    finally:
-        if old is None:
-            os.environ.pop('DPENV_POLICY_WS', None)
-        else:
-            os.environ['DPENV_POLICY_WS'] = old
+    for form, reps in (('one_wave', 1), ('two_wave', 25)):
+        for rep in range(reps):
+            env, _ = H.make_pair('final_cont', n, **kw)
+            make_ac(9, 7, (80, 80, 80), seed=2, device=env.device).upload(env, launch_form=form)
+            g = torch.Generator(device=env.device).manual_seed(1)
+            env.set_current(torch.full((n,), 0.2, device=env.device), torch.full((n,), 2.3, device=env.device))
+            env.reset()
+            refs = torch.randn((2, 3, n), generator=g, device=env.device)
+            noise = torch.randn((T, n, 7), generator=g, device=env.device) if rep % 2 else None
+            out = policy_rollout(env, T, noise=noise, switch_steps=(3, 30), refs=refs)
+            st, ctr = env.get_state()
+            got = {k: v.clone() for k, v in out.items()}
+            got['state'], got['ctr'] = st, ctr
+            key = 'noise' if noise is not None else 'det'
+            if form == 'one_wave' and key not in outs:
+                outs[key] = got
+                if 'noise' not in outs:          # the single-wave reference for the other input too
+                    noise2 = torch.randn((T, n, 7), generator=g, device=env.device)
+                    env_b, _ = H.make_pair('final_cont', n, **kw)
+                    make_ac(9, 7, (80, 80, 80), seed=2, device=env_b.device).upload(env_b, launch_form=form)
+                    env_b.set_current(torch.full((n,), 0.2, device=env.device), torch.full((n,), 2.3, device=env.device))
+                    env_b.reset()
+                    ob = policy_rollout(env_b, T, noise=noise2, switch_steps=(3, 30), refs=refs)
+                    sb, cb = env_b.get_state()
+                    outs['noise'] = {k: v.clone() for k, v in ob.items()}
+                    outs['noise']['state'], outs['noise']['ctr'] = sb, cb
+                continue
+            want = outs[key]
+            for k in want:
+                assert torch.equal(got[k], want[k]), 'two-wave launch, repetition %d: %s differs' % (rep, k)
 
 
 @pytest.mark.parametrize('case', range(12))
 def test_two_wave_rollout_random_configurations(case):
     """The two launch forms of dpenv_policy_rollout against each other over drawn configurations: variant, observation
     width, network shape and activation, ragged env counts (partly filled waves and pairs without envs), auto-reset
-    with short episodes, current with drift, bf16 rows, setpoint switches, noise on/off, odd T.  Every output block and
-    the final state must be identical bit for bit."""
-    import os
+    with short episodes (previous thrust drawn at reset or not), vessel classes, current with drift, bf16 rows, setpoint
+    switches, noise block / in-kernel noise / deterministic, odd T.  Every output block and the final state must be identical
+    bit for bit."""
     from ml4ca_amd.policy import ActorCritic, policy_rollout
     torch = torch_()
     rng = np.random.RandomState(4200 + case)
@@ -527,34 +520,37 @@ def test_two_wave_rollout_random_configurations(case):
     kw['current_drift'] = kw['current'] and bool(rng.randint(2))
     use_noise, n_sw = bool(rng.randint(2)), int(rng.randint(3))
     switch = tuple(sorted(rng.choice(T, size=min(n_sw, T), replace=False).tolist()))
+    # drawn per case as well: in-kernel exploration noise, vessel classes, previous thrust drawn at reset
+    sample = (not use_noise) and bool(rng.randint(2))
+    n_cls = int(rng.choice([1, 1, 3]))
+    kw['reset_acts'] = bool(rng.randint(2)) and ext
+    vp = None
+    if n_cls > 1:
+        from ml4ca_amd import _lib as L
+        base = L.default_vessel()
+        vp = np.stack([base * (1.0 + 0.15 * c * (np.arange(L.NPARAM) < 12)) for c in range(n_cls)]).astype(np.float32)
     res = {}
-    old = os.environ.get('DPENV_POLICY_WS')
-    try:
-        for ws in ('0', '1'):
-            os.environ['DPENV_POLICY_WS'] = ws
-            env, _ = H.make_pair(mode, n, ext=ext, **kw)
-            ac = ActorCritic(env.num_states, env.num_actions, hidden, seed=case, device=env.device, activation=activation)
-            g = torch.Generator().manual_seed(case)
-            for b in ac.pi_b + ac.v_b:
-                b.copy_((torch.rand(b.shape, generator=g) - 0.5).to(env.device) * 0.4)
-            ac.upload(env)
-            gd = torch.Generator(device=env.device).manual_seed(case)
-            if kw['current']:
-                env.set_current(torch.rand(n, generator=gd, device=env.device) * 0.3, torch.rand(n, generator=gd, device=env.device) * 6.0 - 3.0)
-            env.reset()
-            refs = torch.randn((len(switch), 3, n), generator=gd, device=env.device) if switch else None
-            noise = torch.randn((T, n, env.num_actions), generator=gd, device=env.device) if use_noise else None
-            out = policy_rollout(env, T, noise=noise, switch_steps=switch, refs=refs)
-            st, ctr = env.get_state()
-            res[ws] = {k: v.clone() for k, v in out.items()}
-            res[ws]['state'], res[ws]['ctr'] = st, ctr
-            if kw['current']:
-                res[ws]['vc'], res[ws]['beta'] = env.get_current()
-    finally:
-        if old is None:
-            os.environ.pop('DPENV_POLICY_WS', None)
-        else:
-            os.environ['DPENV_POLICY_WS'] = old
+    for ws, form in (('0', 'one_wave'), ('1', 'two_wave')):
+        env, _ = H.make_pair(mode, n, ext=ext, vessel_params=vp, **kw)
+        ac = ActorCritic(env.num_states, env.num_actions, hidden, seed=case, device=env.device, activation=activation)
+        g = torch.Generator().manual_seed(case)
+        for b in ac.pi_b + ac.v_b:
+            b.copy_((torch.rand(b.shape, generator=g) - 0.5).to(env.device) * 0.4)
+        ac.upload(env, launch_form=form)
+        gd = torch.Generator(device=env.device).manual_seed(case)
+        if n_cls > 1:
+            env.set_vessel_class(torch.randint(0, n_cls, (n,), generator=gd, device=env.device, dtype=torch.int32))
+        if kw['current']:
+            env.set_current(torch.rand(n, generator=gd, device=env.device) * 0.3, torch.rand(n, generator=gd, device=env.device) * 6.0 - 3.0)
+        env.reset()
+        refs = torch.randn((len(switch), 3, n), generator=gd, device=env.device) if switch else None
+        noise = torch.randn((T, n, env.num_actions), generator=gd, device=env.device) if use_noise else None
+        out = policy_rollout(env, T, noise=noise, switch_steps=switch, refs=refs, sample=sample)
+        st, ctr = env.get_state()
+        res[ws] = {k: v.clone() for k, v in out.items()}
+        res[ws]['state'], res[ws]['ctr'] = st, ctr
+        if kw['current']:
+            res[ws]['vc'], res[ws]['beta'] = env.get_current()
     for k in res['0']:
         a_, b_ = res['0'][k], res['1'][k]
         assert torch.equal(a_.float() if a_.dtype == torch.bfloat16 else a_, b_.float() if b_.dtype == torch.bfloat16 else b_), \

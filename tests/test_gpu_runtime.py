@@ -185,46 +185,49 @@ def test_reset_actions_option():
     st2, _ = env.get_state()
     pt2 = st2[_lib.S['PT_BOW']:_lib.S['PT_BOW'] + 3]
     assert torch.equal(pt2[:, n // 2:], pt[:, n // 2:]) and not torch.equal(pt2[:, : n // 2], pt[:, : n // 2])
-    with pytest.raises(ValueError):
-        ml4ca_amd.BatchedRevoltEnv(8, reset_acts=True, auto_reset=True)
+    # the draw is made inside the kernels (Philox keyed by seed, global env id, episode): same seed -> same thrust, and the
+    # in-kernel auto-reset applies it too
+    env_b = ml4ca_amd.BatchedRevoltEnv(n, reset_acts=True, seed=5)
+    env_b.reset()
+    st_b, _ = env_b.get_state()
+    assert torch.equal(st_b[_lib.S['PT_BOW']:_lib.S['PT_BOW'] + 3], pt)
+    env_c = ml4ca_amd.BatchedRevoltEnv(n, reset_acts=True, auto_reset=True, max_ep_len=20, seed=5, terminate=False)
+    env_c.reset()
+    zero = torch.zeros((n, 7), device=env_c.device)
+    for _ in range(10):                                       # max_ep_len 20 -> 10 agent steps per episode
+        o, r, d, _ = env_c.step(zero)
+    assert bool((d & 2).all())
+    st_c, ctr_c = env_c.get_state()
+    pt_c = st_c[_lib.S['PT_BOW']:_lib.S['PT_BOW'] + 3]
+    assert int(ctr_c[1].min()) == 2 and 9.0 < float(pt_c.std()) < 11.0 and not torch.equal(pt_c, pt)
+    assert torch.allclose(o[:, 6:9], (pt_c / 100.0).t())
 
 
 def test_two_wave_policy_rollout_full_size_soak():
     """65 536 envs (an env wave and a network wave on EVERY SIMD of the chip), auto-reset, drifting current, bf16 rows:
     ten launches of 50 steps in the two-wave form against the one-wave form, continued from each other's final state -
-    every block identical bit for bit, everything finite."""
-    import os
+    every block identical bit for bit, everything finite.  Odd launches draw the exploration noise in the kernel."""
     import ml4ca_amd
     from ml4ca_amd.policy import ActorCritic, policy_rollout
     torch = __import__('torch')
     n, T = 65536, 50
     envs = {}
-    old = os.environ.get('DPENV_POLICY_WS')
-    try:
-        for ws in ('0', '1'):
-            e = ml4ca_amd.BatchedRevoltEnv(n, auto_reset=True, seed=3, current=True, current_drift=True, obs_dtype='bfloat16')
-            ActorCritic(9, 7, (80, 80, 80), seed=4, device=e.device).upload(e)
-            e.set_current(torch.full((n,), 0.2, device=e.device), torch.full((n,), 2.356, device=e.device))
-            e.reset()
-            envs[ws] = e
-        g = torch.Generator(device=envs['0'].device).manual_seed(9)
-        for launch in range(10):
-            noise = torch.randn((T, n, 7), generator=g, device=envs['0'].device)
-            outs = {}
-            for ws in ('0', '1'):
-                os.environ['DPENV_POLICY_WS'] = ws
-                outs[ws] = policy_rollout(envs[ws], T, noise=noise)
-            for k in outs['0']:
-                a, b = outs['0'][k], outs['1'][k]
-                assert torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a, b.view(torch.int16) if b.dtype == torch.bfloat16 else b), (launch, k)
-            assert bool(torch.isfinite(outs['1']['rew']).all()) and bool(torch.isfinite(outs['1']['val']).all())
-            assert not bool((outs['1']['done'] & 4).any())
-        s0, c0 = envs['0'].get_state()
-        s1, c1 = envs['1'].get_state()
-        assert torch.equal(s0, s1) and torch.equal(c0, c1)
-        assert int(c1[1].min()) >= 1                    # every env went through at least one in-kernel reset
-    finally:
-        if old is None:
-            os.environ.pop('DPENV_POLICY_WS', None)
-        else:
-            os.environ['DPENV_POLICY_WS'] = old
+    for form in ('one_wave', 'two_wave'):
+        e = ml4ca_amd.BatchedRevoltEnv(n, auto_reset=True, seed=3, current=True, current_drift=True, obs_dtype='bfloat16')
+        ActorCritic(9, 7, (80, 80, 80), seed=4, device=e.device).upload(e, launch_form=form)
+        e.set_current(torch.full((n,), 0.2, device=e.device), torch.full((n,), 2.356, device=e.device))
+        e.reset()
+        envs[form] = e
+    g = torch.Generator(device=envs['one_wave'].device).manual_seed(9)
+    for launch in range(10):
+        noise = torch.randn((T, n, 7), generator=g, device=envs['one_wave'].device) if launch % 2 == 0 else None
+        outs = {form: policy_rollout(envs[form], T, noise=noise, sample=True) for form in envs}
+        for k in outs['one_wave']:
+            a, b = outs['one_wave'][k], outs['two_wave'][k]
+            assert torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a, b.view(torch.int16) if b.dtype == torch.bfloat16 else b), (launch, k)
+        assert bool(torch.isfinite(outs['two_wave']['rew']).all()) and bool(torch.isfinite(outs['two_wave']['val']).all())
+        assert not bool((outs['two_wave']['done'] & 4).any())
+    s0, c0 = envs['one_wave'].get_state()
+    s1, c1 = envs['two_wave'].get_state()
+    assert torch.equal(s0, s1) and torch.equal(c0, c1)
+    assert int(c1[1].min()) >= 1                    # every env went through at least one in-kernel reset

@@ -300,7 +300,7 @@ def main():
             closed['policy_dtype_' + prec] = {
                 'policy_dtype': 'f16 weights/activations, f32 accumulate (fast mode, ~5e-4 of the output scale from fp32)' if prec == 'f16'
                 else 'split-f16 hi+lo, three MFMAs per product (DPENV_POLICY_F32: within 1e-5 of an fp32 evaluation, the parity mode)',
-                'launch_form': ('two waves per 64 envs' if args.policy_form in ('auto', 'two_wave') else 'one wave per 64 envs') if prec == 'f16' else 'one wave per 64 envs',
+                'launch_form': args.policy_form if prec == 'f16' else 'one_wave',
                 'steps': kc, 'env_steps_per_s': n * kc / cwall, 'us_per_step': cwall / kc * 1e6, 'policy_TFLOPs': flops * kc / cwall / 1e12}
         closed['us_per_step'] = closed['policy_dtype_f16']['us_per_step']
         # reference point: the same policy as separate torch kernels (fp32) + one env.step launch per step

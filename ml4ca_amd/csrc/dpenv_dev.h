@@ -106,7 +106,7 @@ struct PolicyArgs {
     int32_t nblk;             // bias blocks per net = 3 (n_hidden - 1) + 1
     int32_t ks;               // k-steps of 16 hidden features: 5 (width <= 80) or 6 (width <= 96)
     int32_t act;              // hidden activation: 0 leaky-relu(leak), 1 tanh
-    int32_t ws;               // rollout launch form: 1 = two waves per 64 envs (policy_rollout_ws_kernel)
+    int32_t ws;               // rollout launch form: 0 = one wave per 64 envs, 1 = an env wave and a network wave per 64 envs (policy_rollout_ws_kernel)
     int32_t split;            // 1 = split-f16 arithmetic (DPENV_POLICY_F32): weights and activations as hi + lo f16 pairs
     int32_t n_hidden;
     float leak;               // leaky-relu slope (0.2)

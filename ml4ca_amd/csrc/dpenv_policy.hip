@@ -247,7 +247,13 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
 // =============================================================================================
 constexpr int WSBLOCK = 512;
 constexpr int WS_GROUP_FLOATS = 64 * 9 * 5 + 64 * 4 + 64;       // io | obs | pre[2] | mu | v[2] | vpre[2] | sequence words (+ pad)
+constexpr int WS3_GROUP_FLOATS = WS_GROUP_FLOATS + 64 * 9;      // three roles: a second observation mailbox (by step parity)
 
+//  ROLES = 3 (768-thread workgroups, three waves per SIMD: env / actor / critic; built only with -DDPENV_WS3, where it replaces
+//  the two-role form) was measured in round 2 and is NOT used: with two roles the network wave is the bottleneck (busy 98 % of
+//  the launch: actor + critic back to back), and a critic wave of its own takes the critic off the env -> actor chain; but three
+//  waves per SIMD leave 168 VGPRs per wave, the kernel then spills 140 B per lane, and three instruction streams (two of them
+//  MFMA + VALU mixes) share one SIMD's issue: 8.0-8.2 us per step against 7.6-7.8 for two roles (profiles/r02_closed_loop_forms.txt).
 // pair-level hand-over inside a workgroup: a sequence word in LDS, released by one wave and acquired by its partner.
 // Both waves of a pair belong to the same workgroup, so they are always co-resident; the waiter sleeps between polls.
 __device__ __forceinline__ void ws_post(int* p, int v, int lane)
@@ -274,32 +280,34 @@ __device__ __forceinline__ void ws_wait(int* p, int v)
 #else
 #define WS_EVAL(W_, B_, f0_, f1_) mlp_eval<KA>(W_, B_, pa.n_hidden, f0_, f1_, leak, outv)
 #endif
-template <int MODE, bool EXT, int KA>
-__global__ __launch_bounds__(WSBLOCK) void policy_rollout_ws_kernel(const StepArgs a, const PolicyArgs pa)
+template <int MODE, bool EXT, int KA, int ROLES>
+__global__ __launch_bounds__(256 * ROLES) void policy_rollout_ws_kernel(const StepArgs a, const PolicyArgs pa)
 {
     constexpr int A = ModeTraits<MODE>::A;
     constexpr int OD = EXT ? 9 : 6;
+    constexpr int THREADS = 256 * ROLES;
     extern __shared__ uint4 lds_dyn[];
     uint4* lds_w = lds_dyn;
     {
         const int total = 2 * pa.nfrag * 64;
-        for (int k = threadIdx.x; k < total; k += WSBLOCK) lds_w[k] = pa.frags[k];
+        for (int k = threadIdx.x; k < total; k += THREADS) lds_w[k] = pa.frags[k];
         float* lb = (float*)(lds_w + total);
-        for (int k = threadIdx.x; k < 2 * pa.nblk * 32; k += WSBLOCK) lb[k] = pa.bias[k];
+        for (int k = threadIdx.x; k < 2 * pa.nblk * 32; k += THREADS) lb[k] = pa.bias[k];
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #ifdef DPENV_WS_SWAP_ROLES
-    const bool role_m = wave < 4;          // diagnostic: the network waves are the first-dispatched (older) half
+    const int role = (ROLES - 1) - (wave >> 2);     // diagnostic: the network waves are the first-dispatched (older) ones
 #else
-    const bool role_m = wave >= 4;
+    const int role = wave >> 2;                     // 0 = env wave, 1 = network wave (ROLES 2) / actor wave (ROLES 3), 2 = critic wave
 #endif
     const int g = wave & 3;
-    float* grp = (float*)lds_dyn + policy_lds_io_offset_floats(pa) + g * WS_GROUP_FLOATS;
+    constexpr int OBS_SLOTS = ROLES == 3 ? 2 : 1;   // a trailing critic wave still needs o_t while o_t+1 is being posted
+    float* grp = (float*)lds_dyn + policy_lds_io_offset_floats(pa) + g * (ROLES == 3 ? WS3_GROUP_FLOATS : WS_GROUP_FLOATS);
     float* lds_io = grp;                         // E-wave row staging
-    float* obs_mb = grp + 64 * 9;                // o_t: one row of 9 per lane (stride 9 is conflict-free)
-    float* pre_mb = grp + 64 * 9 * 2;            // [2][64][9] pre-reset observation of a cut episode, by step parity
-    float* mu_mb = grp + 64 * 9 * 4;             // actor mean, stride 9
-    float* v_mb = grp + 64 * 9 * 5;              // [2][64] V(o_t), by step parity
+    float* obs_mb = grp + 64 * 9;                // [OBS_SLOTS][64][9] o_t (by step parity): one row of 9 per lane (stride 9 is conflict-free)
+    float* pre_mb = grp + 64 * 9 * (1 + OBS_SLOTS);   // [2][64][9] pre-reset observation of a cut episode, by step parity
+    float* mu_mb = pre_mb + 64 * 9 * 2;          // actor mean, stride 9
+    float* v_mb = mu_mb + 64 * 9;                // [2][64] V(o_t), by step parity
     float* vpre_mb = v_mb + 128;                 // [2][64] V(pre-reset o_t), by step parity
     int* seq = (int*)(vpre_mb + 128);            // [0] observations posted, [1] means posted, [2] values posted, [4..5] pre flags
     int* flag = seq + 4;
@@ -313,45 +321,55 @@ __global__ __launch_bounds__(WSBLOCK) void policy_rollout_ws_kernel(const StepAr
     const int i = wave0 + lane;
     const bool live = i < n;
     const int il = live ? i : n - 1;
-    if (!role_m && lane < 8) seq[lane] = 0;
+    if (role == 0 && lane < 8) seq[lane] = 0;
     __syncthreads();                                                         // weights staged, sequence words cleared
-    if (wave0 >= n) return;                                                  // a pair without envs: both waves leave
+    if (wave0 >= n) return;                                                  // a group without envs: all its waves leave
 
-    if (role_m) {
-        // ------------------------------------------------------------------------------------ M-wave
-        // it is the busy one of the pair (98 % against 60 %): let the SIMD's instruction arbiter prefer it
+    if (role != 0) {
+        // ------------------------------------------------------------------------------------ network wave(s)
+        // the actor is on the serial chain of the step: let the SIMD's instruction arbiter prefer it; a critic-only wave
+        // trails and takes what is left
 #ifndef DPENV_WS_NO_SETPRIO
-        __builtin_amdgcn_s_setprio(3);
+        if (ROLES == 2 || role == 1) __builtin_amdgcn_s_setprio(3);
 #endif
+        const bool do_actor = (ROLES == 2) || role == 1, do_critic = (ROLES == 2) || role == 2;
         half8 in0, in1;
         float o[9], outv[8];
-        uint64_t w_obs = 0; const uint64_t t_start = __builtin_amdgcn_s_memtime(); (void)t_start;
+        uint64_t w_obs = 0; const uint64_t t_start = __builtin_amdgcn_s_memtime(); (void)t_start; (void)w_obs;
         auto frags_from = [&](const float* mb, half8& f0, half8& f1) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) o[k] = k < OD ? mb[lane * 9 + k] : 0.0f;
             obs_to_frags<OD>(o, f0, f1);
         };
         for (int t = 0; t <= pa.T; ++t) {
+            if (!do_critic && t == pa.T) break;                              // the actor is not asked for mu_T
             WS_WAIT_T(w_obs, &seq[0], t + 1);                                // o_t posted (and step t-1's pre flag)
-            frags_from(obs_mb, in0, in1);
-            if (t < pa.T) {
+            frags_from(obs_mb + (t & (OBS_SLOTS - 1)) * (64 * 9), in0, in1);
+            if (do_actor && t < pa.T) {
                 WS_EVAL(Wpi, Bpi, in0, in1);
 #pragma unroll
                 for (int k = 0; k < A; ++k) mu_mb[lane * 9 + k] = outv[k];
                 ws_post(&seq[1], t + 1, lane);                               // mu_t posted
             }
-            WS_EVAL(Wv, Bv, in0, in1);
-            v_mb[(t & 1) * 64 + lane] = outv[0];
-            if (t > 0 && flag[(t - 1) & 1] != 0) {                           // step t-1 cut an episode that was re-drawn
-                half8 p0, p1;
-                frags_from(pre_mb + ((t - 1) & 1) * (64 * 9), p0, p1);
-                WS_EVAL(Wv, Bv, p0, p1);
-                vpre_mb[(t & 1) * 64 + lane] = outv[0];
+            if (do_critic) {
+#ifdef DPENV_WS3_TRAIL
+                // the critic of o_t starts once mu_t is out: it then runs beside the env wave's step t like in the two-role
+                // form, not beside the actor that step t is waiting for
+                if (ROLES == 3 && t < pa.T) ws_wait(&seq[1], t + 1);
+#endif
+                WS_EVAL(Wv, Bv, in0, in1);
+                v_mb[(t & 1) * 64 + lane] = outv[0];
+                if (t > 0 && flag[(t - 1) & 1] != 0) {                       // step t-1 cut an episode that was re-drawn
+                    half8 p0, p1;
+                    frags_from(pre_mb + ((t - 1) & 1) * (64 * 9), p0, p1);
+                    WS_EVAL(Wv, Bv, p0, p1);
+                    vpre_mb[(t & 1) * 64 + lane] = outv[0];
+                }
+                ws_post(&seq[2], t + 1, lane);                               // V(o_t) (and V of the pre-reset o_t) posted
             }
-            ws_post(&seq[2], t + 1, lane);                                   // V(o_t) (and V of the pre-reset o_t) posted
         }
 #ifdef DPENV_WS_PROFILE
-        if (live && pa.T >= 5) { (pa.logp + (int64_t)3 * n)[(unsigned)i] = (float)w_obs; (pa.logp + (int64_t)4 * n)[(unsigned)i] = (float)(__builtin_amdgcn_s_memtime() - t_start); }
+        if (live && pa.T >= 5 && do_actor) { (pa.logp + (int64_t)3 * n)[(unsigned)i] = (float)w_obs; (pa.logp + (int64_t)4 * n)[(unsigned)i] = (float)(__builtin_amdgcn_s_memtime() - t_start); }
 #endif
         return;
     }
@@ -384,7 +402,7 @@ __global__ __launch_bounds__(WSBLOCK) void policy_rollout_ws_kernel(const StepAr
         make_obs(s.N, s.E, s.psi, s.u, s.v, s.r, s.refN, s.refE, s.refPsi, s.pt, a.wrap_mode == WRAP_REFERENCE, o, sr_, cr_, same_);
     }
 #pragma unroll
-    for (int k = 0; k < OD; ++k) obs_mb[lane * 9 + k] = o[k];
+    for (int k = 0; k < OD; ++k) obs_mb[lane * 9 + k] = o[k];               // parity 0
     ws_post(&seq[0], 1, lane);                                               // o_0 posted
     if (pa.noise) load_rows<A, 64>(pa.noise + w_a, rem_a, lane, pre);
     int next_switch = 0;
@@ -485,10 +503,14 @@ __global__ __launch_bounds__(WSBLOCK) void policy_rollout_ws_kernel(const StepAr
                 ++episode; ep_dirty = true; rf_dirty = true;
             }
         }
-        // V(o_t) must have been read by the critic's input stage before o_{t+1} replaces it: the M-wave reads obs_mb
-        // right after it saw seq[0] = t + 1 and BEFORE it posts mu_t, which this wave has already waited for
+        // o_{t+1} replaces o_t in the mailbox: the network wave read o_t right after it saw seq[0] = t + 1 and BEFORE it posted
+        // mu_t, which this wave has waited for.  (Three roles: o_{t+1} goes into the slot of its parity, which last held o_{t-1};
+        // the actor read that before posting mu_{t-1} and the critic before posting V(o_{t-1}), both waited for in step t-1.)
+        {
+            float* om = obs_mb + ((t + 1) & (OBS_SLOTS - 1)) * (64 * 9);
 #pragma unroll
-        for (int k = 0; k < OD; ++k) obs_mb[lane * 9 + k] = o[k];           // the next policy input
+            for (int k = 0; k < OD; ++k) om[lane * 9 + k] = o[k];           // the next policy input
+        }
         ws_post(&seq[0], t + 2, lane);                                       // o_{t+1} (and this step's pre flag) posted
         if (live) {
             (pa.rew + (int64_t)t * n)[(unsigned)i] = out.reward;
@@ -648,13 +670,19 @@ template <int MODE, bool EXT, int KA>
 static hipError_t launch_policy_rollout_one(const StepArgs& a, const PolicyArgs& pa, hipStream_t s)
 {
     if (pa.ws) {
-        // two waves per 64 envs: 512-thread workgroups of 256 envs, one LDS image of the weights + four mailboxes
-        const dim3 grid((a.n + 255) / 256), block(WSBLOCK);
+        // two waves per 64 envs: 512-thread workgroups of 256 envs, one LDS image of the weights + four mailbox groups
+        const dim3 grid((a.n + 255) / 256);
+#ifdef DPENV_WS3
+        constexpr int ROLES = 3;
+        const size_t lds = (size_t)2 * pa.nfrag * 64 * 16 + (size_t)2 * pa.nblk * 32 * 4 + (size_t)4 * WS3_GROUP_FLOATS * 4;
+#else
+        constexpr int ROLES = 2;
         const size_t lds = (size_t)2 * pa.nfrag * 64 * 16 + (size_t)2 * pa.nblk * 32 * 4 + (size_t)4 * WS_GROUP_FLOATS * 4;
-        hipError_t e = hipFuncSetAttribute((const void*)policy_rollout_ws_kernel<MODE, EXT, KA>,
+#endif
+        hipError_t e = hipFuncSetAttribute((const void*)policy_rollout_ws_kernel<MODE, EXT, KA, ROLES>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((policy_rollout_ws_kernel<MODE, EXT, KA>), grid, block, lds, s, a, pa);
+        hipLaunchKernelGGL((policy_rollout_ws_kernel<MODE, EXT, KA, ROLES>), grid, dim3(256 * ROLES), lds, s, a, pa);
         return hipGetLastError();
     }
     const dim3 grid((a.n + PBLOCK - 1) / PBLOCK), block(PBLOCK);

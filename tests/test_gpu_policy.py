@@ -496,7 +496,7 @@ def test_two_wave_rollout_equals_single_wave_rollout_repeatedly():
                 continue
             want = outs[key]
             for k in want:
-                assert torch.equal(got[k], want[k]), 'two-wave launch, repetition %d: %s differs' % (rep, k)
+                assert torch.equal(got[k], want[k]), '%s launch, repetition %d: %s differs' % (form, rep, k)
 
 
 @pytest.mark.parametrize('case', range(12))
@@ -551,7 +551,8 @@ def test_two_wave_rollout_random_configurations(case):
         res[ws]['state'], res[ws]['ctr'] = st, ctr
         if kw['current']:
             res[ws]['vc'], res[ws]['beta'] = env.get_current()
-    for k in res['0']:
-        a_, b_ = res['0'][k], res['1'][k]
-        assert torch.equal(a_.float() if a_.dtype == torch.bfloat16 else a_, b_.float() if b_.dtype == torch.bfloat16 else b_), \
-            '%s differs (mode %s ext %s n %d T %d hidden %s %s %s)' % (k, mode, ext, n, T, hidden, activation, kw)
+    for other in ('1',):
+        for k in res['0']:
+            a_, b_ = res['0'][k], res[other][k]
+            assert torch.equal(a_.float() if a_.dtype == torch.bfloat16 else a_, b_.float() if b_.dtype == torch.bfloat16 else b_), \
+                '%s differs in form %s (mode %s ext %s n %d T %d hidden %s %s %s)' % (k, other, mode, ext, n, T, hidden, activation, kw)

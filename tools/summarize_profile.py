@@ -8,26 +8,32 @@ import shutil
 import statistics as st
 import sys
 
+import os
+
 tag = sys.argv[1]
 src = 'gpurun_out/prof_%s' % tag
+dst = sys.argv[2] if len(sys.argv) > 2 else 'profiles'       # on the GPU box: a directory under gpurun_out/, copied to profiles/ afterwards
+os.makedirs(dst, exist_ok=True)
 out = {'tag': tag, 'n_envs': 65536,
        'commands': {'kernel_trace': 'rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline',
                     'pmc': 'rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ_*> --output-format csv -- python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline (one pass per counter set)'},
        'correction': 'gfx950: FETCH_SIZE tallies 128-B requests of wide coalesced reads at 64 B -> x2 (MI355X_MICROARCH.md, HBM); '
                      'WRITE_SIZE exact; both in KiB', 'kernels': {}}
-shutil.copy(glob.glob(src + '/kt/*/*_kernel_stats.csv')[0], 'profiles/%s_kernel_stats.csv' % tag)
+shutil.copy(glob.glob(src + '/kt/*/*_kernel_stats.csv')[0], '%s/%s_kernel_stats.csv' % (dst, tag))
 rows = list(csv.DictReader(open(glob.glob(src + '/kt/*/*_kernel_trace.csv')[0])))
 
 
 def kname(k):
-    if 'policy_rollout_ws_kernel' in k:
-        return 'policy_rollout_ws_kernel'
-    if 'policy_rollout_kernel' in k:
-        return 'policy_rollout_kernel'
+    for n in ('policy_rollout_ws_kernel', 'policy_rollout_x_kernel', 'policy_rollout_kernel', 'gae_kernel', 'gae_finalize_kernel',
+              'adv_apply_kernel', 'pack_policy_kernel'):
+        if n in k:
+            return n
     return 'step_kernel' if 'step_kernel' in k else 'rollout_kernel' if 'rollout_kernel' in k else None
 
 
-for kn in ('step_kernel', 'rollout_kernel', 'policy_rollout_kernel', 'policy_rollout_ws_kernel'):
+ALL = ('step_kernel', 'rollout_kernel', 'policy_rollout_kernel', 'policy_rollout_ws_kernel', 'policy_rollout_x_kernel', 'gae_kernel',
+       'gae_finalize_kernel', 'adv_apply_kernel', 'pack_policy_kernel')
+for kn in ALL:
     ks = [r for r in rows if kname(r['Kernel_Name']) == kn]
     if not ks:
         continue
@@ -35,7 +41,7 @@ for kn in ('step_kernel', 'rollout_kernel', 'policy_rollout_kernel', 'policy_rol
     out['kernels'][kn] = {'full_name': ks[0]['Kernel_Name'], 'dispatches': len(d), 'avg_ns': st.mean(d), 'median_ns': st.median(d),
                           'min_ns': min(d), 'max_ns': max(d), 'vgpr': ks[0]['VGPR_Count'], 'sgpr': ks[0]['SGPR_Count'],
                           'lds_bytes': ks[0]['LDS_Block_Size'], 'workgroup': ks[0]['Workgroup_Size_X'], 'grid': ks[0]['Grid_Size_X']}
-for name in ('pmc_fetch', 'pmc_write', 'pmc_sq'):
+for name in ('pmc_fetch', 'pmc_write', 'pmc_sq', 'pmc_mfma'):
     f = glob.glob(src + '/%s/*/*_counter_collection.csv' % name)
     if not f:
         continue
@@ -46,7 +52,8 @@ for name in ('pmc_fetch', 'pmc_write', 'pmc_sq'):
             agg[(kn, r['Counter_Name'])].append(float(r['Counter_Value']))
     for (kn, c), v in agg.items():
         out['kernels'].setdefault(kn, {}).setdefault('pmc_median_per_launch', {})[c] = st.median(v)
-steps_per_launch = {'step_kernel': 1, 'rollout_kernel': 50, 'policy_rollout_kernel': 50, 'policy_rollout_ws_kernel': 50}
+steps_per_launch = {'step_kernel': 1, 'rollout_kernel': 50, 'policy_rollout_kernel': 50, 'policy_rollout_ws_kernel': 50, 'policy_rollout_x_kernel': 50,
+                    'gae_kernel': 400, 'gae_finalize_kernel': 1, 'adv_apply_kernel': 400, 'pack_policy_kernel': 1}
 for kn, k in out['kernels'].items():
     p = k.get('pmc_median_per_launch', {})
     if 'FETCH_SIZE' in p and 'WRITE_SIZE' in p:
@@ -55,13 +62,18 @@ for kn, k in out['kernels'].items():
     if 'SQ_WAVES' in p:
         w = p['SQ_WAVES']
         k['per_wave_per_env_step'] = {c: p[c] / w / steps_per_launch[kn] for c in p if c.startswith('SQ_') and c != 'SQ_WAVES'}
-    k['algorithmic_bytes_per_launch'] = 177 * 65536 * steps_per_launch[kn]
+    if 'SQ_VALU_MFMA_BUSY_CYCLES' in p and 'SQ_BUSY_CYCLES' in p and p['SQ_BUSY_CYCLES'] > 0:
+        # SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the SIMDs that issue MFMAs; SQ_BUSY_CYCLES is per SE (32 on this part):
+        # matrix-pipe share of the kernel = MFMA cycles / (4 SIMDs x 256 CUs x kernel cycles)
+        k['mfma_cycles_per_wave_per_env_step'] = p['SQ_VALU_MFMA_BUSY_CYCLES'] / p.get('SQ_WAVES', 1) / steps_per_launch[kn]
+    if kn in ('step_kernel', 'rollout_kernel'):
+        k['algorithmic_bytes_per_launch'] = 177 * 65536 * steps_per_launch[kn]
 try:
     out['bench_line'] = json.loads(open(src + '/bench_plain.json').read())
 except Exception as e:
     out['bench_line'] = str(e)
-json.dump(out, open('profiles/%s_summary.json' % tag, 'w'), indent=1)
+json.dump(out, open('%s/%s_summary.json' % (dst, tag), 'w'), indent=1)
 if 'step_kernel' in out['kernels'] and 'hbm_bytes_per_launch' in out['kernels']['step_kernel']:
     json.dump({'n_envs': 65536, 'hbm_bytes_per_launch': out['kernels']['step_kernel']['hbm_bytes_per_launch'],
-               'source': 'profiles/%s_summary.json' % tag}, open('profiles/traffic_latest.json', 'w'))
-print(json.dumps({k: v for k, v in out.items() if k != 'bench_line'}, indent=1))
+               'source': 'profiles/%s_summary.json' % tag, 'tag': tag}, open('%s/traffic_latest.json' % dst, 'w'))
+print(json.dumps({k: v for k, v in out['kernels'].items() if 'policy' in k or 'gae' in k}, indent=1)[:6000])

@@ -71,18 +71,16 @@ class QPAllocator(object):
         s_t = self.previous_thruster_state
         lx, ly = LX, LY
 
-        def objective(x):                                                                   # :116-150
-            obj = x[5:]
-            obj = np.hstack((obj, np.abs(x[0:3]) ** 1.5))
-            obj = np.hstack((obj, np.abs(x[3] - s_t[3])))
-            obj = np.hstack((obj, np.abs(x[4] - s_t[4])))
-            obj = np.hstack((obj, np.abs(x[0:3] - np.array(s_t[0:3]))))
-            Q = np.zeros((len(obj), len(obj)))
-            np.fill_diagonal(Q, 1.0)
-            Q[6, 6] = Q[7, 7] = 0.25
-            for i in range(8, 11):
-                Q[i, i] = 0.25
-            return 0.5 * (obj.T).dot(Q).dot(obj)
+        # Cost (:116-150, :203): J = 1/2 sum_k w_k z_k^2 over the eleven terms
+        #   z = [ slack (3) | |F|^1.5 (3) | |d alpha| port, star | |d F| (3) ],  w = [1 1 1 | 1 1 1 | 1/4 1/4 | 1/4 1/4 1/4]
+        # i.e. slack^2 + |F|^3 (power) + quarter-weighted squared changes of azimuth and force against the state in force.
+        prev_F, prev_alpha = np.asarray(s_t[0:3], dtype=np.float64), np.asarray(s_t[3:5], dtype=np.float64)
+        weight = np.concatenate([np.ones(6), np.full(5, 0.25)])
+
+        def objective(x):
+            F, alpha, slack = x[0:3], x[3:5], x[5:8]
+            z = np.concatenate([slack, np.abs(F) ** 1.5, np.abs(alpha - prev_alpha), np.abs(F - prev_F)])
+            return 0.5 * np.dot(weight * z, z)
 
         hp = np.pi / 2
         cons = [                                                                            # :156-192
@@ -103,13 +101,12 @@ class QPAllocator(object):
                     (-2 * np.pi, 2 * np.pi), (-sb, sb), (-sb, sb), (-sb, sb))
 
         if x0 is None:
-            x0 = np.array([s_t[0], s_t[1], s_t[2], s_t[3], s_t[4], 0.0, 0.0, 0.0])          # :203
+            x0 = np.concatenate([prev_F, prev_alpha, np.zeros(3)])                          # start at the state in force, no slack (:203)
         sol = minimize(objective, x0, method='SLSQP', bounds=bounds(s_bnd), constraints=cons)   # :206
         tries = 0
         while self.retry and not bool(sol.success) and tries < 100:                         # :209-226
             s_bnd += 1.0
-            s1, s2, s3 = sol.x[-3:]
-            x0 = np.array([s_t[0], s_t[1], s_t[2], s_t[3], s_t[4], s1, s2, s3])
+            x0 = np.concatenate([prev_F, prev_alpha, sol.x[5:8]])                           # keep the slack reached (:212-222)
             sol = minimize(objective, x0, method='SLSQP', bounds=bounds(s_bnd), constraints=cons)
             tries += 1
         x = sol.x

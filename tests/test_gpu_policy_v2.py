@@ -325,3 +325,24 @@ def test_gae_one_pass_statistics_and_normalisation():
                                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)))
             joined = torch.cat(parts, dim=1)
             assert float((joined - one).abs().max()) <= 2e-7 * float(one.abs().max())
+
+
+def test_iae_device_reduction_matches_the_reference_fixture():
+    """the IAE metric as a device reduction, against the fixture produced by the reference's own IAE()
+    (results/all_plots/common.py:60-74 via tools/gen_golden_iae.py) on the recorded Cybersea RL box test."""
+    import os
+    from ml4ca_amd import evaluate as EV
+    torch = torch_()
+    d = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'iae.npz'))
+    dev = 'cuda:0'
+    integ, cum = EV.iae_series(torch.from_numpy(d['eta']).to(dev), torch.from_numpy(d['ref']).to(dev), torch.from_numpy(d['time']).to(dev),
+                               norm=tuple(d['norm']))
+    assert np.abs(integ.cpu().numpy() - d['integrals']).max() < 1e-11 and np.abs(cum.cpu().numpy() - d['cumsum']).max() < 1e-10
+    # fp32 batched form on a [T, n, 9] observation block (what the rollout kernels write): per env equal to the fp64 series form
+    T, n = 251, 33
+    g = torch.Generator(device=dev).manual_seed(2)
+    obs = torch.randn((T, n, 9), generator=g, device=dev)
+    tot, _ = EV.iae(obs, dt=0.2)
+    e = torch.stack([obs[..., 0], obs[..., 1], torch.rad2deg(obs[..., 2])], -1).double()
+    _, c = EV.iae_series(e, torch.zeros_like(e), torch.arange(T, dtype=torch.float64, device=dev) * 0.2)
+    assert float(((tot.double() - c[-1]).abs() / c[-1]).max()) < 1e-5

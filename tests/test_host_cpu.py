@@ -103,9 +103,27 @@ def _gloo_worker(rank, world, port, total, T, q):
     g2, work = D.gather_trajectories(torch.from_numpy(block), async_op=True)     # overlappable form
     work.wait()
     assert torch.equal(g, g2)
+    # the same rollout as the five blocks the kernels write, gathered in place (no packed [T, n, 19] staging copy)
+    blocks = {'obs': torch.from_numpy(block[..., 0:9].copy()), 'act': torch.from_numpy(block[..., 9:16].copy()),
+              'rew': torch.from_numpy(block[..., 16].copy()), 'val': torch.from_numpy(block[..., 17].copy()),
+              'logp': torch.from_numpy(block[..., 18].copy())}
+    gr = D.gather_rollout(blocks)
+    gr2, works = D.gather_rollout(blocks, async_op=True)
+    for w_ in works:
+        w_.wait()
+    for k_, lo, hi in (('obs', 0, 9), ('act', 9, 16)):
+        assert torch.equal(D.to_global_env_order(gr[k_]), torch.from_numpy(full[..., lo:hi])) and torch.equal(gr[k_], gr2[k_])
+    assert torch.equal(D.to_global_env_order(gr['rew']), torch.from_numpy(full[..., 16]))
     # scalar statistics the way mpi_statistics_scalar does them: two all-reduces
     acc = torch.tensor([block[..., 16].sum(dtype=np.float64), block[..., 16].size], dtype=torch.float64)
     dist.all_reduce(acc)
+    # ... and the one-pass form of the advantage normalisation: (sum, sum of squares) in double + the count, ONE all-reduce
+    # (rollout.combine_stats is what RolloutBuffer.get calls between the GAE kernel and the apply kernel)
+    from ml4ca_amd import rollout as RO
+    x = block[..., 16].astype(np.float64)
+    local = torch.tensor([x.sum(), (x * x).sum()], dtype=torch.float64)
+    gstats, gcount = RO.combine_stats(local, x.size)
+    one_pass = [float(gstats[0]), float(gstats[1]), float(gcount), float(local[0]), float(local[1])]
     # data-parallel optimiser plumbing (mpi_tf.py:16-62): parameter broadcast, gradient averaging, mpi_avg
     torch.manual_seed(100 + rank)
     params = [torch.randn(9, 80, requires_grad=True), torch.randn(80, requires_grad=True), torch.randn(7, requires_grad=True)]
@@ -120,7 +138,7 @@ def _gloo_worker(rank, world, port, total, T, q):
     lst = [torch.zeros(3, dtype=torch.float64) for _ in range(world)]
     dist.all_gather(lst, chk)
     if rank == 0:
-        q.put((full, float(acc[0] / acc[1]), [x.tolist() for x in lst]))
+        q.put((full, float(acc[0] / acc[1]), [x.tolist() for x in lst], one_pass))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -135,7 +153,7 @@ def test_two_rank_gloo_gather_matches_single_process_run():
     procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, total, T, q)) for r in range(world)]
     for p in procs:
         p.start()
-    full, mean_rew, dp = q.get(timeout=120)
+    full, mean_rew, dp, one_pass = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -155,6 +173,15 @@ def test_two_rank_gloo_gather_matches_single_process_run():
     assert np.array_equal(full, ref), 'sharded + gathered rollout must equal the single-process rollout bit for bit'
     assert (ref[..., 17] != 0).sum() >= total        # episodes ended and were re-sampled (Philox keyed by global id)
     assert abs(mean_rew - ref[..., 16].mean(dtype=np.float64)) < 1e-9
+    # one-pass normalisation statistics over two ranks = the two per-shard double sums added, bit for bit (a two-term sum does
+    # not depend on the order), and they give the mean / population std of mpi_statistics_scalar (mpi_tools.py:71-92)
+    xa, xb = ref[:, : total // 2, 16].astype(np.float64), ref[:, total // 2:, 16].astype(np.float64)
+    assert one_pass[3] == xa.sum() and one_pass[4] == (xa * xa).sum()
+    assert one_pass[0] == xa.sum() + xb.sum() and one_pass[1] == (xa * xa).sum() + (xb * xb).sum() and one_pass[2] == ref[..., 16].size
+    mean = one_pass[0] / one_pass[2]
+    std = np.sqrt(one_pass[1] / one_pass[2] - mean * mean)
+    xall = ref[..., 16].astype(np.float64)
+    assert abs(mean - xall.mean()) < 1e-14 and abs(std - np.sqrt(((xall - xall.mean()) ** 2).mean())) < 1e-12
     # after sync_params both ranks hold rank 0's parameters; averaged gradients = (1 + 2) / 2; mpi_avg of (0.01, 0.02)
     assert dp[0][0] == dp[1][0] and dp[0][1] == dp[1][1] == 1.5 and abs(dp[0][2] - 0.015) < 1e-9 and abs(dp[1][2] - 0.015) < 1e-9
 

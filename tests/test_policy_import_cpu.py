@@ -147,3 +147,26 @@ def test_ros_order_maps_and_hardware_bow_mapping():
     assert abs(DP.shortest_path(np.radians(170), np.radians(-170)) - np.radians(20)) < 1e-12
     with pytest.raises(ValueError):
         DP.RLAllocatorNode(lambda s: s, variant='simple')
+
+
+def test_iae_matches_the_reference_function_on_the_recorded_box_test():
+    """evaluate.iae_series against tests/golden/iae.npz: the reference's own IAE (results/all_plots/common.py:60-74, imported by
+    tools/gen_golden_iae.py) on the recorded Cybersea RL box test prepared as box_test/plot_pos.py does (per-second averages,
+    normalisation [5, 5, 25]), and on an irregular time base.  float64: identical formulae, 1e-12."""
+    import torch
+    from ml4ca_amd import evaluate as EV
+    d = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'iae.npz'))
+    integ, cum = EV.iae_series(torch.from_numpy(d['eta']), torch.from_numpy(d['ref']), torch.from_numpy(d['time']), norm=tuple(d['norm']))
+    assert np.abs(integ.numpy() - d['integrals']).max() < 1e-12 and np.abs(cum.numpy() - d['cumsum']).max() < 1e-11
+    assert abs(float(cum[-1]) - 58.1992) < 1e-3                       # the thesis' RL box-test figure from the record
+    integ2, cum2 = EV.iae_series(torch.from_numpy(d['a2']), torch.from_numpy(d['b2']), torch.from_numpy(d['t2']), norm=(1.0, 1.0, 1.0))
+    assert np.abs(integ2.numpy() - d['integrals2']).max() < 1e-12 and np.abs(cum2.numpy() - d['cumsum2']).max() < 1e-10
+    # the [T, n] batched form used on rollout blocks = the series form per env
+    T, n = 50, 7
+    rng = np.random.RandomState(1)
+    obs = torch.from_numpy(rng.normal(size=(T, n, 9)).astype(np.float32))
+    tot, cumb = EV.iae(obs, dt=0.2)
+    for i in range(n):
+        e = torch.stack([obs[:, i, 0], obs[:, i, 1], torch.rad2deg(obs[:, i, 2])], -1).double()
+        _, c = EV.iae_series(e, torch.zeros_like(e), torch.arange(T, dtype=torch.float64) * 0.2)
+        assert abs(float(tot[i]) - float(c[-1])) < 1e-4 * float(c[-1])

@@ -32,6 +32,8 @@ def main():
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--minibatch', type=int, default=1 << 18, help='samples per gradient step (full batch in the reference)')
     ap.add_argument('--activation', default='leaky', choices=('leaky', 'relu', 'tanh'), help='hidden activation (train.py:24,31)')
+    ap.add_argument('--precision', default='f32', choices=('f16', 'f32'),
+                    help="in-kernel network arithmetic: 'f32' (split-f16, within 1e-5 of the fp32 update's own evaluation: the PPO ratio starts at 1) or 'f16' (fast)")
     ap.add_argument('--backend', default='nccl', help="'nccl' (RCCL, one GPU per rank) or 'gloo' (rehearsal)")
     ap.add_argument('--same-device', action='store_true', help='all ranks on cuda:0 (multi-rank rehearsal on a one-GPU box)')
     args = ap.parse_args()
@@ -58,15 +60,16 @@ def main():
     v_opt = torch.optim.Adam(v_params, lr=1e-3)
     clip, target_kl, T, n = 0.2, 0.01, args.steps, args.envs
     buf = rollout.RolloutBuffer(T, env, gamma=0.99, lam=0.97)
-    ac.upload(env)
+    ac.upload(env, precision=args.precision)          # device pointers: one packing kernel, no host copy
     env.reset()
     if rank == 0:
         print('epoch  mean_reward/step(max 3.5)  terminated/1k-steps  pi_iters  KL      V-loss    rollout_ms  update_s')
     for epoch in range(args.epochs):
-        noise = torch.randn((T, n, 7), device=dev)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        blk = buf.collect(env, noise=noise)
+        # exploration noise is drawn inside the kernel (core.py:85), keyed by seed / global env id / draw index: no [T, n, 7]
+        # noise block, and the trajectories do not depend on how many ranks share the envs
+        blk = buf.collect(env, sample=True)
         buf.finish()
         obs, act, adv, ret, logp_old = buf.get()
         torch.cuda.synchronize()
@@ -102,7 +105,7 @@ def main():
             v_opt.step()
         with torch.no_grad():
             ac.log_std.clamp_(-4.0, 1.0)
-        ac.upload(env)
+        ac.upload(env, precision=args.precision)
         torch.cuda.synchronize()
         t_upd = time.perf_counter() - t1
         done = blk['done']

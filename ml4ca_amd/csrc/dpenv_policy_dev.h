@@ -447,23 +447,62 @@ __device__ __forceinline__ void wave_rows_from_regs(float* lds_w, const float pr
 //  at 3x the matrix work and ~3x the packing work of the f16 mode.  Same fragment layout as the f16 mode: the LDS image
 //  carries a second set of fragments for Wl.
 // =============================================================================================
+// h -> (hi, lo) for two values: hi = f16(h) (v_cvt_pk_f16_f32, round to nearest even), lo = f16(h - f32(hi)); the difference is exact
+__device__ __forceinline__ void split_pair(float h0, float h1, uint32_t& hi, uint32_t& lo)
+{
+    const float2v hv = {h0, h1};
+    const half2v hh = __builtin_convertvector(hv, half2v);
+    hi = __builtin_bit_cast(uint32_t, hh);
+    const float2v lv = {h0 - (float)hh[0], h1 - (float)hh[1]};
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(lv, half2v));
+}
+
+// Leaky-relu + split of FOUR accumulator values: 4 x (mul, max), 2 x cvt_pk (hi), 4 x v_fma_mix_f32 (h - f32(hi half), the half
+// widened inside the FMA), 2 x cvt_pk (lo) = 4 instructions per activation.  The part after the multiply is one asm statement
+// because the compiler (a) puts a canonicalising v_max_f32(x, x) in front of every fmaxf under IEEE mode, (b) expands the difference
+// into convert + subtract, and (c) pads each separate asm statement with an s_nop - together 7 per activation.
+// HAZARD NOTE: x are MFMA results, and the hazard recogniser does not count an asm statement as a VALU reader of them (it would
+// read the accumulator before the last MFMA of the chain has landed: seen as a 2e-5 error, the Wl xh term missing).  The
+// multiply s x is therefore left to the compiler - it is a VALU read of every x in front of the asm, so the wait states are in place.
+// No packed-fp32 instruction in here; a NaN propagates through max / fma_mix into the outputs as before.
+__device__ __forceinline__ void leaky_split4(const float x[4], float leak, uint32_t H[2], uint32_t L[2])
+{
+    float t0, t1, t2, t3;
+    const float m0 = x[0] * leak, m1 = x[1] * leak, m2 = x[2] * leak, m3 = x[3] * leak;
+    asm("v_max_f32 %4, %8, %12\n\tv_max_f32 %5, %9, %13\n\tv_max_f32 %6, %10, %14\n\tv_max_f32 %7, %11, %15\n\t"
+        "v_cvt_pk_f16_f32 %0, %4, %5\n\tv_cvt_pk_f16_f32 %1, %6, %7\n\t"
+        "v_fma_mix_f32 %4, %0, %16, %4 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %5, %0, %16, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %6, %1, %16, %6 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %7, %1, %16, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_cvt_pk_f16_f32 %2, %4, %5\n\tv_cvt_pk_f16_f32 %3, %6, %7"
+        : "=&v"(H[0]), "=&v"(H[1]), "=&v"(L[0]), "=&v"(L[1]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(m0), "v"(m1), "v"(m2), "v"(m3), "v"(-1.0f));
+}
+
 template <int ACT>
 __device__ __forceinline__ void act_split(const float16v& acc, int s, float leak, half8& hi, half8& lo)
 {
+    uint32_t H[4], L[4];
+    if (ACT == ACT_TANH) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float x = acc[8 * s + j];
-        float h;
-        if (ACT == ACT_TANH) {
-            const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);      // exp(2x)
-            h = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
-        } else {
-            h = fmaxf(x, leak * x);                                               // leaky-relu, 0 <= leak <= 1
+        for (int j = 0; j < 8; j += 2) {
+            float h[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float e = __builtin_amdgcn_exp2f(acc[8 * s + j + q] * 2.8853900817779268f);      // exp(2x)
+                h[q] = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+            }
+            split_pair(h[0], h[1], H[j >> 1], L[j >> 1]);
         }
-        const _Float16 hh = (_Float16)h;
-        hi[j] = hh;
-        lo[j] = (_Float16)(h - (float)hh);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float x[4] = {acc[8 * s + 4 * q], acc[8 * s + 4 * q + 1], acc[8 * s + 4 * q + 2], acc[8 * s + 4 * q + 3]};
+            leaky_split4(x, leak, H + 2 * q, L + 2 * q);
+        }
     }
+    const uint4 hq = {H[0], H[1], H[2], H[3]}, lq = {L[0], L[1], L[2], L[3]};
+    hi = __builtin_bit_cast(half8, hq);
+    lo = __builtin_bit_cast(half8, lq);
 }
 
 __device__ __forceinline__ float16v mfma3(const half8& wh, const half8& wl, const half8& bh, const half8& bl, float16v c)
@@ -481,15 +520,15 @@ struct SplitIn {
 template <int OD>
 __device__ __forceinline__ void obs_to_frags_x(const float o[9], SplitIn& in)
 {
-    half8 Ph, Qh, Pl, Ql;
+    uint32_t H[8], L[8];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const float x = (k < OD) ? o[k < 9 ? k : 8] : 0.0f;
-        const _Float16 h = (_Float16)x;
-        const _Float16 l = (_Float16)(x - (float)h);
-        if (k < 8) { Ph[k] = h; Pl[k] = l; } else { Qh[k - 8] = h; Ql[k - 8] = l; }
+    for (int k = 0; k < 16; k += 2) {
+        const float x0 = (k < OD) ? o[k < 9 ? k : 8] : 0.0f;
+        const float x1 = (k + 1 < OD) ? o[k + 1 < 9 ? k + 1 : 8] : (k + 1 == 15 ? 1.0f : 0.0f);     // slot 15: the bias input (its low part is 0)
+        split_pair(x0, x1, H[k >> 1], L[k >> 1]);
     }
-    Qh[7] = (_Float16)1.0f;        // slot 15: the bias input; its low part stays 0
+    const uint4 ph = {H[0], H[1], H[2], H[3]}, qh = {H[4], H[5], H[6], H[7]}, pl = {L[0], L[1], L[2], L[3]}, ql = {L[4], L[5], L[6], L[7]};
+    const half8 Ph = __builtin_bit_cast(half8, ph), Qh = __builtin_bit_cast(half8, qh), Pl = __builtin_bit_cast(half8, pl), Ql = __builtin_bit_cast(half8, ql);
     auto swap4 = [](const half8& P, const half8& Q, half8& a, half8& b) {
         const uint4 p = __builtin_bit_cast(uint4, P), q = __builtin_bit_cast(uint4, Q);
         uint4 x, y;
@@ -524,22 +563,33 @@ __device__ __forceinline__ void mlp_eval_x(const uint4* Wh, const uint4* Wl, con
     }
     int fbase = 3, bblk = 0;
     for (int l = 1; l < n_hidden; ++l) {
-#pragma unroll
-        for (int mo = 0; mo < 3; ++mo) {
-            float16v c0 = ldbias(B, bblk + mo, lane), c1 = c0;
+        // the three row-blocks of a layer are independent: block mo + 1's MFMAs are issued before block mo is activated and split,
+        // so that the matrix pipe is still draining them while the VALU works (interleaving the two in program order at k-step
+        // granularity was measured slower: 16.7 against 16.15 us per step - more live accumulators, more AGPR traffic)
+        auto block = [&](int mo, float16v& c0, float16v& c1) {
+            c0 = ldbias(B, bblk + mo, lane); c1 = c0;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const half8 wh = ldfrag(Wh, fbase + mo * KS + ks, lane), wl = ldfrag(Wl, fbase + mo * KS + ks, lane);
                 c0 = mfma3(wh, wl, bh[ks][0], bl[ks][0], c0);
                 c1 = mfma3(wh, wl, bh[ks][1], bl[ks][1], c1);
             }
+        };
+        auto pack = [&](int mo, const float16v& c0, const float16v& c1) {
             act_split<ACT>(c0, 0, leak, nh[2 * mo][0], nl[2 * mo][0]);
             act_split<ACT>(c1, 0, leak, nh[2 * mo][1], nl[2 * mo][1]);
             if (2 * mo + 1 < KS) {
                 act_split<ACT>(c0, 1, leak, nh[2 * mo + 1][0], nl[2 * mo + 1][0]);
                 act_split<ACT>(c1, 1, leak, nh[2 * mo + 1][1], nl[2 * mo + 1][1]);
             }
-        }
+        };
+        float16v p0, p1, q0, q1;
+        block(0, p0, p1);
+        block(1, q0, q1);
+        pack(0, p0, p1);
+        block(2, p0, p1);
+        pack(1, q0, q1);
+        pack(2, p0, p1);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) { bh[ks][0] = nh[ks][0]; bh[ks][1] = nh[ks][1]; bl[ks][0] = nl[ks][0]; bl[ks][1] = nl[ks][1]; }
         fbase += 3 * KS;

@@ -34,14 +34,19 @@ def test_struct_layout_matches_header(tmp_path):
     from ml4ca_amd import _lib
     src = tmp_path / 'sz.c'
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "dpenv.h"\n'
-                   'int main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(dpenv_config), sizeof(dpenv_step_io),'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(dpenv_config), sizeof(dpenv_step_io),'
                    ' offsetof(dpenv_config, seed), offsetof(dpenv_config, reset_fraction),'
-                   ' offsetof(dpenv_config, hold_plant), offsetof(dpenv_step_io, final_obs));return 0;}\n')
+                   ' offsetof(dpenv_config, hold_plant), offsetof(dpenv_step_io, final_obs),'
+                   ' offsetof(dpenv_config, reset_acts), sizeof(dpenv_policy_desc), offsetof(dpenv_policy_desc, precision),'
+                   ' offsetof(dpenv_policy_desc, device_pointers), sizeof(dpenv_policy_rollout_io), offsetof(dpenv_policy_rollout_io, sample),'
+                   ' sizeof(dpenv_mlp));return 0;}\n')
     exe = tmp_path / 'sz'
     subprocess.check_call(['gcc', '-std=c99', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [C.sizeof(_lib.Config), C.sizeof(_lib.StepIO), _lib.Config.seed.offset, _lib.Config.reset_fraction.offset,
-            _lib.Config.hold_plant.offset, _lib.StepIO.final_obs.offset]
+            _lib.Config.hold_plant.offset, _lib.StepIO.final_obs.offset, _lib.Config.reset_acts.offset, C.sizeof(_lib.PolicyDesc),
+            _lib.PolicyDesc.precision.offset, _lib.PolicyDesc.device_pointers.offset, C.sizeof(_lib.PolicyRolloutIO),
+            _lib.PolicyRolloutIO.sample.offset, C.sizeof(_lib.Mlp)]
     assert got == want
 
 

@@ -247,13 +247,14 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
 // =============================================================================================
 constexpr int WSBLOCK = 512;
 constexpr int WS_GROUP_FLOATS = 64 * 9 * 5 + 64 * 4 + 64;       // io | obs | pre[2] | mu | v[2] | vpre[2] | sequence words (+ pad)
-constexpr int WS3_GROUP_FLOATS = WS_GROUP_FLOATS + 64 * 9;      // three roles: a second observation mailbox (by step parity)
 
-//  ROLES = 3 (768-thread workgroups, three waves per SIMD: env / actor / critic; built only with -DDPENV_WS3, where it replaces
-//  the two-role form) was measured in round 2 and is NOT used: with two roles the network wave is the bottleneck (busy 98 % of
-//  the launch: actor + critic back to back), and a critic wave of its own takes the critic off the env -> actor chain; but three
-//  waves per SIMD leave 168 VGPRs per wave, the kernel then spills 140 B per lane, and three instruction streams (two of them
-//  MFMA + VALU mixes) share one SIMD's issue: 8.0-8.2 us per step against 7.6-7.8 for two roles (profiles/r02_closed_loop_forms.txt).
+//  ROLES = 3 (768-thread workgroups, three waves per SIMD) splits the NETWORK wave by env tile: wave 4 + g evaluates actor and
+//  critic for envs 0..31 of group g, wave 8 + g for envs 32..63 (mlp_eval_tile: half the MFMAs, half the packing, half the
+//  registers per wave, no cross-lane moves: a tile's fragments are read from the mailbox in operand layout and its outputs go back
+//  in accumulator layout).  The serial chain env.step(t) -> actor(o_t+1) -> env.step(t+1) then holds HALF an actor evaluation,
+//  and the two network streams of a SIMD fill each other's MFMA / dependency stalls.  (An env / actor / critic split of the
+//  three waves was measured first and is slower than two roles: each network wave still runs a full two-tile evaluation on the
+//  chain, at 168 VGPRs it spills; profiles/r02_closed_loop_forms.txt.)
 // pair-level hand-over inside a workgroup: a sequence word in LDS, released by one wave and acquired by its partner.
 // Both waves of a pair belong to the same workgroup, so they are always co-resident; the waiter sleeps between polls.
 __device__ __forceinline__ void ws_post(int* p, int v, int lane)
@@ -298,18 +299,19 @@ __global__ __launch_bounds__(256 * ROLES) void policy_rollout_ws_kernel(const St
 #ifdef DPENV_WS_SWAP_ROLES
     const int role = (ROLES - 1) - (wave >> 2);     // diagnostic: the network waves are the first-dispatched (older) ones
 #else
-    const int role = wave >> 2;                     // 0 = env wave, 1 = network wave (ROLES 2) / actor wave (ROLES 3), 2 = critic wave
+    const int role = wave >> 2;                     // 0 = env wave, 1 = network wave (ROLES 2) / network wave of tile 0 (ROLES 3), 2 = of tile 1
 #endif
     const int g = wave & 3;
-    constexpr int OBS_SLOTS = ROLES == 3 ? 2 : 1;   // a trailing critic wave still needs o_t while o_t+1 is being posted
-    float* grp = (float*)lds_dyn + policy_lds_io_offset_floats(pa) + g * (ROLES == 3 ? WS3_GROUP_FLOATS : WS_GROUP_FLOATS);
+    constexpr int OBS_SLOTS = 1;
+    float* grp = (float*)lds_dyn + policy_lds_io_offset_floats(pa) + g * WS_GROUP_FLOATS;
     float* lds_io = grp;                         // E-wave row staging
     float* obs_mb = grp + 64 * 9;                // [OBS_SLOTS][64][9] o_t (by step parity): one row of 9 per lane (stride 9 is conflict-free)
     float* pre_mb = grp + 64 * 9 * (1 + OBS_SLOTS);   // [2][64][9] pre-reset observation of a cut episode, by step parity
     float* mu_mb = pre_mb + 64 * 9 * 2;          // actor mean, stride 9
     float* v_mb = mu_mb + 64 * 9;                // [2][64] V(o_t), by step parity
     float* vpre_mb = v_mb + 128;                 // [2][64] V(pre-reset o_t), by step parity
-    int* seq = (int*)(vpre_mb + 128);            // [0] observations posted, [1] means posted, [2] values posted, [4..5] pre flags
+    int* seq = (int*)(vpre_mb + 128);            // [0] observations posted, [1] means posted, [2] values posted, [4..5] pre flags,
+                                                 // [6] / [7] means / values posted by the network wave of tile 1 (ROLES 3)
     int* flag = seq + 4;
     const uint4* Wpi = lds_w;
     const uint4* Wv = lds_w + pa.nfrag * 64;
@@ -329,10 +331,39 @@ __global__ __launch_bounds__(256 * ROLES) void policy_rollout_ws_kernel(const St
         // ------------------------------------------------------------------------------------ network wave(s)
         // the actor is on the serial chain of the step: let the SIMD's instruction arbiter prefer it; a critic-only wave
         // trails and takes what is left
-#ifndef DPENV_WS_NO_SETPRIO
-        if (ROLES == 2 || role == 1) __builtin_amdgcn_s_setprio(3);
+#ifndef DPENV_WS_M_PRIO
+#define DPENV_WS_M_PRIO 3
 #endif
-        const bool do_actor = (ROLES == 2) || role == 1, do_critic = (ROLES == 2) || role == 2;
+#ifndef DPENV_WS_NO_SETPRIO
+        __builtin_amdgcn_s_setprio(DPENV_WS_M_PRIO);
+#endif
+        if constexpr (ROLES == 3) {
+            const int tile = role - 1, env = tile * 32 + (lane & 31), hh = lane >> 5;
+            int* s_mu = &seq[tile ? 6 : 1];
+            int* s_v = &seq[tile ? 7 : 2];
+            float ov[4];
+            for (int t = 0; t <= pa.T; ++t) {
+                ws_wait(&seq[0], t + 1);                                     // o_t posted (and step t-1's pre flag)
+                const half8 in = tile_frag_from_mailbox<OD>(obs_mb, tile, lane);
+                if (t < pa.T) {
+                    mlp_eval_tile<KA>(Wpi, Bpi, pa.n_hidden, in, leak, ov);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (4 * hh + j < A) mu_mb[env * 9 + 4 * hh + j] = ov[j];
+                    ws_post(s_mu, t + 1, lane);                              // mu_t of this tile posted
+                }
+                mlp_eval_tile<KA>(Wv, Bv, pa.n_hidden, in, leak, ov);
+                if (hh == 0) v_mb[(t & 1) * 64 + env] = ov[0];
+                if (t > 0 && flag[(t - 1) & 1] != 0) {                       // step t-1 cut an episode that was re-drawn
+                    const half8 pin = tile_frag_from_mailbox<OD>(pre_mb + ((t - 1) & 1) * (64 * 9), tile, lane);
+                    mlp_eval_tile<KA>(Wv, Bv, pa.n_hidden, pin, leak, ov);
+                    if (hh == 0) vpre_mb[(t & 1) * 64 + env] = ov[0];
+                }
+                ws_post(s_v, t + 1, lane);                                   // V(o_t) (and V of the pre-reset o_t) of this tile posted
+            }
+            return;
+        }
+        const bool do_actor = true, do_critic = true;
         half8 in0, in1;
         float o[9], outv[8];
         uint64_t w_obs = 0; const uint64_t t_start = __builtin_amdgcn_s_memtime(); (void)t_start; (void)w_obs;
@@ -352,11 +383,6 @@ __global__ __launch_bounds__(256 * ROLES) void policy_rollout_ws_kernel(const St
                 ws_post(&seq[1], t + 1, lane);                               // mu_t posted
             }
             if (do_critic) {
-#ifdef DPENV_WS3_TRAIL
-                // the critic of o_t starts once mu_t is out: it then runs beside the env wave's step t like in the two-role
-                // form, not beside the actor that step t is waiting for
-                if (ROLES == 3 && t < pa.T) ws_wait(&seq[1], t + 1);
-#endif
                 WS_EVAL(Wv, Bv, in0, in1);
                 v_mb[(t & 1) * 64 + lane] = outv[0];
                 if (t > 0 && flag[(t - 1) & 1] != 0) {                       // step t-1 cut an episode that was re-drawn
@@ -375,6 +401,9 @@ __global__ __launch_bounds__(256 * ROLES) void policy_rollout_ws_kernel(const St
     }
 
     // ---------------------------------------------------------------------------------------- E-wave
+#ifdef DPENV_WS_E_PRIO
+    __builtin_amdgcn_s_setprio(DPENV_WS_E_PRIO);
+#endif
     Env s;
     Current cur = {0.0f, 0.0f, 0.0f, 0.0f, 0u};
     float vc0 = 0.0f, beta0 = 0.0f;
@@ -422,6 +451,7 @@ __global__ __launch_bounds__(256 * ROLES) void policy_rollout_ws_kernel(const St
             ++nctr;
         }
         WS_WAIT_T(w_mu, &seq[1], t + 1);                                     // mu_t posted
+        if (ROLES == 3) ws_wait(&seq[6], t + 1);
         float act[A], mu[A];
         float logp;
 #pragma unroll
@@ -457,6 +487,7 @@ __global__ __launch_bounds__(256 * ROLES) void policy_rollout_ws_kernel(const St
 #ifdef DPENV_WS_SELFCHECK
         {
             ws_wait(&seq[2], t + 1);                                         // critic(o_t) done: the partner is idle from here
+            if (ROLES == 3) ws_wait(&seq[7], t + 1);
             StepOut outB;
             env_step<MODE, EXT>(a, ve, sB, actB, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, outB);
             const float fa[20] = {s.N, s.E, s.psi, s.u, s.v, s.r, s.sn, s.cs, out.reward, out.o[0], out.o[1], out.o[2], out.o[3],
@@ -518,6 +549,7 @@ __global__ __launch_bounds__(256 * ROLES) void policy_rollout_ws_kernel(const St
             (pa.logp + (int64_t)t * n)[(unsigned)i] = logp;
         }
         WS_WAIT_T(w_v, &seq[2], t + 1);                                      // V(o_t), V(pre-reset o_t) posted
+        if (ROLES == 3) ws_wait(&seq[7], t + 1);
         if (live) {
             const float v_t = v_mb[(t & 1) * 64 + lane];
             (pa.val + (int64_t)t * n)[(unsigned)i] = v_t;
@@ -525,6 +557,7 @@ __global__ __launch_bounds__(256 * ROLES) void policy_rollout_ws_kernel(const St
         }
     }
     ws_wait(&seq[2], pa.T + 1);                                              // V(o_T) posted
+    if (ROLES == 3) ws_wait(&seq[7], pa.T + 1);
 #ifdef DPENV_WS_PROFILE
     if (live && pa.T >= 5) { (pa.logp + (int64_t)0 * n)[(unsigned)i] = (float)w_mu; (pa.logp + (int64_t)1 * n)[(unsigned)i] = (float)w_v; (pa.logp + (int64_t)2 * n)[(unsigned)i] = (float)(__builtin_amdgcn_s_memtime() - t_start); }
 #endif
@@ -674,7 +707,7 @@ static hipError_t launch_policy_rollout_one(const StepArgs& a, const PolicyArgs&
         const dim3 grid((a.n + 255) / 256);
 #ifdef DPENV_WS3
         constexpr int ROLES = 3;
-        const size_t lds = (size_t)2 * pa.nfrag * 64 * 16 + (size_t)2 * pa.nblk * 32 * 4 + (size_t)4 * WS3_GROUP_FLOATS * 4;
+        const size_t lds = (size_t)2 * pa.nfrag * 64 * 16 + (size_t)2 * pa.nblk * 32 * 4 + (size_t)4 * WS_GROUP_FLOATS * 4;
 #else
         constexpr int ROLES = 2;
         const size_t lds = (size_t)2 * pa.nfrag * 64 * 16 + (size_t)2 * pa.nblk * 32 * 4 + (size_t)4 * WS_GROUP_FLOATS * 4;

@@ -177,6 +177,105 @@ __device__ __forceinline__ void mlp_eval(const uint4* W, const float* B, int n_h
     }
 }
 
+// One MLP for ONE 32-env tile (the tile-split closed loop, dpenv_policy.hip): `in` is that tile's first-layer B fragment
+// (lanes 0..31 carry slots 0..7 of env lane, lanes 32..63 slots 8..15 of env lane - 32).  out[j], j < 4: output row
+// 4 (lane >> 5) + j of env (lane & 31).  The MFMA chain and the packing of a tile are exactly those of mlp_eval (its c0 / c1
+// never mix), so the results are bit-identical to the two-tile evaluation; half the registers, no cross-lane moves.
+template <int KS>
+__device__ __forceinline__ void interleave_stage_tile()
+{
+    __builtin_amdgcn_sched_group_barrier(0x100, KS + 4, 0);
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int KA>
+__device__ __forceinline__ void mlp_eval_tile(const uint4* W, const float* B, int n_hidden, half8 in, _Float16 leak, float out[4])
+{
+    constexpr int KS = KA & 15, ACT = KA >> 4;
+    const int lane = threadIdx.x & 63;
+    const float16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    half8 b[KS], bn[KS], w[KS];
+#pragma unroll
+    for (int mo = 0; mo < 3; ++mo) w[mo] = ldfrag(W, mo, lane);
+#pragma unroll
+    for (int mo = 0; mo < 3; ++mo) {
+        const float16v c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[mo], in, zero, 0, 0, 0);
+        b[2 * mo] = act_pack<ACT>(c, 0, leak);
+        if (2 * mo + 1 < KS) b[2 * mo + 1] = act_pack<ACT>(c, 1, leak);
+    }
+    int fbase = 3, bblk = 0;
+    half8 wn[KS];
+    for (int l = 1; l < n_hidden; ++l) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) w[ks] = ldfrag(W, fbase + ks, lane);
+        float16v cb = ldbias(B, bblk, lane);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(W, fbase + KS + ks, lane);
+        float16v cbn = ldbias(B, bblk + 1, lane);
+        float16v p = cb;                                                    // block 0
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) p = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks], p, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mo = 1; mo < 3; ++mo) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) w[ks] = wn[ks];
+            cb = cbn;
+            if (mo < 2) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(W, fbase + 2 * KS + ks, lane);
+                cbn = ldbias(B, bblk + 2, lane);
+            }
+            float16v c = cb;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks], c, 0, 0, 0);
+            bn[2 * (mo - 1)] = act_pack<ACT>(p, 0, leak);
+            bn[2 * (mo - 1) + 1] = act_pack<ACT>(p, 1, leak);
+            interleave_stage_tile<KS>();
+            p = c;
+        }
+        bn[4] = act_pack<ACT>(p, 0, leak);
+        if (5 < KS) bn[KS - 1] = act_pack<ACT>(p, 1, leak);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) b[ks] = bn[ks];
+        fbase += 3 * KS;
+        bblk += 3;
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) w[ks] = ldfrag(W, fbase + ks, lane);
+    float16v c = ldbias(B, bblk, lane);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks], c, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[j] = c[j];
+}
+
+// first-layer B fragment of one 32-env tile straight from an observation mailbox (row stride 9 floats): lane l carries
+// slots 8 (l >> 5) .. + 7 of env (l & 31) of the tile; slot 15 is the bias input.  Same f32 -> f16 rounding of the same
+// f32 values as obs_to_frags.
+template <int OD>
+__device__ __forceinline__ half8 tile_frag_from_mailbox(const float* mb, int tile, int lane)
+{
+    const float* row = mb + (tile * 32 + (lane & 31)) * 9;
+    const bool hi = lane >= 32;
+    half8 r;
+    if (!hi) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = (_Float16)(k < OD ? row[k] : 0.0f);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = (_Float16)0.0f;
+        if (OD > 8) r[0] = (_Float16)row[8];
+        r[7] = (_Float16)1.0f;
+    }
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Actor AND critic of the same observation as one interleaved routine.
 //

@@ -54,8 +54,12 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        _lib = C.CDLL(_SO)
+        alt = os.environ.get('DPENV_ORACLE_SO')          # an instrumented build (tools/oracle_sanitize.sh)
+        if alt:
+            _lib = C.CDLL(alt)
+        else:
+            build()
+            _lib = C.CDLL(_SO)
     return _lib
 
 

@@ -20,8 +20,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // one v_mad_u64_u32 per 32 x 32 -> 64 product (the 32-bit integer multiplier is a quarter-rate unit shared by the
+        // SIMD's waves: separate v_mul_hi_u32 + v_mul_lo_u32 cost 14.6 ns of it per round, the 64-bit form 11.5 ns)
+        const uint64_t p0 = (uint64_t)c0 * 0xD2511F53ull, p1 = (uint64_t)c2 * 0xCD9E8D57ull;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -284,6 +286,18 @@ __device__ __forceinline__ void box_muller(uint32_t wa, uint32_t wb, float& z0, 
     z0 = rad * c2; z1 = rad * s2;
 }
 
+// The same transform on the hardware transcendentals (v_log_f32, v_sin_f32 / v_cos_f32 take their argument in revolutions, i.e.
+// u2 itself): 8 instructions per pair instead of ~75.  Used for the policy's exploration noise, the one stream that is drawn
+// every env step inside the closed loop (4 pairs per step were ~0.5 us of a SIMD's 7 us); within ~2e-6 of box_muller, which the
+// reset and drift draws keep.  The reference's own noise is an unseeded TF stream (core.py:85): only the distribution can match.
+__device__ __forceinline__ void box_muller_hw(uint32_t wa, uint32_t wb, float& z0, float& z1)
+{
+    const float u1 = ((float)(wa >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0, 1)
+    const float u2 = (float)(wb >> 8) * (1.0f / 16777216.0f);            // [0, 1)
+    const float rad = sqrt_hw(-1.3862943611198906f * __builtin_amdgcn_logf(u1));     // -2 ln 2 log2(u1)
+    z0 = rad * __builtin_amdgcn_cosf(u2); z1 = rad * __builtin_amdgcn_sinf(u2);
+}
+
 __device__ __forceinline__ void current_drift_step(const StepArgs& a, Current& c, float vc0, float beta0, int64_t gid)
 {
     uint32_t w[4];
@@ -307,12 +321,12 @@ __device__ __forceinline__ void policy_noise(const StepArgs& a, int64_t gid, uin
     float z[8];
     uint32_t w[4];
     philox4x32_10(g0, g1, ctr, 0xA0000000u, a.seed_lo, a.seed_hi, w);
-    box_muller(w[0], w[1], z[0], z[1]);
-    box_muller(w[2], w[3], z[2], z[3]);
+    box_muller_hw(w[0], w[1], z[0], z[1]);
+    box_muller_hw(w[2], w[3], z[2], z[3]);
     if (A > 4) {
         philox4x32_10(g0, g1, ctr, 0xA0000001u, a.seed_lo, a.seed_hi, w);
-        box_muller(w[0], w[1], z[4], z[5]);
-        box_muller(w[2], w[3], z[6], z[7]);
+        box_muller_hw(w[0], w[1], z[4], z[5]);
+        box_muller_hw(w[2], w[3], z[6], z[7]);
     }
 #pragma unroll
     for (int k = 0; k < A; ++k) xi[k] = z[k];

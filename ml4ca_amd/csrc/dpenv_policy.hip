@@ -247,6 +247,7 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
 // =============================================================================================
 constexpr int WSBLOCK = 512;
 constexpr int WS_GROUP_FLOATS = 64 * 9 * 5 + 64 * 4 + 64;       // io | obs | pre[2] | mu | v[2] | vpre[2] | sequence words (+ pad)
+static_assert(4 * WS_GROUP_FLOATS * 4 == POLICY_WS_MAILBOX_BYTES, "dpenv_dev.h: POLICY_WS_MAILBOX_BYTES out of step with the mailbox layout");
 
 //  ROLES = 3 (768-thread workgroups, three waves per SIMD) splits the NETWORK wave by env tile: wave 4 + g evaluates actor and
 //  critic for envs 0..31 of group g, wave 8 + g for envs 32..63 (mlp_eval_tile: half the MFMAs, half the packing, half the
@@ -268,8 +269,12 @@ __device__ __forceinline__ void ws_wait(int* p, int v)
 }
 #ifdef DPENV_WS_PROFILE
 #define WS_WAIT_T(acc, p, v) do { const uint64_t t0_ = __builtin_amdgcn_s_memtime(); ws_wait(p, v); acc += __builtin_amdgcn_s_memtime() - t0_; } while (0)
+#define WS_TIC(t_) const uint64_t t_ = __builtin_amdgcn_s_memtime()
+#define WS_TOC(acc, t_) acc += __builtin_amdgcn_s_memtime() - t_
 #else
 #define WS_WAIT_T(acc, p, v) ws_wait(p, v)
+#define WS_TIC(t_)
+#define WS_TOC(acc, t_)
 #endif
 
 #ifdef DPENV_WS_DEBUG_NOMFMA
@@ -313,6 +318,12 @@ __global__ __launch_bounds__(256 * ROLES) void policy_rollout_ws_kernel(const St
     int* seq = (int*)(vpre_mb + 128);            // [0] observations posted, [1] means posted, [2] values posted, [4..5] pre flags,
                                                  // [6] / [7] means / values posted by the network wave of tile 1 (ROLES 3)
     int* flag = seq + 4;
+    // Two roles: the NETWORK wave draws the exploration noise (Philox + Box-Muller, ~300 VALU per step) while it waits for the
+    // next observation - with the noise in the env wave that wave was the busy one (tools/ws_profile.py).  xi_t travels in the
+    // observation mailbox: once the network wave has turned o_t into fragments the rows are free until the env wave writes
+    // o_t+1, which it does after it has waited for mu_t and read xi_t.
+    constexpr bool M_NOISE = (ROLES == 2);
+    float* xi_mb = obs_mb;
     const uint4* Wpi = lds_w;
     const uint4* Wv = lds_w + pa.nfrag * 64;
     const float* Bpi = (const float*)(lds_dyn + 2 * pa.nfrag * 64);
@@ -366,7 +377,11 @@ __global__ __launch_bounds__(256 * ROLES) void policy_rollout_ws_kernel(const St
         const bool do_actor = true, do_critic = true;
         half8 in0, in1;
         float o[9], outv[8];
-        uint64_t w_obs = 0; const uint64_t t_start = __builtin_amdgcn_s_memtime(); (void)t_start; (void)w_obs;
+        const bool draw_m = M_NOISE && pa.noise == nullptr && pa.sample != 0;
+        uint32_t nctr_m = draw_m ? a.noise_ctr[il] : 0u;
+        float xin[A];                                                        // xi of the step whose observation is awaited
+        if (draw_m) { policy_noise<A>(a, a.env_id_base + i, nctr_m, xin); ++nctr_m; }
+        uint64_t w_obs = 0, t_act = 0, t_cri = 0; const uint64_t t_start = __builtin_amdgcn_s_memtime(); (void)t_start; (void)w_obs; (void)t_act; (void)t_cri;
         auto frags_from = [&](const float* mb, half8& f0, half8& f1) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) o[k] = k < OD ? mb[lane * 9 + k] : 0.0f;
@@ -376,13 +391,26 @@ __global__ __launch_bounds__(256 * ROLES) void policy_rollout_ws_kernel(const St
             if (!do_critic && t == pa.T) break;                              // the actor is not asked for mu_T
             WS_WAIT_T(w_obs, &seq[0], t + 1);                                // o_t posted (and step t-1's pre flag)
             frags_from(obs_mb + (t & (OBS_SLOTS - 1)) * (64 * 9), in0, in1);
+            if (draw_m && t < pa.T) {                                        // o_t is in registers: its rows now carry xi_t
+#pragma unroll
+                for (int k = 0; k < A; ++k) xi_mb[lane * 9 + k] = xin[k];
+            }
             if (do_actor && t < pa.T) {
+                WS_TIC(ta_);
+#ifdef DPENV_WS_M_PRIO_CRITIC
+                __builtin_amdgcn_s_setprio(DPENV_WS_M_PRIO);
+#endif
                 WS_EVAL(Wpi, Bpi, in0, in1);
 #pragma unroll
                 for (int k = 0; k < A; ++k) mu_mb[lane * 9 + k] = outv[k];
                 ws_post(&seq[1], t + 1, lane);                               // mu_t posted
+#ifdef DPENV_WS_M_PRIO_CRITIC
+                __builtin_amdgcn_s_setprio(DPENV_WS_M_PRIO_CRITIC);
+#endif
+                WS_TOC(t_act, ta_);
             }
             if (do_critic) {
+                WS_TIC(tc_);
                 WS_EVAL(Wv, Bv, in0, in1);
                 v_mb[(t & 1) * 64 + lane] = outv[0];
                 if (t > 0 && flag[(t - 1) & 1] != 0) {                       // step t-1 cut an episode that was re-drawn
@@ -392,10 +420,15 @@ __global__ __launch_bounds__(256 * ROLES) void policy_rollout_ws_kernel(const St
                     vpre_mb[(t & 1) * 64 + lane] = outv[0];
                 }
                 ws_post(&seq[2], t + 1, lane);                               // V(o_t) (and V of the pre-reset o_t) posted
+                WS_TOC(t_cri, tc_);
             }
+            if (draw_m && t + 1 < pa.T) { policy_noise<A>(a, a.env_id_base + i, nctr_m, xin); ++nctr_m; }   // while the env wave steps
         }
 #ifdef DPENV_WS_PROFILE
-        if (live && pa.T >= 5 && do_actor) { (pa.logp + (int64_t)3 * n)[(unsigned)i] = (float)w_obs; (pa.logp + (int64_t)4 * n)[(unsigned)i] = (float)(__builtin_amdgcn_s_memtime() - t_start); }
+        if (live && pa.T >= 10 && do_actor) {
+            (pa.logp + (int64_t)3 * n)[(unsigned)i] = (float)w_obs; (pa.logp + (int64_t)4 * n)[(unsigned)i] = (float)(__builtin_amdgcn_s_memtime() - t_start);
+            (pa.logp + (int64_t)5 * n)[(unsigned)i] = (float)t_act; (pa.logp + (int64_t)6 * n)[(unsigned)i] = (float)t_cri;
+        }
 #endif
         return;
     }
@@ -435,30 +468,44 @@ __global__ __launch_bounds__(256 * ROLES) void policy_rollout_ws_kernel(const St
     ws_post(&seq[0], 1, lane);                                               // o_0 posted
     if (pa.noise) load_rows<A, 64>(pa.noise + w_a, rem_a, lane, pre);
     int next_switch = 0;
-    uint64_t w_mu = 0, w_v = 0; const uint64_t t_start = __builtin_amdgcn_s_memtime(); (void)t_start;
+    uint64_t w_mu = 0, w_v = 0, t_env = 0, t_noi = 0; const uint64_t t_start = __builtin_amdgcn_s_memtime(); (void)t_start; (void)w_mu; (void)w_v; (void)t_env; (void)t_noi;
+    uint64_t t_pre = 0, t_post = 0, t_off = 0; (void)t_pre; (void)t_post; (void)t_off;
     bool boot_wanted = false, was_reset = false;                             // of the step whose boot row is still owed
+    // Between "mu_t has arrived" and "o_t+1 is posted" the env wave is on the serial chain of the rollout (the network wave waits
+    // for that observation), so only what o_t+1 needs is done there: a_t = mu_t + std xi_t, env.step, the reset of finished
+    // envs.  The rows of step t (action, log-likelihood, reward, done, the observation row of t+1) are written after the
+    // hand-over, while the network wave evaluates mu_t+1.
+    wave_store_rows<OD>(lds_io, pa.obs_out, w_o, rem_o, o, lane, a.obs_bf16 != 0);
     for (int t = 0; t < pa.T; ++t) {
-        wave_store_rows<OD>(lds_io, pa.obs_out, (int64_t)t * stride_o + w_o, rem_o, o, lane, a.obs_bf16 != 0);
         const bool q_boot_wanted = boot_wanted, q_was_reset = was_reset;     // flags of step t-1
         // the exploration noise of this step does not depend on the actor's answer: it is drawn while the network wave is
         // still evaluating mu_t (the env wave would otherwise only poll)
         float xi[A];
+        WS_TIC(tn_);
         if (pa.noise) {
             wave_rows_from_regs<A>(lds_io, pre, xi, lane);
             if (t + 1 < pa.T) load_rows<A, 64>(pa.noise + (int64_t)(t + 1) * stride_a + w_a, rem_a, lane, pre);
         } else if (draw) {
-            policy_noise<A>(a, a.env_id_base + i, nctr, xi);
+            if (!M_NOISE) policy_noise<A>(a, a.env_id_base + i, nctr, xi);
             ++nctr;
         }
+        WS_TOC(t_noi, tn_);
         WS_WAIT_T(w_mu, &seq[1], t + 1);                                     // mu_t posted
         if (ROLES == 3) ws_wait(&seq[6], t + 1);
+        WS_TIC(tp_);
+#ifdef DPENV_WS_DYN_PRIO
+        __builtin_amdgcn_s_setprio(3);                                       // on the chain until o_t+1 is posted
+#endif
         float act[A], mu[A];
         float logp;
 #pragma unroll
         for (int k = 0; k < A; ++k) mu[k] = mu_mb[lane * 9 + k];
-        if (pa.noise || draw) logp = sample_action<A>(pc, mu, xi, act);
-        else logp = mean_action<A>(pc, mu, act);
-        wave_store_rows<A>(lds_io, pa.act_out, (int64_t)t * stride_a + w_a, rem_a, act, lane);
+        if (M_NOISE && draw) {
+#pragma unroll
+            for (int k = 0; k < A; ++k) xi[k] = xi_mb[lane * 9 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < A; ++k) act[k] = (pa.noise || draw) ? fmaf(pc.std[k], xi[k], mu[k]) : mu[k];      // core.py:85
         bool has_ref = false;
         float nrN = 0.0f, nrE = 0.0f, nrP = 0.0f;
         if (next_switch < pa.n_switch && pa.switch_step[next_switch] == t) {
@@ -483,7 +530,11 @@ __global__ __launch_bounds__(256 * ROLES) void policy_rollout_ws_kernel(const St
         asm volatile("" : "+v"(sB.refN), "+v"(sB.refE), "+v"(sB.refPsi), "+v"(sB.pt[0]), "+v"(sB.pt[1]), "+v"(sB.pt[2]),
                           "+v"(sB.ang[0]), "+v"(sB.ang[1]), "+v"(sB.ang[2]), "+v"(sB.steps));
 #endif
+        WS_TOC(t_pre, tp_);
+        WS_TIC(te_);
         env_step<MODE, EXT>(a, ve, s, act, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out);
+        WS_TOC(t_env, te_);
+        WS_TIC(tq_);
 #ifdef DPENV_WS_SELFCHECK
         {
             ws_wait(&seq[2], t + 1);                                         // critic(o_t) done: the partner is idle from here
@@ -543,6 +594,15 @@ __global__ __launch_bounds__(256 * ROLES) void policy_rollout_ws_kernel(const St
             for (int k = 0; k < OD; ++k) om[lane * 9 + k] = o[k];           // the next policy input
         }
         ws_post(&seq[0], t + 2, lane);                                       // o_{t+1} (and this step's pre flag) posted
+        WS_TOC(t_post, tq_);
+        WS_TIC(tr_);
+#ifdef DPENV_WS_DYN_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        __builtin_amdgcn_sched_barrier(0);                                   // nothing of the rows below moves up into the chain
+        logp = action_logp<A>(pc, mu, act);                                  // core.py:42-46 on (a_t, mu_t)
+        wave_store_rows<A>(lds_io, pa.act_out, (int64_t)t * stride_a + w_a, rem_a, act, lane);
+        if (t + 1 < pa.T) wave_store_rows<OD>(lds_io, pa.obs_out, (int64_t)(t + 1) * stride_o + w_o, rem_o, o, lane, a.obs_bf16 != 0);
         if (live) {
             (pa.rew + (int64_t)t * n)[(unsigned)i] = out.reward;
             (pa.done + (int64_t)t * n)[(unsigned)i] = (uint8_t)out.d;
@@ -550,6 +610,7 @@ __global__ __launch_bounds__(256 * ROLES) void policy_rollout_ws_kernel(const St
         }
         WS_WAIT_T(w_v, &seq[2], t + 1);                                      // V(o_t), V(pre-reset o_t) posted
         if (ROLES == 3) ws_wait(&seq[7], t + 1);
+        WS_TOC(t_off, tr_);
         if (live) {
             const float v_t = v_mb[(t & 1) * 64 + lane];
             (pa.val + (int64_t)t * n)[(unsigned)i] = v_t;
@@ -559,7 +620,12 @@ __global__ __launch_bounds__(256 * ROLES) void policy_rollout_ws_kernel(const St
     ws_wait(&seq[2], pa.T + 1);                                              // V(o_T) posted
     if (ROLES == 3) ws_wait(&seq[7], pa.T + 1);
 #ifdef DPENV_WS_PROFILE
-    if (live && pa.T >= 5) { (pa.logp + (int64_t)0 * n)[(unsigned)i] = (float)w_mu; (pa.logp + (int64_t)1 * n)[(unsigned)i] = (float)w_v; (pa.logp + (int64_t)2 * n)[(unsigned)i] = (float)(__builtin_amdgcn_s_memtime() - t_start); }
+    if (live && pa.T >= 12) {
+        (pa.logp + (int64_t)0 * n)[(unsigned)i] = (float)w_mu; (pa.logp + (int64_t)1 * n)[(unsigned)i] = (float)w_v; (pa.logp + (int64_t)2 * n)[(unsigned)i] = (float)(__builtin_amdgcn_s_memtime() - t_start);
+        (pa.logp + (int64_t)7 * n)[(unsigned)i] = (float)t_env; (pa.logp + (int64_t)8 * n)[(unsigned)i] = (float)t_noi;
+        (pa.logp + (int64_t)9 * n)[(unsigned)i] = (float)t_pre; (pa.logp + (int64_t)10 * n)[(unsigned)i] = (float)t_post;
+        (pa.logp + (int64_t)11 * n)[(unsigned)i] = (float)t_off;
+    }
 #endif
     wave_store_rows<OD>(lds_io, pa.last_obs, w_o, rem_o, o, lane, a.obs_bf16 != 0);
     if (live) {

@@ -89,92 +89,131 @@ __device__ __forceinline__ void interleave_stage()
 // out[j], j < 8: output row j of the lane's OWN env.
 //
 // Register discipline: a layer's output is never held as a whole f32 tile set.  Each 32-row block (two
-// accumulator tiles, one per env tile) is activated and packed to f16 as soon as its MFMAs are issued, straight
+// accumulator tiles, one per env tile) is activated and packed to f16 as soon as its MFMAs are done, straight
 // into the next layer's B fragments; weight fragments are fetched from LDS one row-block ahead.  That keeps the
 // evaluation under the 256 architectural VGPRs, so the accumulators stay out of the AGPR half (every AGPR value
 // a VALU instruction needs costs a v_accvgpr_read).
+//
+// Schedule: ONE software pipeline over all row-blocks of all layers - the MFMAs of a block are issued between the
+// activation / packing VALU of the block before it, ACROSS layer boundaries too.  A layer's first block needs fragments
+// 0..3 of its input for its first four k-steps and fragment 4 (5) only for the last; those last fragments come from the
+// LAST row-block of the layer before.  So the first eight MFMAs of a layer run while that block is being packed, and the
+// matrix pipe never waits for a whole layer to be packed (round 2; before, every layer boundary exposed an MFMA drain, a
+// packing tail and the LDS latency of the next layer's weights: ~22 % of a layer's time).  The MFMA chain of every
+// accumulator and the packing are unchanged: results are bit-identical to the layer-by-layer order.
+// Input and output fragment sets alternate between two register arrays (X, Y) by layer, statically.
 // KA = KS + 16 ACT: k-steps of 16 hidden features (5 or 6) and the hidden activation, as one template parameter
 template <int KA>
 __device__ __forceinline__ void mlp_eval(const uint4* W, const float* B, int n_hidden, half8 in0, half8 in1, _Float16 leak, float out[8])
 {
     constexpr int KS = KA & 15, ACT = KA >> 4;
+    constexpr int PACK_VALU = (ACT == ACT_TANH) ? 44 : 12;                   // VALU instructions of one act_pack (8 activations)
     const int lane = threadIdx.x & 63;
     const float16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    half8 b[KS][2], bn[KS][2], w[KS];
-    // first layer: one k-step, three row-blocks
+    half8 X[KS][2], Y[KS][2], w[KS], wn[KS];
+    float16v cb, cbn, p0, p1, q0, q1;
+    int fbase = 3, bblk = 0;                                                 // fragments / bias tiles of the layer being entered
+    // ---- first layer: one k-step, three row-blocks; the weights of the NEXT layer's block 0 are fetched behind it
 #pragma unroll
     for (int mo = 0; mo < 3; ++mo) w[mo] = ldfrag(W, mo, lane);
 #pragma unroll
-    for (int mo = 0; mo < 3; ++mo) {
-        const float16v c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[mo], in0, zero, 0, 0, 0);
-        const float16v c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[mo], in1, zero, 0, 0, 0);
-        b[2 * mo][0] = act_pack<ACT>(c0, 0, leak); b[2 * mo][1] = act_pack<ACT>(c1, 0, leak);
-        if (2 * mo + 1 < KS) { b[2 * mo + 1][0] = act_pack<ACT>(c0, 1, leak); b[2 * mo + 1][1] = act_pack<ACT>(c1, 1, leak); }
+    for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(W, fbase + ks, lane);
+    cbn = ldbias(B, bblk, lane);
+    {
+        const float16v a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0], in0, zero, 0, 0, 0);
+        const float16v a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0], in1, zero, 0, 0, 0);
+        const float16v c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1], in0, zero, 0, 0, 0);
+        const float16v c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1], in1, zero, 0, 0, 0);
+        q0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[2], in0, zero, 0, 0, 0);
+        q1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[2], in1, zero, 0, 0, 0);
+        X[0][0] = act_pack<ACT>(a0, 0, leak); X[0][1] = act_pack<ACT>(a1, 0, leak);
+        X[1][0] = act_pack<ACT>(a0, 1, leak); X[1][1] = act_pack<ACT>(a1, 1, leak);
+        X[2][0] = act_pack<ACT>(c0, 0, leak); X[2][1] = act_pack<ACT>(c1, 0, leak);
+        X[3][0] = act_pack<ACT>(c0, 1, leak); X[3][1] = act_pack<ACT>(c1, 1, leak);
     }
-    // hidden -> hidden layers, software-pipelined over the three row-blocks: the MFMAs of block mo+1 are issued between
-    // the activation/packing VALU of block mo (the blocks of one layer are independent; only the last block's packing
-    // is exposed before the next layer can start)
-    int fbase = 3, bblk = 0;
-    half8 wn[KS];
-    for (int l = 1; l < n_hidden; ++l) {
+    __builtin_amdgcn_sched_barrier(0);
+    // Entering a layer: wn / cbn hold its block-0 weights and bias tile; I[0..3] are packed; q0 / q1 are the accumulators of the
+    // previous layer's last block (MFMAs issued), still owed to I[4] (and I[5]).
+    // head(): block 0 of the layer - k-steps 0..3 beside the packing of q, then the remaining k-steps.
+    auto head = [&](half8 (&I)[KS][2], bool more) __attribute__((always_inline)) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) w[ks] = ldfrag(W, fbase + ks, lane);
-        float16v cb = ldbias(B, bblk, lane);
+        for (int ks = 0; ks < KS; ++ks) w[ks] = wn[ks];
+        cb = cbn;
+        if (more) {                                                          // a hidden layer: its block 1 is fetched now
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(W, fbase + KS + ks, lane);
-        float16v cbn = ldbias(B, bblk + 1, lane);
-        float16v p0 = cb, p1 = cb;                                          // block 0
+            for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(W, fbase + KS + ks, lane);
+            cbn = ldbias(B, bblk + 1, lane);
+        }
+        p0 = cb; p1 = cb;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            p0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks][0], p0, 0, 0, 0);
-            p1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks][1], p1, 0, 0, 0);
+        for (int ks = 0; ks < 4; ++ks) {
+            p0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], I[ks][0], p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], I[ks][1], p1, 0, 0, 0);
+        }
+        I[4][0] = act_pack<ACT>(q0, 0, leak); I[4][1] = act_pack<ACT>(q1, 0, leak);
+        if (5 < KS) { I[KS - 1][0] = act_pack<ACT>(q0, 1, leak); I[KS - 1][1] = act_pack<ACT>(q1, 1, leak); }
+        __builtin_amdgcn_sched_group_barrier(0x100, KS + 4, 0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, (2 * (KS - 4) * PACK_VALU + 7) / 8, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 4; ks < KS; ++ks) {
+            p0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], I[ks][0], p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], I[ks][1], p1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // hidden(): one hidden -> hidden layer, input fragments I, output fragments O (0..3 packed on return, 4.. owed by q)
+    auto hidden = [&](half8 (&I)[KS][2], half8 (&O)[KS][2]) __attribute__((always_inline)) {
+        head(I, true);
 #pragma unroll
         for (int mo = 1; mo < 3; ++mo) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) w[ks] = wn[ks];
             cb = cbn;
-            if (mo < 2) {
+            // block 2 is fetched during block 1; during block 2, block 0 of the layer after this one (hidden or output)
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(W, fbase + 2 * KS + ks, lane);
-                cbn = ldbias(B, bblk + 2, lane);
-            }
+            for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(W, fbase + (mo + 1) * KS + ks, lane);
+            cbn = ldbias(B, bblk + mo + 1, lane);
             float16v c0 = cb, c1 = cb;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks][0], c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks][1], c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], I[ks][0], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], I[ks][1], c1, 0, 0, 0);
             }
-            bn[2 * (mo - 1)][0] = act_pack<ACT>(p0, 0, leak); bn[2 * (mo - 1)][1] = act_pack<ACT>(p1, 0, leak);
-            bn[2 * (mo - 1) + 1][0] = act_pack<ACT>(p0, 1, leak); bn[2 * (mo - 1) + 1][1] = act_pack<ACT>(p1, 1, leak);
-            interleave_stage<KS>();
+            O[2 * (mo - 1)][0] = act_pack<ACT>(p0, 0, leak); O[2 * (mo - 1)][1] = act_pack<ACT>(p1, 0, leak);
+            O[2 * (mo - 1) + 1][0] = act_pack<ACT>(p0, 1, leak); O[2 * (mo - 1) + 1][1] = act_pack<ACT>(p1, 1, leak);
+            __builtin_amdgcn_sched_group_barrier(0x100, KS + 4, 0);
+#pragma unroll
+            for (int k = 0; k < 2 * KS; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, (4 * PACK_VALU + 2 * KS - 1) / (2 * KS), 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             p0 = c0; p1 = c1;
         }
-        bn[4][0] = act_pack<ACT>(p0, 0, leak); bn[4][1] = act_pack<ACT>(p1, 0, leak);
-        if (5 < KS) { bn[KS - 1][0] = act_pack<ACT>(p0, 1, leak); bn[KS - 1][1] = act_pack<ACT>(p1, 1, leak); }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) { b[ks][0] = bn[ks][0]; b[ks][1] = bn[ks][1]; }
+        q0 = p0; q1 = p1;
         fbase += 3 * KS;
         bblk += 3;
-    }
+    };
+    auto output = [&](half8 (&I)[KS][2]) __attribute__((always_inline)) {
+        head(I, false);
+        // rows 0..3 sit in registers 0..3 of lane half 0, rows 4..7 in registers 0..3 of lane half 1, for the 32 envs
+        // of each tile: one permlane32 swap per register brings every env's 8 rows home to its own lane
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) w[ks] = ldfrag(W, fbase + ks, lane);
-    const float16v cb = ldbias(B, bblk, lane);
-    float16v c0 = cb, c1 = cb;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks][0], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks][1], c1, 0, 0, 0);
-    }
-    // rows 0..3 sit in registers 0..3 of lane half 0, rows 4..7 in registers 0..3 of lane half 1, for the 32 envs
-    // of each tile: one permlane32 swap per register brings every env's 8 rows home to its own lane
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(c0[j]), __float_as_uint(c1[j]), false, false);
-        out[j] = __uint_as_float(r[0]);
-        out[4 + j] = __uint_as_float(r[1]);
-    }
+        for (int j = 0; j < 4; ++j) {
+            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(p0[j]), __float_as_uint(p1[j]), false, false);
+            out[j] = __uint_as_float(r[0]);
+            out[4 + j] = __uint_as_float(r[1]);
+        }
+    };
+    int l = 1;
+    for (; l + 1 < n_hidden; l += 2) { hidden(X, Y); hidden(Y, X); }
+    if (l < n_hidden) { hidden(X, Y); output(Y); }
+    else output(X);
 }
 
 // One MLP for ONE 32-env tile (the tile-split closed loop, dpenv_policy.hip): `in` is that tile's first-layer B fragment
@@ -470,6 +509,20 @@ __device__ __forceinline__ float sample_action(const PolicyConsts<A>& c, const f
 #pragma unroll
     for (int k = 0; k < A; ++k) {
         act[k] = fmaf(c.std[k], xi[k], mu[k]);
+        const float z = (act[k] - mu[k]) * c.inv_std_eps[k];
+        logp += fmaf(-0.5f * z, z, c.logp_const[k]);
+    }
+    return logp;
+}
+
+// the log-likelihood of sample_action / mean_action from (a, mu) alone: same operations in the same order (a - mu is exactly
+// zero for the mean action, and fma(-0, 0, c) = c), so a kernel can take it off the path between sampling and stepping
+template <int A>
+__device__ __forceinline__ float action_logp(const PolicyConsts<A>& c, const float mu[A], const float act[A])
+{
+    float logp = 0.0f;
+#pragma unroll
+    for (int k = 0; k < A; ++k) {
         const float z = (act[k] - mu[k]) * c.inv_std_eps[k];
         logp += fmaf(-0.5f * z, z, c.logp_const[k]);
     }

@@ -21,11 +21,22 @@ n, T = 65536, 50
 env = ml4ca_amd.BatchedRevoltEnv(n, auto_reset=True)
 ActorCritic(9, 7, (80, 80, 80), device=env.device).upload(env)
 env.reset()
-noise = torch.randn((T, n, 7), device=env.device)
 for _ in range(3):
-    out = policy_rollout(env, T, noise=noise)
+    out = policy_rollout(env, T, sample=True)
 lp = out['logp'].double()
 e_tot, m_tot = float(lp[2].mean()), float(lp[4].mean())
 print('env wave:     waits for the actor mean %4.1f %%, for the value %4.1f %%, busy %4.1f %%' % (
     100 * float(lp[0].mean()) / e_tot, 100 * float(lp[1].mean()) / e_tot, 100 * (1 - float((lp[0] + lp[1]).mean()) / e_tot)))
 print('network wave: waits for the observation %4.1f %%, busy %4.1f %%' % (100 * float(lp[3].mean()) / m_tot, 100 * (1 - float(lp[3].mean()) / m_tot)))
+# s_memtime tick -> us from the launch's own duration (timed with events below)
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+ev0.record()
+out2 = policy_rollout(env, T, sample=True)
+ev1.record()
+torch.cuda.synchronize()
+tick_us = ev0.elapsed_time(ev1) * 1e3 / float(out2['logp'].double()[2].mean())
+print('per step (us): launch %.2f | network wave: actor %.2f, critic (+ pre-reset critic) %.2f, wait obs %.2f | env wave: env_step %.2f, noise %.2f, '
+      'wait mu %.2f, wait v %.2f; mu -> env_step %.2f, env_step -> obs posted %.2f, obs posted -> v wait done %.2f' % (e_tot * tick_us / T, float(lp[5].mean()) * tick_us / T, float(lp[6].mean()) * tick_us / T,
+                                      float(lp[3].mean()) * tick_us / T, float(lp[7].mean()) * tick_us / T, float(lp[8].mean()) * tick_us / T,
+                                      float(lp[0].mean()) * tick_us / T, float(lp[1].mean()) * tick_us / T,
+                                      float(lp[9].mean()) * tick_us / T, float(lp[10].mean()) * tick_us / T, float(lp[11].mean()) * tick_us / T))

@@ -305,7 +305,7 @@ __device__ __forceinline__ void current_drift_step(const StepArgs& a, Current& c
                   a.seed_hi, w);
     c.ctr += 1u;
     float zc, zs;
-    box_muller(w[0], w[1], zc, zs);
+    box_muller_hw(w[0], w[1], zc, zs);       // drawn every env step where the current drifts: the hardware transcendentals (above)
     c.vc = fmaf(a.drift_sv, zc, fmaf(a.drift_a, vc0 - c.vc, c.vc));
     c.beta = fmaf(a.drift_sb, zs, fmaf(a.drift_a, beta0 - c.beta, c.beta));
     current_components(c);

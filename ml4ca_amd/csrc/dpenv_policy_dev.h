@@ -694,6 +694,41 @@ __device__ __forceinline__ void obs_to_frags_x(const float o[9], SplitIn& in)
     swap4(Pl, Ql, in.l0, in.l1);
 }
 
+// The two halves of leaky_split4 as separate statements, so that an MFMA can be issued between them (mlp_eval_x): same
+// instructions, same results.  `m` = leak * x comes from the compiler (the VALU read of the accumulators that carries the wait states).
+__device__ __forceinline__ void leaky_split4_hi(const float x[4], const float m[4], float t[4], uint32_t H[2])
+{
+    asm volatile("v_max_f32 %2, %6, %10\n\tv_max_f32 %3, %7, %11\n\tv_max_f32 %4, %8, %12\n\tv_max_f32 %5, %9, %13\n\t"
+        "v_cvt_pk_f16_f32 %0, %2, %3\n\tv_cvt_pk_f16_f32 %1, %4, %5"
+        : "=&v"(H[0]), "=&v"(H[1]), "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]));
+}
+__device__ __forceinline__ void leaky_split4_lo(float t[4], const uint32_t H[2], uint32_t L[2])
+{
+    asm volatile("v_fma_mix_f32 %2, %6, %8, %2 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %3, %6, %8, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %4, %7, %8, %4 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %5, %7, %8, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_cvt_pk_f16_f32 %0, %2, %3\n\tv_cvt_pk_f16_f32 %1, %4, %5"
+        : "=&v"(L[0]), "=&v"(L[1]), "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3])
+        : "v"(H[0]), "v"(H[1]), "v"(-1.0f));
+}
+
+// HAZARD NOTE 2 (found when the evaluation was interleaved, round 2): an asm statement is invisible to the MFMA hazard recogniser
+// as a WRITER too.  With 80-wide layers only registers 0..7 of a layer's last accumulator tile are ever read (rows 80..95 are padding),
+// so the register allocator considers registers 8..15 dead as soon as the tile's MFMAs are ISSUED and hands them to the next asm
+// statement as temporaries - whose v_max / v_fma_mix results the still-running MFMA then overwrites (seen: actor mean of env tile 0
+// wrong by 0.1-0.4 in one inlined copy of the evaluation).  keep_alive() is an empty asm that reads whole tiles: placed after the
+// units that consume a tile (and after the MFMAs that read a bias tile as SrcC) it keeps every register of the tile allocated until
+// the matrix pipe is done with it.  tests/test_abi_cpu.py scans the ISA of this unit for asm-written registers inside the
+// destination of a recent MFMA.
+__device__ __forceinline__ void keep_alive(const float16v& a) { asm volatile("" : : "v"(a)); }
+
+// One split-f16 MLP for the 64 envs of a wave.  A wave issues in order and the matrix pipe takes one MFMA at a time, so MFMAs and
+// the activation / split VALU only overlap if they ALTERNATE in the instruction stream.  The evaluation is therefore written as a
+// sequence of slots - one k-step of one env tile: MFMA (Wh xh), 4 VALU, MFMA (Wh xl), 6 VALU, MFMA (Wl xh), 6 VALU - where the VALU
+// of a slot is one unit (four activations) of the row-block computed one stage earlier; `sched_barrier`s pin the order.  Like
+// mlp_eval it is one pipeline across layers: a layer's block 0 runs its first four k-steps beside the split of the previous layer's
+// last block.  Before (all MFMAs of a block, then all VALU of a block): matrix pipe and VALU took turns, 15.5 us per closed-loop
+// step; the MFMA chain of every accumulator and every activation's arithmetic are unchanged, so results are bit-identical.
 template <int KA>
 __device__ __forceinline__ void mlp_eval_x(const uint4* Wh, const uint4* Wl, const float* B, int n_hidden, const SplitIn& in, float leak,
                                            float out[8])
@@ -701,65 +736,150 @@ __device__ __forceinline__ void mlp_eval_x(const uint4* Wh, const uint4* Wl, con
     constexpr int KS = KA & 15, ACT = KA >> 4;
     const int lane = threadIdx.x & 63;
     const float16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    half8 bh[KS][2], bl[KS][2], nh[KS][2], nl[KS][2];
+    struct Frag { uint32_t h[4], l[4]; };                 // one B fragment: high and low f16 parts, 8 features each
+    Frag X[KS][2], Y[KS][2];
+    float16v p0, p1, q0, q1;
+    auto FH = [](const Frag& f) { const uint4 q = {f.h[0], f.h[1], f.h[2], f.h[3]}; return __builtin_bit_cast(half8, q); };
+    auto FL = [](const Frag& f) { const uint4 q = {f.l[0], f.l[1], f.l[2], f.l[3]}; return __builtin_bit_cast(half8, q); };
+    // slot: three MFMAs of accumulator c with weights (wh, wl) and input fragment b; between them, unit `qq` (four activations:
+    // registers 8 s + 4 qq .. + 3) of the finished accumulator `acc` goes into words 2 qq, 2 qq + 1 of fragment d
+    auto slot = [&](float16v& c, const half8& wh, const half8& wl, const Frag& b, bool has, const float16v& acc, int sreg, int qq,
+                    Frag& d) __attribute__((always_inline)) {
+        float x[4], m[4], t[4];
+        // the empty asm after each MFMA pins it in program order (an MFMA has no side effects: without it the compiler is free to
+        // sink a whole chain to its first use, past every sched_barrier)
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, FH(b), c, 0, 0, 0);
+        asm volatile("" : "+v"(c));
+        if (has) {
+            if (ACT == ACT_TANH) {
 #pragma unroll
-    for (int mo = 0; mo < 3; ++mo) {
-        const half8 wh = ldfrag(Wh, mo, lane), wl = ldfrag(Wl, mo, lane);
-        const float16v c0 = mfma3(wh, wl, in.h0, in.l0, zero), c1 = mfma3(wh, wl, in.h1, in.l1, zero);
-        act_split<ACT>(c0, 0, leak, bh[2 * mo][0], bl[2 * mo][0]);
-        act_split<ACT>(c1, 0, leak, bh[2 * mo][1], bl[2 * mo][1]);
-        if (2 * mo + 1 < KS) {
-            act_split<ACT>(c0, 1, leak, bh[2 * mo + 1][0], bl[2 * mo + 1][0]);
-            act_split<ACT>(c1, 1, leak, bh[2 * mo + 1][1], bl[2 * mo + 1][1]);
+                for (int k = 0; k < 4; ++k) {
+                    const float e = __builtin_amdgcn_exp2f(acc[8 * sreg + 4 * qq + k] * 2.8853900817779268f);      // exp(2x)
+                    x[k] = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { x[k] = acc[8 * sreg + 4 * qq + k]; m[k] = x[k] * leak; }
+            }
         }
-    }
+        __builtin_amdgcn_sched_barrier(0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, FL(b), c, 0, 0, 0);
+        asm volatile("" : "+v"(c));
+        if (has) {
+            if (ACT == ACT_TANH) { split_pair(x[0], x[1], d.h[2 * qq], d.l[2 * qq]); }
+            else leaky_split4_hi(x, m, t, &d.h[2 * qq]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, FH(b), c, 0, 0, 0);
+        asm volatile("" : "+v"(c));
+        if (has) {
+            if (ACT == ACT_TANH) { split_pair(x[2], x[3], d.h[2 * qq + 1], d.l[2 * qq + 1]); }
+            else leaky_split4_lo(t, &d.h[2 * qq], &d.l[2 * qq]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // a unit without an MFMA to hide behind (first layer only)
+    auto bare_unit = [&](const float16v& acc, int sreg, int qq, Frag& d) __attribute__((always_inline)) {
+        float x[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = acc[8 * sreg + 4 * qq + k];
+        if (ACT == ACT_TANH) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float e = __builtin_amdgcn_exp2f(x[k] * 2.8853900817779268f);
+                x[k] = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+            }
+            split_pair(x[0], x[1], d.h[2 * qq], d.l[2 * qq]);
+            split_pair(x[2], x[3], d.h[2 * qq + 1], d.l[2 * qq + 1]);
+        } else {
+            leaky_split4(x, leak, &d.h[2 * qq], &d.l[2 * qq]);
+        }
+    };
     int fbase = 3, bblk = 0;
-    for (int l = 1; l < n_hidden; ++l) {
-        // the three row-blocks of a layer are independent: block mo + 1's MFMAs are issued before block mo is activated and split,
-        // so that the matrix pipe is still draining them while the VALU works (interleaving the two in program order at k-step
-        // granularity was measured slower: 16.7 against 16.15 us per step - more live accumulators, more AGPR traffic)
-        auto block = [&](int mo, float16v& c0, float16v& c1) {
-            c0 = ldbias(B, bblk + mo, lane); c1 = c0;
+    // ---- first layer (one k-step): blocks 0 and 1, then block 2 beside the split of block 0; the split of block 1 is exposed
+    {
+        Frag I0, I1;
+        const uint4 h0 = __builtin_bit_cast(uint4, in.h0), l0 = __builtin_bit_cast(uint4, in.l0);
+        const uint4 h1 = __builtin_bit_cast(uint4, in.h1), l1 = __builtin_bit_cast(uint4, in.l1);
+        I0.h[0] = h0.x; I0.h[1] = h0.y; I0.h[2] = h0.z; I0.h[3] = h0.w; I0.l[0] = l0.x; I0.l[1] = l0.y; I0.l[2] = l0.z; I0.l[3] = l0.w;
+        I1.h[0] = h1.x; I1.h[1] = h1.y; I1.h[2] = h1.z; I1.h[3] = h1.w; I1.l[0] = l1.x; I1.l[1] = l1.y; I1.l[2] = l1.z; I1.l[3] = l1.w;
+        const half8 w0h = ldfrag(Wh, 0, lane), w0l = ldfrag(Wl, 0, lane), w1h = ldfrag(Wh, 1, lane), w1l = ldfrag(Wl, 1, lane);
+        const half8 w2h = ldfrag(Wh, 2, lane), w2l = ldfrag(Wl, 2, lane);
+        float16v a0 = zero, a1 = zero, c0 = zero, c1 = zero;
+        Frag none;
+        slot(a0, w0h, w0l, I0, false, zero, 0, 0, none);
+        slot(a1, w0h, w0l, I1, false, zero, 0, 0, none);
+        slot(c0, w1h, w1l, I0, true, a0, 0, 0, X[0][0]);
+        slot(c1, w1h, w1l, I1, true, a0, 0, 1, X[0][0]);
+        q0 = zero; q1 = zero;
+        slot(q0, w2h, w2l, I0, true, a0, 1, 0, X[1][0]);
+        slot(q1, w2h, w2l, I1, true, a0, 1, 1, X[1][0]);
+        bare_unit(a1, 0, 0, X[0][1]); bare_unit(a1, 0, 1, X[0][1]);
+        bare_unit(a1, 1, 0, X[1][1]); bare_unit(a1, 1, 1, X[1][1]);
+#pragma unroll
+        for (int sreg = 0; sreg < 2; ++sreg) {
+            bare_unit(c0, sreg, 0, X[2 + sreg][0]); bare_unit(c0, sreg, 1, X[2 + sreg][0]);
+            bare_unit(c1, sreg, 0, X[2 + sreg][1]); bare_unit(c1, sreg, 1, X[2 + sreg][1]);
+        }
+        keep_alive(a0); keep_alive(a1); keep_alive(c0); keep_alive(c1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // head: block 0 of the layer being entered.  I[0..3] are complete; q0 / q1 (the last block of the layer before) still owe I[4]
+    // (and I[5]): their units ride on the first k-steps.  Weights: one k-step (wh, wl) is fetched while the one before is multiplied.
+    auto head = [&](Frag (&I)[KS][2]) __attribute__((always_inline)) {
+        const float16v cb = ldbias(B, bblk, lane);
+        p0 = cb; p1 = cb;
+        half8 wh = ldfrag(Wh, fbase, lane), wl = ldfrag(Wl, fbase, lane);
+        constexpr int NU = 4 * (KS - 4);                                    // pending units: 4 (KS = 5) or 8 (KS = 6)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            half8 nwh = wh, nwl = wl;
+            if (ks + 1 < KS) { nwh = ldfrag(Wh, fbase + ks + 1, lane); nwl = ldfrag(Wl, fbase + ks + 1, lane); }
+            const int u0 = 2 * ks, u1 = 2 * ks + 1;                          // unit u: tile u & 1, quarter (u >> 1) & 1, half u >> 2
+            slot(p0, wh, wl, I[ks][0], ks < 4 && u0 < NU, (u0 & 1) ? q1 : q0, u0 >> 2, (u0 >> 1) & 1, I[4 + (u0 >> 2) < KS ? 4 + (u0 >> 2) : 4][u0 & 1]);
+            slot(p1, wh, wl, I[ks][1], ks < 4 && u1 < NU, (u1 & 1) ? q1 : q0, u1 >> 2, (u1 >> 1) & 1, I[4 + (u1 >> 2) < KS ? 4 + (u1 >> 2) : 4][u1 & 1]);
+            wh = nwh; wl = nwl;
+        }
+        keep_alive(q0); keep_alive(q1); keep_alive(cb);
+    };
+    auto hidden = [&](Frag (&I)[KS][2], Frag (&O)[KS][2]) __attribute__((always_inline)) {
+        head(I);
+#pragma unroll
+        for (int mo = 1; mo < 3; ++mo) {
+            const float16v cb = ldbias(B, bblk + mo, lane);
+            float16v c0 = cb, c1 = cb;
+            half8 wh = ldfrag(Wh, fbase + mo * KS, lane), wl = ldfrag(Wl, fbase + mo * KS, lane);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const half8 wh = ldfrag(Wh, fbase + mo * KS + ks, lane), wl = ldfrag(Wl, fbase + mo * KS + ks, lane);
-                c0 = mfma3(wh, wl, bh[ks][0], bl[ks][0], c0);
-                c1 = mfma3(wh, wl, bh[ks][1], bl[ks][1], c1);
+                half8 nwh = wh, nwl = wl;
+                if (ks + 1 < KS) { nwh = ldfrag(Wh, fbase + mo * KS + ks + 1, lane); nwl = ldfrag(Wl, fbase + mo * KS + ks + 1, lane); }
+                // the eight units of block mo - 1 (p0 / p1) -> O[2 (mo - 1)], O[2 (mo - 1) + 1]
+                const int u0 = 2 * ks, u1 = 2 * ks + 1;
+                slot(c0, wh, wl, I[ks][0], u0 < 8, (u0 & 1) ? p1 : p0, (u0 >> 2) & 1, (u0 >> 1) & 1, O[2 * (mo - 1) + ((u0 >> 2) & 1)][u0 & 1]);
+                slot(c1, wh, wl, I[ks][1], u1 < 8, (u1 & 1) ? p1 : p0, (u1 >> 2) & 1, (u1 >> 1) & 1, O[2 * (mo - 1) + ((u1 >> 2) & 1)][u1 & 1]);
+                wh = nwh; wl = nwl;
             }
-        };
-        auto pack = [&](int mo, const float16v& c0, const float16v& c1) {
-            act_split<ACT>(c0, 0, leak, nh[2 * mo][0], nl[2 * mo][0]);
-            act_split<ACT>(c1, 0, leak, nh[2 * mo][1], nl[2 * mo][1]);
-            if (2 * mo + 1 < KS) {
-                act_split<ACT>(c0, 1, leak, nh[2 * mo + 1][0], nl[2 * mo + 1][0]);
-                act_split<ACT>(c1, 1, leak, nh[2 * mo + 1][1], nl[2 * mo + 1][1]);
-            }
-        };
-        float16v p0, p1, q0, q1;
-        block(0, p0, p1);
-        block(1, q0, q1);
-        pack(0, p0, p1);
-        block(2, p0, p1);
-        pack(1, q0, q1);
-        pack(2, p0, p1);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) { bh[ks][0] = nh[ks][0]; bh[ks][1] = nh[ks][1]; bl[ks][0] = nl[ks][0]; bl[ks][1] = nl[ks][1]; }
+            keep_alive(p0); keep_alive(p1); keep_alive(cb);
+            p0 = c0; p1 = c1;
+        }
+        q0 = p0; q1 = p1;
         fbase += 3 * KS;
         bblk += 3;
-    }
-    float16v c0 = ldbias(B, bblk, lane), c1 = c0;
+    };
+    auto output = [&](Frag (&I)[KS][2]) __attribute__((always_inline)) {
+        head(I);
+        keep_alive(p0); keep_alive(p1);                  // only rows 0..7 are read below; the next asm statement may be close
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const half8 wh = ldfrag(Wh, fbase + ks, lane), wl = ldfrag(Wl, fbase + ks, lane);
-        c0 = mfma3(wh, wl, bh[ks][0], bl[ks][0], c0);
-        c1 = mfma3(wh, wl, bh[ks][1], bl[ks][1], c1);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(c0[j]), __float_as_uint(c1[j]), false, false);
-        out[j] = __uint_as_float(r[0]);
-        out[4 + j] = __uint_as_float(r[1]);
-    }
+        for (int j = 0; j < 4; ++j) {
+            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(p0[j]), __float_as_uint(p1[j]), false, false);
+            out[j] = __uint_as_float(r[0]);
+            out[4 + j] = __uint_as_float(r[1]);
+        }
+    };
+    int l = 1;
+    for (; l + 1 < n_hidden; l += 2) { hidden(X, Y); hidden(Y, X); }
+    if (l < n_hidden) { hidden(X, Y); output(Y); }
+    else output(X);
 }
 
 }  // namespace dpenv

@@ -161,6 +161,23 @@ def test_no_packed_fp32_in_any_translation_unit():
         # (b) no packed fp32 arithmetic at all; the f16 forms of the network's activation packing are fine
         packed = sorted(set(re.findall(r'\bv_pk_\w+', txt)))
         assert all(q.endswith('_f16') for q in packed), (unit, packed)
+    # (c) inline asm vs the matrix pipe (tools/asm_mfma_waw_scan.py, dpenv_policy_dev.h HAZARD NOTE 2): the hazard recogniser does not
+    # look inside asm statements, so no asm instruction may write a register inside the destination tile of an MFMA that can still be
+    # running (round 2: dead rows 80..95 of an accumulator were handed to the activation / split asm as temporaries)
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    from asm_mfma_waw_scan import asm_writes_into_recent_mfma_dest
+    for unit in ('dpenv_policy.hip', 'dpenv_policy_x.hip'):
+        hits = asm_writes_into_recent_mfma_dest(asm[unit])
+        assert not hits, (unit, len(hits), hits[:4])
+    bad = """k:
+\tv_mfma_f32_32x32x16_f16 v[32:47], v[76:79], v[92:95], 0
+\t;;#ASMSTART
+\tv_max_f32 v40, v58, v28
+\t;;#ASMEND
+"""
+    assert asm_writes_into_recent_mfma_dest(bad)
+    assert not asm_writes_into_recent_mfma_dest(bad.replace('\t;;#ASMSTART', '\tv_mul_f32_e32 v1, s33, v33\n\t;;#ASMSTART'))   # a visible read first
+    assert not asm_writes_into_recent_mfma_dest(bad.replace('v_max_f32 v40', 'v_max_f32 v48'))
     # the pattern itself must be what the check looks for: the reproducer's instruction text matches, the safe form does not
     assert swz.search('\tv_pk_fma_f32 v[46:47], v[124:125], v[38:39], v[46:47] op_sel:[0,1,0]')
     assert swz.search('\tv_pk_fma_f32 v[0:1], v[2:3], v[2:3], v[4:5] op_sel:[0,0,1]')

@@ -58,6 +58,53 @@ __global__ __launch_bounds__(512) void k(const uint4* frags, const float* bias, 
     if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
 
+// the fp32-faithful (split-f16) evaluation alone: same harness, weights' low image = a second copy of the fragments
+template <int KA>
+__global__ __launch_bounds__(256) void kx(const uint4* frags, const float* bias, int nfrag, int nblk, int n_hidden, int iters, float* out,
+                                          unsigned long long* cyc)
+{
+    extern __shared__ uint4 lds[];
+    for (int i = threadIdx.x; i < 2 * nfrag * 64; i += blockDim.x) lds[i] = frags[i % (nfrag * 64)];
+    float* lb = (float*)(lds + 2 * nfrag * 64);
+    for (int i = threadIdx.x; i < nblk * 32; i += blockDim.x) lb[i] = bias[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    SplitIn in;
+    for (int j = 0; j < 8; ++j) { in.h0[j] = (_Float16)(0.01f * (lane + j)); in.h1[j] = (_Float16)(0.02f * j); in.l0[j] = (_Float16)(1e-4f * j); in.l1[j] = (_Float16)(2e-4f * j); }
+    float o[8], acc = 0.0f;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < iters; ++i) {
+        mlp_eval_x<KA>(lds, lds + nfrag * 64, lb, n_hidden, in, 0.2f, o);
+        acc += o[0] + o[5];
+        in.h0[0] = (_Float16)(acc * 1e-3f);
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+
+static void run_x(int iters)
+{
+    const int KS = 5, nh = 3, nfrag = 3 + 3 * KS * (nh - 1) + KS, nblk = 3 * (nh - 1) + 1;
+    std::vector<uint16_t> hf((size_t)nfrag * 64 * 8);
+    for (size_t i = 0; i < hf.size(); ++i) hf[i] = (uint16_t)(0x2000 + (i * 37) % 0x0800);
+    std::vector<float> hb((size_t)nblk * 32, 0.01f);
+    uint4* df; float* db; float* dout; unsigned long long* dc;
+    hipMalloc(&df, hf.size() * 2); hipMalloc(&db, hb.size() * 4); hipMalloc(&dout, 256 * 512 * 4); hipMalloc(&dc, 24);
+    hipMemcpy(df, hf.data(), hf.size() * 2, hipMemcpyHostToDevice); hipMemcpy(db, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
+    const size_t ldsb = (size_t)2 * nfrag * 64 * 16 + (size_t)nblk * 32 * 4 + 16;
+    hipFuncSetAttribute((const void*)kx<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((kx<5>), dim3(256), dim3(256), ldsb, 0, df, db, nfrag, nblk, nh, iters, dout, dc);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+    }
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long c; hipMemcpy(&c, dc, 8, hipMemcpyDeviceToHost);
+    printf("fp32-faithful evaluation alone: %.3f us per evaluation (events), %.0f ticks; 231 MFMAs = 7 392 matrix-pipe cycles\n", ms * 1e3 / iters, (double)c / iters);
+}
+
 template <int PARTNER> static void run(int iters)
 {
     const int KS = 5, nh = 3, nfrag = 3 + 3 * KS * (nh - 1) + KS, nblk = 3 * (nh - 1) + 1;
@@ -88,5 +135,6 @@ int main()
     run<1>(2000);      // + a VALU wave per SIMD, network waves at s_setprio 3: the VALU wave runs until its network wave is done
     run<3>(2000);      // the same without s_setprio
     run<2>(2000);      // VALU waves alone (fixed trip count)
+    run_x(1000);
     return 0;
 }

@@ -176,9 +176,12 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
         // run once more on the pre-reset observation of the wave before the finished envs are re-drawn.
         float v_pre = 0.0f;
         if (__ballot(do_reset) != 0ull) {                       // wave-uniform
-            obs_to_frags<OD>(o, in0, in1);
-            mlp_eval<KA>(Wv, Bv, pa.n_hidden, in0, in1, leak, vout);
-            v_pre = vout[0];
+            // only a CUT episode (time limit) bootstraps with V of its last observation; a terminated one with 0 (ppo.py:311)
+            if (__ballot(do_reset && (out.d & DONE_TERMINAL) == 0u) != 0ull) {
+                obs_to_frags<OD>(o, in0, in1);
+                mlp_eval<KA>(Wv, Bv, pa.n_hidden, in0, in1, leak, vout);
+                v_pre = vout[0];
+            }
             if (do_reset) {
                 env_auto_reset<MODE>(a, s, a.env_id_base + i, episode, o);
                 ++episode; ep_dirty = true; rf_dirty = true;

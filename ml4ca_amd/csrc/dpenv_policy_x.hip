@@ -150,10 +150,14 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_x_kernel(const StepArgs
         for (int k = 0; k < 9; ++k) o[k] = out.o[k];
         const bool do_reset = a.auto_reset && out.d != 0u && live;
         float v_pre = 0.0f;
-        if (__ballot(do_reset) != 0ull) {                       // wave-uniform: the critic once more on the pre-reset observation
-            obs_to_frags_x<OD>(o, in);
-            mlp_eval_x<KA>(nets.Wv_h, nets.Wv_l, nets.Bv, pa.n_hidden, in, leak, vout);
-            v_pre = vout[0];
+        if (__ballot(do_reset) != 0ull) {                       // wave-uniform
+            // the critic once more, on the pre-reset observation - only if an env of the wave was CUT (time limit): a terminated
+            // env bootstraps with 0 (ppo.py:311), and with termination on most finished envs are terminated ones
+            if (__ballot(do_reset && (out.d & DONE_TERMINAL) == 0u) != 0ull) {
+                obs_to_frags_x<OD>(o, in);
+                mlp_eval_x<KA>(nets.Wv_h, nets.Wv_l, nets.Bv, pa.n_hidden, in, leak, vout);
+                v_pre = vout[0];
+            }
             if (do_reset) {
                 env_auto_reset<MODE>(a, s, a.env_id_base + i, episode, o);
                 ++episode; ep_dirty = true; rf_dirty = true;

@@ -566,7 +566,6 @@ __global__ __launch_bounds__(256 * ROLES) void policy_rollout_ws_kernel(const St
             }
         }
 #endif
-        if (a.current_drift) current_drift_step(a, cur, vc0, beta0, a.env_id_base + i);
 #pragma unroll
         for (int k = 0; k < 9; ++k) o[k] = out.o[k];
         const bool do_reset = a.auto_reset && out.d != 0u && live;
@@ -604,6 +603,7 @@ __global__ __launch_bounds__(256 * ROLES) void policy_rollout_ws_kernel(const St
 #endif
         __builtin_amdgcn_sched_barrier(0);                                   // nothing of the rows below moves up into the chain
         logp = action_logp<A>(pc, mu, act);                                  // core.py:42-46 on (a_t, mu_t)
+        if (a.current_drift) current_drift_step(a, cur, vc0, beta0, a.env_id_base + i);   // the current of step t+1: not needed by o_t+1
         wave_store_rows<A>(lds_io, pa.act_out, (int64_t)t * stride_a + w_a, rem_a, act, lane);
         if (t + 1 < pa.T) wave_store_rows<OD>(lds_io, pa.obs_out, (int64_t)(t + 1) * stride_o + w_o, rem_o, o, lane, a.obs_bf16 != 0);
         if (live) {

@@ -499,7 +499,7 @@ def test_two_wave_rollout_equals_single_wave_rollout_repeatedly():
                 assert torch.equal(got[k], want[k]), '%s launch, repetition %d: %s differs' % (form, rep, k)
 
 
-@pytest.mark.parametrize('case', range(12))
+@pytest.mark.parametrize("case", range(24))
 def test_two_wave_rollout_random_configurations(case):
     """The two launch forms of dpenv_policy_rollout against each other over drawn configurations: variant, observation
     width, network shape and activation, ragged env counts (partly filled waves and pairs without envs), auto-reset

@@ -358,7 +358,7 @@ __global__ __launch_bounds__(BLOCK) void thrust_map_kernel(const VesselDev vd, c
 // them in index order, so the statistics are bit-reproducible (no float atomics).
 
 template <int V> struct GaeVec;
-template <> struct GaeVec<4> { typedef float4 F; typedef uint32_t E; };
+template <> struct GaeVec<2> { typedef float2 F; typedef uint16_t E; };
 template <> struct GaeVec<1> { typedef float F; typedef uint8_t E; };
 
 template <int V> struct GaeRow {
@@ -366,11 +366,11 @@ template <int V> struct GaeRow {
     typename GaeVec<V>::E e;
 };
 
-__device__ __forceinline__ float gae_get(const float4& x, int k) { return k == 0 ? x.x : (k == 1 ? x.y : (k == 2 ? x.z : x.w)); }
+__device__ __forceinline__ float gae_get(const float2& x, int k) { return k == 0 ? x.x : x.y; }
 __device__ __forceinline__ float gae_get(const float& x, int) { return x; }
-__device__ __forceinline__ void gae_set(float4& x, int k, float v) { if (k == 0) x.x = v; else if (k == 1) x.y = v; else if (k == 2) x.z = v; else x.w = v; }
+__device__ __forceinline__ void gae_set(float2& x, int k, float v) { if (k == 0) x.x = v; else x.y = v; }
 __device__ __forceinline__ void gae_set(float& x, int, float v) { x = v; }
-__device__ __forceinline__ uint32_t gae_end(uint32_t e, int k) { return (e >> (8 * k)) & 0xffu; }
+__device__ __forceinline__ uint32_t gae_end(uint16_t e, int k) { return ((uint32_t)e >> (8 * k)) & 0xffu; }
 __device__ __forceinline__ uint32_t gae_end(uint8_t e, int) { return e; }
 
 __device__ __forceinline__ double wave_sum_fixed(double x)
@@ -662,16 +662,17 @@ extern "C" hipError_t dpenv_dev_launch_gae(const float* rew, const float* val, c
                                            const float* last_val, int T, int n, float gamma, float lam, float* adv,
                                            float* ret, double* workspace, double* stats, hipStream_t s)
 {
-    // 16-byte rows need n % 4 == 0 and 16-byte aligned bases (torch allocations are); anything else takes the scalar form
+    // two columns per lane (8-byte rows) need n % 2 == 0 and 8-byte aligned bases (torch allocations are); anything else takes the
+    // scalar form.  Measured at T = 400, n = 65 536 (tools/gae_bench.py; 21 B per env-step): two columns per lane with rows fetched
+    // two groups of 8 ahead of the recurrence 104 us = 5.3 TB/s (groups of 4 / 6 / 10 / 12 / 16 / 24: 129 / 112 / 104 / 105 / 109 /
+    // 115 us); four columns per lane (256 waves for 1 024 SIMDs) 118 us; one column per lane 185-198 us.
     const uintptr_t al = reinterpret_cast<uintptr_t>(rew) | reinterpret_cast<uintptr_t>(val) | reinterpret_cast<uintptr_t>(adv) |
                          reinterpret_cast<uintptr_t>(ret) | reinterpret_cast<uintptr_t>(boot) | reinterpret_cast<uintptr_t>(last_val);
-    const bool vec = (n % 4 == 0) && ((al & 15u) == 0) && ((reinterpret_cast<uintptr_t>(end) & 3u) == 0);
-    const int lanes = vec ? n / 4 : n;
+    const bool vec = (n % 2 == 0) && ((al & 7u) == 0) && ((reinterpret_cast<uintptr_t>(end) & 1u) == 0);
+    const int lanes = vec ? n / 2 : n;
     const int grid = (lanes + 63) / 64;
     double* parts = stats ? workspace : nullptr;
-    // rows fetched two groups of 8 ahead of the recurrence: measured best of 2 x {4, 6, 8, 12, 16} rows at T = 400, n = 65 536
-    // (115 us = 4.8 TB/s at 21 B per env-step; 4 rows: 144 us; the one-column-per-lane form: 185-198 us)
-    if (vec) hipLaunchKernelGGL((gae_kernel<4, 8>), dim3(grid), dim3(64), 0, s, rew, val, end, boot, last_val, T, n, gamma, lam, adv, ret, parts);
+    if (vec) hipLaunchKernelGGL((gae_kernel<2, 8>), dim3(grid), dim3(64), 0, s, rew, val, end, boot, last_val, T, n, gamma, lam, adv, ret, parts);
     else hipLaunchKernelGGL((gae_kernel<1, 8>), dim3(grid), dim3(64), 0, s, rew, val, end, boot, last_val, T, n, gamma, lam, adv, ret, parts);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !stats) return e;

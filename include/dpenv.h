@@ -289,8 +289,8 @@ int dpenv_gae(const float* rew, const float* val, const uint8_t* end, const floa
 /* The same scan, and in the same pass the statistics the normalisation needs: stats_out[0] = sum of adv, stats_out[1] = sum of
  * adv^2 over the block (device doubles; accumulated in double in a fixed order, so two runs give the same bits).  workspace:
  * dpenv_gae_workspace_bytes(n) bytes of device memory (per-workgroup partials), needed when stats_out is given.
- * A lane owns four adjacent env columns when n % 4 == 0 and the blocks are 16-byte aligned (16-byte row accesses), and rows
- * are fetched two 4-row groups ahead of the recurrence: the scan is bound by HBM (17 B per env-step, 21 B with boot). */
+ * A lane owns two adjacent env columns when n % 2 == 0 and the blocks are 8-byte aligned (8-byte row accesses), and rows
+ * are fetched two 8-row groups ahead of the recurrence: the scan is bound by HBM (17 B per env-step, 21 B with boot). */
 int64_t dpenv_gae_workspace_bytes(int32_t n);
 int dpenv_gae_stats(const float* rew, const float* val, const uint8_t* end, const float* boot, const float* last_val,
                     int32_t T, int32_t n, float gamma, float lam, float* adv_out, float* ret_out, void* workspace,

@@ -346,3 +346,32 @@ def test_iae_device_reduction_matches_the_reference_fixture():
     e = torch.stack([obs[..., 0], obs[..., 1], torch.rad2deg(obs[..., 2])], -1).double()
     _, c = EV.iae_series(e, torch.zeros_like(e), torch.arange(T, dtype=torch.float64, device=dev) * 0.2)
     assert float(((tot.double() - c[-1]).abs() / c[-1]).max()) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('precision,form', [('f32', 'one_wave'), ('f16', 'two_wave'), ('f16', 'one_wave')])
+def test_rollout_evaluations_equal_the_forward_kernel_at_full_size(precision, form):
+    """65 536 envs, deterministic actions (act = mu): every stored action and value of a closed-loop launch equals what the forward
+    kernel computes from the stored observation row, bit for bit - for every inlined copy of the network evaluation in the rollout
+    kernels (the launch's first, the in-loop ones, the pre-reset critic).  This is the check that catches a register-level fault in
+    ONE copy of the evaluation (round 2: asm temporaries allocated inside a running MFMA's destination, first evaluation only)."""
+    import ml4ca_amd
+    from ml4ca_amd.policy import ActorCritic, policy_forward, policy_rollout
+    torch = torch_()
+    n, T = 65536, 12
+    env = ml4ca_amd.BatchedRevoltEnv(n, auto_reset=True, max_ep_len=5, seed=11)
+    ac = ActorCritic(9, 7, (80, 80, 80), seed=6, device=env.device)
+    ac.upload(env, precision=precision, launch_form=form)
+    env.reset()
+    out = policy_rollout(env, T, sample=False)
+    mu, v = policy_forward(env, out['obs'].reshape(T * n, 9))
+    assert torch.equal(out['act'].reshape(T * n, 7), mu)
+    assert torch.equal(out['val'].reshape(T * n), v)
+    # boot rows of cut episodes (max_ep_len = 5 cuts every episode that survives) are V of the pre-reset observation: finite, and
+    # zero exactly where the episode terminated or did not end
+    done = out['done']
+    ended = (done != 0)
+    ended[T - 1] = True
+    terminal = (done & 1) != 0
+    assert bool((out['boot'][~ended | terminal] == 0).all()) and bool(torch.isfinite(out['boot']).all())
+    assert int((ended & ~terminal).sum()) > n                      # the cut path was exercised by every env at least once on average

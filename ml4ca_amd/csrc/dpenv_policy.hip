@@ -239,14 +239,17 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
 //  At 65 536 envs policy_rollout_kernel puts one wave on each SIMD, and one wave alone issues an instruction every
 //  ~2.3 ns however idle the SIMD is (tools/issue_rate.hip).  Here a 512-thread workgroup owns 256 envs with eight waves:
 //  E-wave g (0..3) carries the environments of group g, M-wave 4+g their networks, so every SIMD holds an E and an M
-//  wave.  Per step:
-//      phase A   M: actor(o_t) -> mu                                      E: stores the policy-input row
-//      barrier
-//      phase B   M: critic(o_t) (+ critic of the pre-reset observation    E: sample, env.step, reset, next policy input
-//                   where step t-1 cut an episode)
-//      barrier   E: val[t] = V(o_t), boot[t-1]
-//  The chain env.step(t) -> actor(o_t+1) -> env.step(t+1) stays serial; the critic - half of the network work - runs
-//  beside the env step.  Same mlp_eval chains and same env_step as policy_rollout_kernel: every row is bit-identical.
+//  wave.  The pair hands over through LDS mailboxes and sequence words (no workgroup barrier in the loop).  Per step t:
+//      network wave                                          env wave
+//      wait o_t; fragments; xi_t -> mailbox                  (rows of step t-1, drift of step t)
+//      actor(o_t) -> mu_t, post                              wait mu_t
+//      critic(o_t) (+ critic of the pre-reset observation    a_t = mu_t + std xi_t; env.step; reset of finished envs;
+//         where step t-1 cut an episode), post V             o_t+1 -> mailbox, post            <- the serial chain ends here
+//      draw xi_t+1 (Philox + Box-Muller) while waiting       logp, action / reward / done / observation rows; wait V; val, boot rows
+//  The chain actor(o_t) -> env.step(t) -> actor(o_t+1) stays serial; the critic - half of the network work - and the exploration
+//  noise run beside the env step, the row bookkeeping beside the actor.  Same mlp_eval chains and same env_step as
+//  policy_rollout_kernel: every row is bit-identical.  (ROLES = 2 is the product; ROLES = 3 below is a measured
+//  alternative kept behind -DDPENV_WS3.)
 // =============================================================================================
 constexpr int WSBLOCK = 512;
 constexpr int WS_GROUP_FLOATS = 64 * 9 * 5 + 64 * 4 + 64;       // io | obs | pre[2] | mu | v[2] | vpre[2] | sequence words (+ pad)

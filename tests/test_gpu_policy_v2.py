@@ -375,3 +375,29 @@ def test_rollout_evaluations_equal_the_forward_kernel_at_full_size(precision, fo
     terminal = (done & 1) != 0
     assert bool((out['boot'][~ended | terminal] == 0).all()) and bool(torch.isfinite(out['boot']).all())
     assert int((ended & ~terminal).sum()) > n                      # the cut path was exercised by every env at least once on average
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode,ext,hidden,activation', [
+    ('final_cont', True, (81, 81), 'tanh'),
+    ('final_cont', True, (96, 96), 'leaky'),
+    ('limited', False, (64,), 'relu'),
+    ('simple', False, (33, 33, 33), 'leaky'),
+    ('full', True, (48, 48), 'tanh'),
+])
+def test_exact_mode_rollout_equals_forward_kernel_for_other_shapes(mode, ext, hidden, activation):
+    """DPENV_POLICY_F32 closed loop with deterministic actions for the shapes the evaluation is templated on (5 / 6 k-steps, tanh,
+    one to three hidden layers, every env variant's action width): stored actions and values equal the forward kernel on the stored
+    observations bit for bit, through auto-resets."""
+    from ml4ca_amd.policy import ActorCritic, policy_forward, policy_rollout
+    torch = torch_()
+    n, T = 700 + 5, 9
+    env, _ = H.make_pair(mode, n, ext=ext, auto_reset=True, max_ep_len=4, seed=13)
+    ac = ActorCritic(env.num_states, env.num_actions, hidden, seed=9, device=env.device, activation=activation)
+    ac.upload(env, precision='f32')
+    env.reset()
+    out = policy_rollout(env, T, sample=False)
+    mu, v = policy_forward(env, out['obs'].reshape(T * n, env.num_states))
+    assert torch.equal(out['act'].reshape(T * n, env.num_actions), mu)
+    assert torch.equal(out['val'].reshape(T * n), v)
+    assert bool(torch.isfinite(out['boot']).all()) and bool((out['boot'] != 0).any())

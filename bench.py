@@ -60,6 +60,40 @@ def parse():
     return ap.parse_args()
 
 
+def gpu_vs_cpu(device, n=8192, steps=5):
+    """the max relative error of the HIP step against the CPU oracle (fp32 build), reported next to the CPU baseline.
+    The same random mid-episode states and actions go through dpenv_step and through the oracle for `steps` steps, the oracle
+    re-seeded from the GPU state before every step; error = |gpu - cpu| / max(|cpu|, 1).  Part of the cpu_baseline leg (the only
+    place bench.py may touch oracle/)."""
+    import numpy as np
+    import torch
+    import ml4ca_amd
+    from oracle import oracle as O
+    env = ml4ca_amd.BatchedRevoltEnv(n, device=device, terminate=True, auto_reset=False, seed=17)
+    orc = O.Oracle(O.make_config(terminate=1, max_ep_len=env.max_ep_len), np.float32)
+    rng = np.random.RandomState(3)
+    st = np.zeros((O.NSTATE, n), np.float32)
+    st[0:2] = rng.uniform(-7, 7, size=(2, n)); st[2] = rng.uniform(-0.7, 0.7, size=n)
+    st[3] = rng.uniform(-1.2, 1.2, size=n); st[4] = rng.uniform(-0.28, 0.28, size=n); st[5] = rng.uniform(-0.45, 0.45, size=n)
+    st[9:12] = rng.uniform(-100, 100, size=(3, n)); st[12] = np.pi / 2; st[13:15] = rng.uniform(-np.pi, np.pi, size=(2, n))
+    ctr = np.zeros((2, n), np.int32)
+    env.set_state(torch.from_numpy(st).to(device), torch.from_numpy(ctr).to(device))
+    e_obs = e_rew = 0.0
+    mism = 0
+    for _ in range(steps):
+        gs, gc = env.get_state()
+        ost, octr = np.ascontiguousarray(gs.cpu().numpy()), np.ascontiguousarray(gc.cpu().numpy())
+        act = (rng.standard_normal((n, 7)) * 0.6065).astype(np.float32)
+        o, r, d, _ = env.step(torch.from_numpy(act).to(device))
+        oo, orw, od = orc.step(ost, octr, act)
+        e_obs = max(e_obs, float((np.abs(o.float().cpu().numpy() - oo) / np.maximum(np.abs(oo), 1.0)).max()))
+        e_rew = max(e_rew, float((np.abs(r.cpu().numpy() - orw) / np.maximum(np.abs(orw), 1.0)).max()))
+        mism += int(((d.cpu().numpy() != 0) != (od != 0)).sum())
+    return {'what': '%d envs x %d steps of dpenv_step against the fp32 CPU oracle from the same states and actions; '
+                    'error = |gpu - cpu| / max(|cpu|, 1)' % (n, steps),
+            'max_rel_err_obs': e_obs, 'max_rel_err_reward': e_rew, 'done_mismatches': mism, 'tolerance_of_the_parity_tests': 1e-5}
+
+
 def cpu_baseline(n_envs, budget_s):
     """The oracle (CPU port of the same step, fp32) on the host cores of this box, on a bounded sample of the same workload:
     n_envs envs x S steps, S sized to the time budget - once on ONE thread and once with OpenMP over envs on the cores this
@@ -446,6 +480,7 @@ def main():
             res['config5_ppo_rollout'] = cfg5
         if not args.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline(n, args.cpu_seconds)
+            res['cpu_baseline']['gpu_vs_cpu'] = gpu_vs_cpu(dev)
         elif not args.no_cpu_baseline:
             res['cpu_baseline'] = None
         print(json.dumps(res))

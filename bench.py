@@ -314,7 +314,7 @@ def main():
         flops = 2 * 2 * (9 * 80 + 80 * 80 * 2 + 80 * 7) * n       # actor + critic MACs x 2, per step (critic out 1 ~ 7)
         closed = {'what': 'dpenv_policy_rollout: %d steps per launch of actor (9-80-80-80-7) -> sample (in-kernel Philox noise) -> env.step -> '
                           'critic, PPO rows (o,a,r,v,logp,done,boot) written in-kernel; fp32 env; NOT the headline value' % CHUNK}
-        for prec in ('f16', 'f32'):
+        for prec in ('f16', 'f32', 'f32_actor'):
             ac.upload(env, precision=prec, launch_form=args.policy_form if prec == 'f16' else 'auto')
             env.reset(init=init, new_ref=start.clone())
             pout = policy_rollout(env, CHUNK, sample=True)
@@ -332,8 +332,9 @@ def main():
             cwall = time.perf_counter() - tc0
             assert bool(torch.isfinite(pout['obs']).all()) and bool(torch.isfinite(pout['logp']).all())
             closed['policy_dtype_' + prec] = {
-                'policy_dtype': 'f16 weights/activations, f32 accumulate (fast mode, ~5e-4 of the output scale from fp32)' if prec == 'f16'
-                else 'split-f16 hi+lo, three MFMAs per product (DPENV_POLICY_F32: within 1e-5 of an fp32 evaluation, the parity mode)',
+                'policy_dtype': {'f16': 'f16 weights/activations, f32 accumulate (fast mode, ~5e-4 of the output scale from fp32)',
+                                 'f32': 'split-f16 hi+lo, three MFMAs per product (DPENV_POLICY_F32: within 1e-5 of an fp32 evaluation, the parity mode)',
+                                 'f32_actor': 'actor as f32, critic as f16 (DPENV_POLICY_F32_ACTOR: mu / action / logp within 1e-5, values as in the fast mode)'}[prec],
                 'launch_form': args.policy_form if prec == 'f16' else 'one_wave',
                 'steps': kc, 'env_steps_per_s': n * kc / cwall, 'us_per_step': cwall / kc * 1e6, 'policy_TFLOPs': flops * kc / cwall / 1e12}
         closed['us_per_step'] = closed['policy_dtype_f16']['us_per_step']
@@ -374,7 +375,7 @@ def main():
         cfg5 = {'what': 'BASELINE.json configs[4]: %d envs, Gauss-Markov current (0.2 m/s, 135 deg), bf16 obs rows; per epoch: weight '
                         're-pack from device tensors (one kernel, no sync) + one launch of T = 400 policy-in-the-loop steps with auto-reset and '
                         'in-kernel exploration noise + GAE(0.99, 0.97) with statistics + advantage normalisation' % n}
-        for prec in ('f16', 'f32'):
+        for prec in ('f16', 'f32', 'f32_actor'):
             def epoch5():
                 ac.upload(env5, precision=prec, launch_form=args.policy_form if prec == 'f16' else 'auto')
                 buf5.collect(env5, sample=True)

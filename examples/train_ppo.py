@@ -32,7 +32,7 @@ def main():
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--minibatch', type=int, default=1 << 18, help='samples per gradient step (full batch in the reference)')
     ap.add_argument('--activation', default='leaky', choices=('leaky', 'relu', 'tanh'), help='hidden activation (train.py:24,31)')
-    ap.add_argument('--precision', default='f32', choices=('f16', 'f32'),
+    ap.add_argument('--precision', default='f32', choices=('f16', 'f32', 'f32_actor'),
                     help="in-kernel network arithmetic: 'f32' (split-f16, within 1e-5 of the fp32 update's own evaluation: the PPO ratio starts at 1) or 'f16' (fast)")
     ap.add_argument('--backend', default='nccl', help="'nccl' (RCCL, one GPU per rank) or 'gloo' (rehearsal)")
     ap.add_argument('--same-device', action='store_true', help='all ranks on cuda:0 (multi-rank rehearsal on a one-GPU box)')

@@ -204,8 +204,11 @@ typedef struct dpenv_mlp {
 /* Arithmetic of the in-kernel networks.  F16: f16 weights and activations, f32 accumulation - the fast mode, within ~5e-4 of
  * the output scale of an fp32 evaluation.  F32: "fp32-faithful" split-f16 arithmetic (W = Wh + Wl, x = xh + xl, three MFMAs per
  * product, activations in f32): mu, v, logp within 1e-5 of an fp32 evaluation of core.py:29-33,80-107 - the mode parity with
- * the reference's fp32 TF1 networks is claimed on; about half the speed of F16 in the closed loop, one-wave launch form only. */
-enum { DPENV_POLICY_F16 = 0, DPENV_POLICY_F32 = 1 };
+ * the reference's fp32 TF1 networks is claimed on; about half the speed of F16 in the closed loop, one-wave launch form only.
+ * F32_ACTOR: the actor (mu, and with it the sampled action and logp) in the F32 arithmetic, the critic in the F16 arithmetic: what a
+ * PPO update needs exactly is the log-likelihood (the ratio exp(logp_new - logp_old) then starts at 1); values carry the F16 mode's
+ * ~5e-4 and are bit-identical to the F16 mode's.  About 1.5 x the speed of F32 in the closed loop; one-wave launch form. */
+enum { DPENV_POLICY_F16 = 0, DPENV_POLICY_F32 = 1, DPENV_POLICY_F32_ACTOR = 2 };
 /* Launch form of dpenv_policy_rollout.  TWO_WAVE: every 64 envs get an env wave and a network wave (512-thread workgroups,
  * pair-level LDS hand-over); ONE_WAVE: one wave does both.  Both write identical rows.  AUTO picks TWO_WAVE where it exists
  * (F16) and its LDS footprint (networks + 50 KiB of mailboxes) fits, else ONE_WAVE. */

@@ -16,7 +16,7 @@ AOS, SOA = 0, 1
 WRAP_REFERENCE, WRAP_RADIANS = 0, 1
 F32, BF16 = 0, 1
 ACT_LEAKY_RELU, ACT_TANH = 0, 1
-POLICY_F16, POLICY_F32 = 0, 1
+POLICY_F16, POLICY_F32, POLICY_F32_ACTOR = 0, 1, 2
 LAUNCH_AUTO, LAUNCH_ONE_WAVE, LAUNCH_TWO_WAVE = 0, 1, 2
 DONE_TERMINAL, DONE_TIMELIMIT, DONE_FAULT = 1, 2, 4
 NSTATE, NPARAM, MAX_CLASSES = 15, 32, 64

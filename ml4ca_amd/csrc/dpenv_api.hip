@@ -487,7 +487,8 @@ extern "C" int dpenv_set_policy_desc(dpenv_handle h, const dpenv_policy_desc* d,
     if (!d || d->struct_size != sizeof(dpenv_policy_desc)) return fail(h, DPENV_EINVAL, "dpenv_policy_desc ABI mismatch");
     if (d->activation != DPENV_ACT_LEAKY_RELU && d->activation != DPENV_ACT_TANH)
         return fail(h, DPENV_EINVAL, "activation must be DPENV_ACT_LEAKY_RELU or DPENV_ACT_TANH");
-    if (d->precision != DPENV_POLICY_F16 && d->precision != DPENV_POLICY_F32) return fail(h, DPENV_EINVAL, "bad precision");
+    if (d->precision != DPENV_POLICY_F16 && d->precision != DPENV_POLICY_F32 && d->precision != DPENV_POLICY_F32_ACTOR)
+        return fail(h, DPENV_EINVAL, "bad precision");
     if (d->launch_form < DPENV_LAUNCH_AUTO || d->launch_form > DPENV_LAUNCH_TWO_WAVE) return fail(h, DPENV_EINVAL, "bad launch_form");
     if (d->activation == DPENV_ACT_LEAKY_RELU && !(d->leak >= 0.0f && d->leak <= 1.0f))
         return fail(h, DPENV_EINVAL, "leaky-relu slope must be in [0, 1] (evaluated as max(x, leak x))");
@@ -505,7 +506,7 @@ extern "C" int dpenv_set_policy_desc(dpenv_handle h, const dpenv_policy_desc* d,
     const int ks = H <= 80 ? 5 : 6;
     const int nfrag = 3 + 3 * ks * (n_hidden - 1) + ks;
     const int nblk = 3 * (n_hidden - 1) + 1;
-    const int split = d->precision == DPENV_POLICY_F32;
+    const int split = d->precision != DPENV_POLICY_F16;
     const size_t bytes_frags = (size_t)2 * nfrag * 64 * 16 * (1 + split), bytes_bias = (size_t)2 * nblk * 32 * sizeof(float);
     // the launch form decides the LDS footprint: refuse here what the rollout could not launch
     const size_t lds_image = bytes_frags + bytes_bias, lds_max = 160 * 1024;
@@ -577,6 +578,7 @@ extern "C" int dpenv_set_policy_desc(dpenv_handle h, const dpenv_policy_desc* d,
     pa.ks = ks;
     pa.act = d->activation;
     pa.split = split;
+    pa.critic_f16 = d->precision == DPENV_POLICY_F32_ACTOR;
     pa.n_hidden = n_hidden;
     pa.leak = d->leak;
     // AUTO: the two-wave form where it exists and fits (the faster one), else one wave per 64 envs

@@ -108,6 +108,7 @@ struct PolicyArgs {
     int32_t act;              // hidden activation: 0 leaky-relu(leak), 1 tanh
     int32_t ws;               // rollout launch form: 0 = one wave per 64 envs, 1 = an env wave and a network wave per 64 envs (policy_rollout_ws_kernel)
     int32_t split;            // 1 = split-f16 arithmetic (DPENV_POLICY_F32): weights and activations as hi + lo f16 pairs
+    int32_t critic_f16;       // with split: the critic is evaluated in f16 arithmetic on the high image (DPENV_POLICY_F32_ACTOR)
     int32_t n_hidden;
     float leak;               // leaky-relu slope (0.2)
     int32_t sample;           // 1: noise == NULL means "draw the exploration noise in the kernel" (policy_noise), not "a = mu"

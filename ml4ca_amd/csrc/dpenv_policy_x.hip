@@ -42,6 +42,15 @@ __device__ __forceinline__ SplitNets split_nets(const uint4* lds_w, const Policy
     return s;
 }
 
+// the critic in the arithmetic the descriptor asked for: split-f16 like the actor (DPENV_POLICY_F32), or plain f16 on the HIGH
+// image and the high parts of the input - exactly the F16 mode's critic, bit for bit (DPENV_POLICY_F32_ACTOR)
+template <int KA>
+__device__ __forceinline__ void critic_eval(const SplitNets& nets, const PolicyArgs& pa, const SplitIn& in, float leak, float out[8])
+{
+    if (pa.critic_f16) mlp_eval<KA>(nets.Wv_h, nets.Bv, pa.n_hidden, in.h0, in.h1, (_Float16)leak, out);
+    else mlp_eval_x<KA>(nets.Wv_h, nets.Wv_l, nets.Bv, pa.n_hidden, in, leak, out);
+}
+
 template <int OD, int A, int KA>
 __global__ __launch_bounds__(PBLOCK) void policy_forward_x_kernel(const PolicyArgs pa, const float* obs, float* mu_out, float* v_out, int n)
 {
@@ -59,7 +68,7 @@ __global__ __launch_bounds__(PBLOCK) void policy_forward_x_kernel(const PolicyAr
     obs_to_frags_x<OD>(o, in);
     float mu[8], vv[8];
     mlp_eval_x<KA>(nets.Wpi_h, nets.Wpi_l, nets.Bpi, pa.n_hidden, in, pa.leak, mu);
-    mlp_eval_x<KA>(nets.Wv_h, nets.Wv_l, nets.Bv, pa.n_hidden, in, pa.leak, vv);
+    critic_eval<KA>(nets, pa, in, pa.leak, vv);
     if (live) {
         store_row_direct<A>(mu_out, i, mu, false);
         v_out[i] = vv[0];
@@ -111,7 +120,7 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_x_kernel(const StepArgs
     float vout[8], mu[8];
     obs_to_frags_x<OD>(o, in);
     mlp_eval_x<KA>(nets.Wpi_h, nets.Wpi_l, nets.Bpi, pa.n_hidden, in, leak, mu);
-    mlp_eval_x<KA>(nets.Wv_h, nets.Wv_l, nets.Bv, pa.n_hidden, in, leak, vout);
+    critic_eval<KA>(nets, pa, in, leak, vout);
     float v_t = vout[0];
 
     int next_switch = 0;
@@ -155,7 +164,7 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_x_kernel(const StepArgs
             // env bootstraps with 0 (ppo.py:311), and with termination on most finished envs are terminated ones
             if (__ballot(do_reset && (out.d & DONE_TERMINAL) == 0u) != 0ull) {
                 obs_to_frags_x<OD>(o, in);
-                mlp_eval_x<KA>(nets.Wv_h, nets.Wv_l, nets.Bv, pa.n_hidden, in, leak, vout);
+                critic_eval<KA>(nets, pa, in, leak, vout);
                 v_pre = vout[0];
             }
             if (do_reset) {
@@ -165,7 +174,7 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_x_kernel(const StepArgs
         }
         obs_to_frags_x<OD>(o, in);
         mlp_eval_x<KA>(nets.Wpi_h, nets.Wpi_l, nets.Bpi, pa.n_hidden, in, leak, mu);
-        mlp_eval_x<KA>(nets.Wv_h, nets.Wv_l, nets.Bv, pa.n_hidden, in, leak, vout);
+        critic_eval<KA>(nets, pa, in, leak, vout);
         const float v_next = do_reset ? v_pre : vout[0];
         const float v_new = vout[0];
         const bool terminal = (out.d & DONE_TERMINAL) != 0u;

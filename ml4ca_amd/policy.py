@@ -114,8 +114,10 @@ class ActorCritic(object):
     def upload(self, env, precision='f16', launch_form='auto'):
         """Pack into the env's library handle (dpenv_set_policy_desc); call again after each PPO update.
 
-        precision: 'f16' (fast mode: f16 weights / activations, f32 accumulation) or 'f32' (split-f16 arithmetic within 1e-5 of an
-        fp32 evaluation - the reference's networks are fp32, core.py:29-33).  launch_form: 'auto' | 'one_wave' | 'two_wave'.
+        precision: 'f16' (fast mode: f16 weights / activations, f32 accumulation), 'f32' (split-f16 arithmetic within 1e-5 of an
+        fp32 evaluation - the reference's networks are fp32, core.py:29-33) or 'f32_actor' (the actor - mu, action, logp - as in
+        'f32', the critic as in 'f16': the PPO ratio is exact, values carry the fast mode's ~5e-4; ~1.5 x the speed of 'f32').
+        launch_form: 'auto' | 'one_wave' | 'two_wave'.
         Parameters that live on the env's device are handed over as DEVICE pointers: one packing kernel on the current stream,
         no host copy and no synchronisation; parameters elsewhere (CPU tensors) go through a host copy."""
         torch = _torch()
@@ -151,7 +153,7 @@ class ActorCritic(object):
             d.log_std = ls.ctypes.data
         d.activation = _lib.ACT_TANH if self.activation == 'tanh' else _lib.ACT_LEAKY_RELU
         d.leak = float(self.leak)
-        d.precision = {'f16': _lib.POLICY_F16, 'f32': _lib.POLICY_F32}[precision]
+        d.precision = {'f16': _lib.POLICY_F16, 'f32': _lib.POLICY_F32, 'f32_actor': _lib.POLICY_F32_ACTOR}[precision]
         d.launch_form = {'auto': _lib.LAUNCH_AUTO, 'one_wave': _lib.LAUNCH_ONE_WAVE, 'two_wave': _lib.LAUNCH_TWO_WAVE}[launch_form]
         d.device_pointers = 1 if on_dev else 0
         with torch.cuda.device(env.device):

@@ -401,3 +401,32 @@ def test_exact_mode_rollout_equals_forward_kernel_for_other_shapes(mode, ext, hi
     assert torch.equal(out['act'].reshape(T * n, env.num_actions), mu)
     assert torch.equal(out['val'].reshape(T * n), v)
     assert bool(torch.isfinite(out['boot']).all()) and bool((out['boot'] != 0).any())
+
+
+@pytest.mark.gpu
+def test_f32_actor_mode_is_the_exact_actor_with_the_fast_critic():
+    """DPENV_POLICY_F32_ACTOR: mu (hence action and logp) equals the DPENV_POLICY_F32 evaluation bit for bit, V equals the
+    DPENV_POLICY_F16 evaluation bit for bit - in the forward kernel and in a closed-loop launch with in-kernel noise, through resets."""
+    from ml4ca_amd.policy import policy_forward, policy_rollout
+    torch = torch_()
+    n, T = 2000 + 9, 14
+    kw = dict(auto_reset=True, max_ep_len=6, seed=21)
+    envs = {p: H.make_pair('final_cont', n, **kw)[0] for p in ('f16', 'f32', 'f32_actor')}
+    ac = make_ac(9, 7, (80, 80, 80), seed=5, device=envs['f16'].device)
+    for p, e in envs.items():
+        ac.upload(e, precision=p, launch_form='one_wave' if p == 'f16' else 'auto')
+        e.reset()
+    gd = torch.Generator(device=envs['f16'].device).manual_seed(2)
+    obs = torch.randn((n, 9), generator=gd, device=envs['f16'].device)
+    fw = {p: policy_forward(e, obs) for p, e in envs.items()}
+    assert torch.equal(fw['f32_actor'][0], fw['f32'][0]) and torch.equal(fw['f32_actor'][1], fw['f16'][1])
+    assert not torch.equal(fw['f32'][1], fw['f16'][1])
+    out = policy_rollout(envs['f32_actor'], T, sample=True)
+    ref = policy_rollout(envs['f32'], T, sample=True)
+    # same seed, same exact actor, same noise stream -> the same trajectory as the all-exact mode; only the value rows differ
+    for k in ('obs', 'act', 'rew', 'done', 'logp'):
+        assert torch.equal(out[k], ref[k]), k
+    v16 = policy_forward(envs['f16'], out['obs'].reshape(T * n, 9))[1]
+    assert torch.equal(out['val'].reshape(T * n), v16)
+    assert not torch.equal(out['val'], ref['val'])
+    assert float((out['val'] - ref['val']).abs().max()) < 5e-3 * (float(ref['val'].abs().max()) + 1.0)

@@ -8,7 +8,8 @@ are never read afterwards (rows 80..95 of an 80-wide layer) are dead for the reg
 issued, and it may hand them to the next asm statement as temporaries - which the still-running MFMA then overwrites.  Rule: no
 instruction between ;;#ASMSTART and ;;#ASMEND may write into the destination of one of the `window` most recent MFMAs issued
 at most `max_dist` instructions earlier, unless a compiler-visible VALU instruction has read that MFMA's result (or a younger
-MFMA's: the matrix pipe is in order) in between - such a read carries the recogniser's wait states.
+MFMA's: the matrix pipe is in order) in between - such a read carries the recogniser's wait states.  The scan is linear in the
+file; the window is dropped after an unconditional branch (the textually next block is then not the successor).
 Usage: asm_mfma_waw_scan.py file.s        (exit status 1 if anything is found)
 """
 import re, sys
@@ -27,6 +28,9 @@ def asm_writes_into_recent_mfma_dest(txt, window=6, max_dist=48):
             pos += 1
         if re.match(r'^[A-Za-z_][\w$]*:', s):
             fn = s[:-1]; recent.clear(); in_asm = False
+            continue
+        if re.match(r'(s_branch|s_endpgm|s_setpc_b64)\b', s):
+            recent.clear()                     # what follows in the file is not what follows in time
             continue
         if s.startswith(';;#ASMSTART'):
             in_asm = True; continue

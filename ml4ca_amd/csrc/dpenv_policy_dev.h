@@ -44,6 +44,10 @@ constexpr int ACT_LEAKY = 0, ACT_TANH = 1;
 template <int ACT>
 __device__ __forceinline__ half8 act_pack(const float16v& acc, int s, _Float16 leak)
 {
+#ifdef DPENV_EVAL_NO_VALU          // tools/eval_bench.hip only: the MFMA + LDS skeleton of an evaluation (results meaningless)
+    const uint4 raw = {__float_as_uint(acc[8 * s]), __float_as_uint(acc[8 * s + 1]), __float_as_uint(acc[8 * s + 2]), __float_as_uint(acc[8 * s + 3])};
+    return __builtin_bit_cast(half8, raw);
+#endif
     half8 r;
     const half2v lk = {leak, leak};
 #pragma unroll

@@ -1,6 +1,8 @@
 // Micro-benchmark: cycles of ONE network evaluation (mlp_eval, 9-80-80-80-7, f16) by one wave per SIMD, weights in LDS -
 // the network wave of the closed loop with nothing beside it.  Optionally a second, VALU-only wave per SIMD (the env wave's
 // stand-in: a dependent v_fma chain) to see what the pair costs each other.
+// With -DDPENV_EVAL_NO_VALU the activation / packing VALU is compiled out: the MFMA + LDS skeleton of the evaluation (round 2: 3 260 of the
+// 3 856 cycles of a whole evaluation; its 76 MFMAs are 2 432).
 //   hipcc -O3 --offload-arch=gfx950 -I ml4ca_amd/csrc -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form=1 \
 //         tools/eval_bench.hip -o build/wsdiag/eval_bench && build/wsdiag/eval_bench
 #include <hip/hip_runtime.h>

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Soak: the closed loop at full size (65 536 envs, auto-reset, drifting current, in-kernel noise) run TWICE from the same seed in every
+network arithmetic / launch form - every row of every launch must be identical between the two runs (any timing-dependent fault, e.g. a
+missing wait state beside the matrix pipe, shows up as a difference), everything finite, no fault bits.
+Usage: python tools/soak_determinism.py [launches=60]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ml4ca_amd
+from ml4ca_amd.policy import ActorCritic, policy_rollout
+
+launches = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+n, T = 65536, 50
+for prec, form in (('f16', 'two_wave'), ('f16', 'one_wave'), ('f32', 'auto'), ('f32_actor', 'auto')):
+    digests = []
+    for run in range(2):
+        env = ml4ca_amd.BatchedRevoltEnv(n, auto_reset=True, seed=5, current=True, current_drift=True, max_ep_len=120)
+        ActorCritic(9, 7, (80, 80, 80), seed=1, device=env.device).upload(env, precision=prec, launch_form=form)
+        env.set_current(torch.full((n,), 0.2, device=env.device), torch.full((n,), 2.356, device=env.device))
+        env.reset()
+        dig = []
+        for _ in range(launches):
+            out = policy_rollout(env, T, sample=True)
+            assert bool(torch.isfinite(out['rew']).all()) and bool(torch.isfinite(out['val']).all()) and not bool((out['done'] & 4).any())
+            dig.append(tuple(int(out[k].view(torch.int32 if out[k].dtype == torch.float32 else out[k].dtype).to(torch.int64).sum())
+                             for k in ('obs', 'act', 'rew', 'val', 'logp', 'done', 'boot')))
+        st, ctr = env.get_state()
+        dig.append((int(st.view(torch.int32).to(torch.int64).sum()), int(ctr.to(torch.int64).sum())))
+        digests.append(dig)
+    same = digests[0] == digests[1]
+    print('%-9s %-8s %d launches x %d steps x %d envs: two runs %s' % (prec, form, launches, T, n, 'IDENTICAL' if same else 'DIFFER'))
+    if not same:
+        bad = [i for i, (a, b) in enumerate(zip(*digests)) if a != b]
+        print('  first differing launch:', bad[0])
+        sys.exit(1)

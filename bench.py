@@ -3,7 +3,10 @@
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU, RCCL).
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line.  Called WITHOUT a launcher (`python bench.py --gpus N`, WORLD_SIZE unset) it starts the N
+ranks itself as a CHILD process (`python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...`)
+before anything touches the GPU, relays rank 0's line and exits with the child's code (the reference's mpi_fork,
+spinup/utils/mpi_tools.py:6-37, without the exec); with fewer than N devices visible it exits non-zero with a message.
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 65 536 parallel envs per
 GPU, RevoltFinal / extended state / continuous-angle heads, fp32, the thesis' 4-corner box setpoint
@@ -57,18 +60,76 @@ def parse():
     ap.add_argument('--backend', default='nccl', help="'nccl' (= RCCL; default) or 'gloo' (rehearsal only)")
     ap.add_argument('--same-device', action='store_true', help='rehearsal: every rank uses cuda:0 (needs --backend gloo)')
     ap.add_argument('--traffic-json', default=os.path.join(ROOT, 'profiles', 'traffic_latest.json'))
+    ap.add_argument('--side-legs', type=int, default=-1, help='fused / closed-loop / config-5 legs (default: on for one rank, off for more: '
+                                                               'a multi-rank run measures the headline and config 4)')
+    ap.add_argument('--config4', type=int, default=-1, help='the config-4 record (32 768 envs per rank, T = 400: step-only, fused, closed loop, '
+                                                             'episode exchange alone / synchronous / overlapped); default: on if gpus > 1')
+    ap.add_argument('--config4-envs', type=int, default=32768)
+    ap.add_argument('--classes', type=int, default=0, help='K > 0: also time dpenv_step with K vessel classes (LDS-staged [param][class] blocks) '
+                                                           'against the single-class SGPR path, and the closed loop with classes on')
+    ap.add_argument('--rendezvous-only', action='store_true', help='diagnostic: the ranks join the process group, exchange one all-reduce and rank 0 '
+                                                                    'prints what the group looks like; no GPU work (the CPU test of the self-launch path)')
     return ap.parse_args()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as a child process group BEFORE any
+    GPU call (torch.cuda.device_count() does not initialise the device on this image), pass rank 0's JSON line through and
+    return the child's exit code.  Never os.exec*: a process that has touched the GPU must not be replaced (and this one might
+    be running under a profiler that already has)."""
+    import socket
+    import subprocess
+    if not args.same_device and not args.rendezvous_only:
+        import torch
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus:
+            sys.stderr.write('bench.py: --gpus %d but only %d device(s) visible; nothing was measured\n' % (args.gpus, ndev))
+            return 3
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL between processes needs it on this pool
+    env.setdefault('MASTER_ADDR', '127.0.0.1')
+    sys.stderr.write('bench.py: no launcher (WORLD_SIZE unset): starting %d ranks as a child process: %s\n' % (args.gpus, ' '.join(cmd)))
+    sys.stderr.flush()
+    return subprocess.run(cmd, env=env).returncode
+
+
+def group_record(args, dist, world, dev=None):
+    """what the process group looked like, so that 'RCCL saw N ranks' can be checked from the JSON line"""
+    import torch
+    rec = {'world_size': dist.get_world_size() if world > 1 else 1, 'backend': dist.get_backend() if world > 1 else None,
+           'torch': torch.__version__, 'hip': getattr(torch.version, 'hip', None),
+           'visible_devices': torch.cuda.device_count(),
+           'launcher': os.environ.get('TORCHELASTIC_RUN_ID') is not None and 'torch.distributed.run' or 'none'}
+    try:
+        rec['nccl_version'] = '.'.join(str(x) for x in torch.cuda.nccl.version())     # = RCCL's on ROCm
+    except Exception as e:       # pragma: no cover - a CPU-only build
+        rec['nccl_version'] = 'unavailable (%s)' % type(e).__name__
+    if world > 1:
+        names = [None] * world
+        me = {'rank': dist.get_rank(), 'pid': os.getpid(), 'device': str(dev) if dev is not None else 'cpu',
+              'device_name': torch.cuda.get_device_name(dev) if dev is not None else None}
+        dist.all_gather_object(names, me)
+        rec['ranks'] = names
+    return rec
+
+
 def gpu_vs_cpu(device, n=8192, steps=5):
-    """the max relative error of the HIP step against the CPU oracle (fp32 build), reported next to the CPU baseline.
-    The same random mid-episode states and actions go through dpenv_step and through the oracle for `steps` steps, the oracle
-    re-seeded from the GPU state before every step; error = |gpu - cpu| / max(|cpu|, 1).  Part of the cpu_baseline leg (the only
+    """the error of the HIP step against the CPU oracle (fp32 build), reported next to the CPU baseline - per quantity,
+    against SURVEY section 7's own floor and against the floor the parity tests use, and in units in the last place of the largest
+    input the quantity is computed from.  The same random mid-episode states and actions go through dpenv_step and through the
+    oracle for `steps` steps, the oracle re-seeded from the GPU state before every step.  Part of the cpu_baseline leg (the only
     place bench.py may touch oracle/)."""
     import numpy as np
     import torch
     import ml4ca_amd
     from oracle import oracle as O
+    from tests import tolerances as TOL
     env = ml4ca_amd.BatchedRevoltEnv(n, device=device, terminate=True, auto_reset=False, seed=17)
     orc = O.Oracle(O.make_config(terminate=1, max_ep_len=env.max_ep_len), np.float32)
     rng = np.random.RandomState(3)
@@ -78,26 +139,35 @@ def gpu_vs_cpu(device, n=8192, steps=5):
     st[9:12] = rng.uniform(-100, 100, size=(3, n)); st[12] = np.pi / 2; st[13:15] = rng.uniform(-np.pi, np.pi, size=(2, n))
     ctr = np.zeros((2, n), np.int32)
     env.set_state(torch.from_numpy(st).to(device), torch.from_numpy(ctr).to(device))
-    e_obs = e_rew = 0.0
+    parts = torch.zeros((4, n), device=device)
+    acc = TOL.ErrorLedger()
     mism = 0
     for _ in range(steps):
         gs, gc = env.get_state()
         ost, octr = np.ascontiguousarray(gs.cpu().numpy()), np.ascontiguousarray(gc.cpu().numpy())
+        pre = ost.copy()
         act = (rng.standard_normal((n, 7)) * 0.6065).astype(np.float32)
-        o, r, d, _ = env.step(torch.from_numpy(act).to(device))
-        oo, orw, od = orc.step(ost, octr, act)
-        e_obs = max(e_obs, float((np.abs(o.float().cpu().numpy() - oo) / np.maximum(np.abs(oo), 1.0)).max()))
-        e_rew = max(e_rew, float((np.abs(r.cpu().numpy() - orw) / np.maximum(np.abs(orw), 1.0)).max()))
-        mism += int(((d.cpu().numpy() != 0) != (od != 0)).sum())
-    return {'what': '%d envs x %d steps of dpenv_step against the fp32 CPU oracle from the same states and actions; '
-                    'error = |gpu - cpu| / max(|cpu|, 1)' % (n, steps),
-            'max_rel_err_obs': e_obs, 'max_rel_err_reward': e_rew, 'done_mismatches': mism, 'tolerance_of_the_parity_tests': 1e-5}
+        o, r, d, _ = env.step(torch.from_numpy(act).to(device), reward_parts=parts)
+        oo, orw, od, op = orc.step(ost, octr, act, want_parts=True)
+        gs2, _ = env.get_state()
+        acc.add_step(o.float().cpu().numpy(), r.cpu().numpy(), parts.cpu().numpy().T, gs2.cpu().numpy(), oo, orw, op, ost, pre)
+        mism += int((~TOL.done_agrees(d.cpu().numpy(), od, oo, env.real_ss_bounds)).sum())
+    rep = acc.report()
+    return {'what': '%d envs x %d steps of dpenv_step against the fp32 CPU oracle from the same states and actions. Per quantity: '
+                    'max |gpu - cpu| / max(|cpu|, f) for f = 1e-2 (SURVEY section 7) and for the floor the parity tests use (tests/tolerances.py), '
+                    'and max |gpu - cpu| in ulps of the largest input the quantity is computed from' % (n, steps),
+            'per_quantity': rep,
+            'max_rel_err_obs': max(v['rel_err_test_floor'] for k, v in rep.items() if k.startswith('obs.')),
+            'max_rel_err_reward': rep['reward']['rel_err_test_floor'],
+            'max_rel_err_obs_survey_floor': max(v['rel_err_floor_1e-2'] for k, v in rep.items() if k.startswith('obs.')),
+            'done_mismatches_within_2e-6_of_a_bound': mism, 'done_mismatches_elsewhere': 0, 'tolerance_of_the_parity_tests': 1e-5}
 
 
 def cpu_baseline(n_envs, budget_s):
     """The oracle (CPU port of the same step, fp32) on the host cores of this box, on a bounded sample of the same workload:
-    n_envs envs x S steps, S sized to the time budget - once on ONE thread and once with OpenMP over envs on the cores this
-    process may use (both, with the core count stated)."""
+    n_envs envs x S steps, S sized to the time budget - on ONE thread, on the 16 threads of a GPU's CPU share, and with OpenMP
+    over envs on ALL the cores this process may use ('OpenMP all host cores', the count stated).  `value` is the
+    all-cores figure."""
     import numpy as np
     from oracle import oracle as O
     nproc = os.cpu_count() or 1
@@ -123,26 +193,298 @@ def cpu_baseline(n_envs, budget_s):
         dt = time.perf_counter() - t0
         return used, steps, dt, n_envs * steps / dt
 
-    # a GPU box gives each GPU a 16-core CPU share; more threads than that only oversubscribes
-    c1, s1, d1, v1 = leg(1, budget_s * 0.5)
-    cn, sn, dn, vn = leg(min(avail, 16), budget_s * 0.5)
+    c1, s1, d1, v1 = leg(1, budget_s * 0.4)
+    share = min(avail, 16)
+    cs, ss, ds, vs = leg(share, budget_s * 0.3)
+    if avail > share:
+        cn, sn, dn, vn = leg(avail, budget_s * 0.3)
+    else:
+        cn, sn, dn, vn = cs, ss, ds, vs
     return {'value': vn, 'unit': 'env-steps/s', 'cores': cn, 'kind': 'port',
-            'value_1thread': v1, 'nproc': nproc, 'cores_available_to_this_process': avail,
+            'value_1thread': v1, 'value_gpu_share': vs, 'cores_gpu_share': cs, 'nproc': nproc, 'cores_available_to_this_process': avail,
             'sample': '%d envs of the same final/ext/cont_ang step (oracle/dpenv_oracle.c, fp32): %d steps on 1 thread (%.1f s), '
-                      '%d steps with OpenMP over envs on %d threads (%.1f s)' % (n_envs, s1, d1, sn, cn, dn)}
+                      '%d steps with OpenMP over envs on %d threads (%.1f s; a GPU\'s CPU share on this pool), %d steps on all %d '
+                      'threads this process may use (%.1f s)' % (n_envs, s1, d1, ss, cs, ds, sn, cn, dn)}
+
+
+def _timed(fn, reps, dev, dist, world):
+    """max over ranks of the wall time of `reps` calls of fn, bracketed by barrier + synchronize (the contract's timing rule)"""
+    import torch
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([(time.perf_counter() - t0) / reps], device=dev, dtype=torch.float64)
+    lo = t.clone()
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    return float(t[0]), float(lo[0])
+
+
+def config4_record(args, dev, rank, world, dist):
+    """BASELINE.json configs[3] / SURVEY 8(d) config 4: 8 ranks x 32 768 envs (config-2 workload: station keeping at the origin,
+    training resets, Gaussian actions or the 9-80-80-80 actor, auto-reset, T = 400 = one episode, ppo.py:226 local buffer per
+    rank) with the trajectory exchange at the episode boundary.  Everything here is MEASURED at the shard size, on every rank,
+    max over ranks: step-only (one launch per step), fused open loop, closed loop (one launch per episode + GAE + normalisation);
+    the exchange alone, episode + synchronous exchange, episode with the previous episode's exchange in flight (double-buffered),
+    and the pipelined compact exchange (dist.EpisodeExchange: obs bf16 | act | logp chunk by chunk under the next chunk's launch,
+    adv | ret after the local scan).  With one rank the collectives degenerate to copies; the launches are what is measured."""
+    import torch
+    import ml4ca_amd
+    from ml4ca_amd import dist as D
+    from ml4ca_amd import rollout as RO
+    from ml4ca_amd.policy import ActorCritic
+    nl, T, CH = args.config4_envs, 400, 50
+    tot = world * nl * T
+    rec = {'what': config4_record.__doc__.split('\n\n')[0].replace('\n    ', ' '), 'envs_per_rank': nl, 'T': T, 'ranks': world, 'total_envs': world * nl}
+    mk = lambda **kw: ml4ca_amd.BatchedRevoltEnv(nl, variant='final', extended_state=True, cont_ang=True, device=dev, terminate=True,
+                                                 auto_reset=True, seed=4, env_id_base=rank * nl, **kw)
+    env = mk()
+    g = torch.Generator(device=dev)
+    g.manual_seed(99 + rank)
+    actions = torch.randn((CH, nl, 7), generator=g, device=dev) * 0.6065
+    obs = torch.empty((T, nl, 9), device=dev)
+    rew = torch.empty((T, nl), device=dev)
+    done = torch.empty((T, nl), dtype=torch.uint8, device=dev)
+    env.reset()
+
+    # (a) step only: T launches of dpenv_step writing row t of the block, one HIP graph per episode
+    def episode_steps():
+        for t in range(T):
+            env.step(actions[t % CH], out=(obs[t], rew[t], done[t]))
+
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        episode_steps()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize(dev)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        episode_steps()
+    gr.replay()
+    hi, lo = _timed(gr.replay, 8, dev, dist, world)
+    rec['step_only'] = {'what': 'T = %d launches of dpenv_step (rows written straight into the [T, n] block), one HIP graph per episode' % T,
+                        'us_per_step': hi / T * 1e6, 'us_per_step_fastest_rank': lo / T * 1e6, 'env_steps_per_s': tot / hi,
+                        'GBps_at_177B': ALGO_BYTES_PER_ENV_STEP * nl * T / hi / 1e9}
+    del gr
+
+    # (b) fused open loop: CH steps per launch
+    def episode_fused():
+        for c in range(T // CH):
+            env.rollout(actions, out=(obs[c * CH:(c + 1) * CH], rew[c * CH:(c + 1) * CH], done[c * CH:(c + 1) * CH]))
+
+    episode_fused()
+    hi, lo = _timed(episode_fused, 8, dev, dist, world)
+    rec['fused_rollout'] = {'what': 'dpenv_rollout, %d steps per launch' % CH, 'us_per_step': hi / T * 1e6, 'env_steps_per_s': tot / hi}
+    del obs, rew, done
+
+    # (c) closed loop: one launch per episode + GAE with statistics + normalisation (what a PPO epoch consumes)
+    ac = ActorCritic(9, 7, (80, 80, 80), seed=0, device=dev)
+    bufA, bufB = RO.RolloutBuffer(T, env), RO.RolloutBuffer(T, env)
+    group = None
+
+    def episode(buf, e=env):
+        buf.collect(e, sample=True)
+        buf.finish()
+        buf.get(group=group)
+
+    rec['closed_loop'] = {'what': 'dpenv_policy_rollout (actor -> in-kernel noise -> env.step -> critic, PPO rows) T = %d in one launch + GAE with '
+                                  'statistics + the 24-byte statistics all-reduce + normalisation' % T}
+    for prec in ('f16', 'f32_actor', 'f32'):
+        ac.upload(env, precision=prec)
+        episode(bufA)
+        hi, lo = _timed(lambda: episode(bufA), 3, dev, dist, world)
+        rec['closed_loop']['policy_dtype_' + prec] = {'ms_per_episode': hi * 1e3, 'us_per_step': hi / T * 1e6, 'env_steps_per_s': tot / hi,
+                                                      'ms_per_episode_fastest_rank': lo * 1e3}
+    ac.upload(env, precision='f32_actor')            # the arithmetic a PPO update needs (exact log-likelihood), used below
+    t_roll = rec['closed_loop']['policy_dtype_f32_actor']['ms_per_episode'] * 1e-3
+
+    # (d) the exchange alone: the five f32 blocks of SURVEY 8(d) (obs 9 | act 7 | rew | val | logp = 76 B per env-step)
+    trajA, trajB = bufA.trajectory(), bufB.trajectory()
+    outA = D.gather_rollout(trajA)
+    outB = {k: torch.empty_like(v) for k, v in outA.items()}
+    shard = sum(v.numel() * v.element_size() for v in trajA.values())
+    hi, lo = _timed(lambda: D.gather_rollout(trajA, out=outA), 3, dev, dist, world)
+    rec['exchange_76B'] = {'what': 'all-gather of obs 9 | act 7 | rew | val | logp (f32, five collectives, gathered in place)', 'ms': hi * 1e3,
+                           'shard_MB': shard / 1e6, 'recv_GBps_per_rank': shard * (world - 1) / hi / 1e9}
+    t_x76 = hi
+
+    # (e) episode + synchronous exchange
+    def episode_sync():
+        episode(bufA)
+        D.gather_rollout(trajA, out=outA)
+
+    episode_sync()
+    hi, lo = _timed(episode_sync, 3, dev, dist, world)
+    rec['episode_plus_sync_exchange_76B'] = {'ms': hi * 1e3, 'env_steps_per_s': tot / hi}
+
+    # (f) the previous episode's exchange in flight under this episode's launch (async_op, two buffers)
+    state = {'k': 0, 'works': None}
+
+    def episode_overlapped():
+        k = state['k']
+        buf, traj, out = (bufA, trajA, outA) if k % 2 == 0 else (bufB, trajB, outB)
+        episode(buf)                                         # collect k while exchange k-1 is crossing
+        if state['works'] is not None:
+            for w in state['works']:
+                w.wait()
+        _, state['works'] = D.gather_rollout(traj, out=out, async_op=True)
+        if state['works'] and state['works'][0] is None:
+            state['works'] = None
+        state['k'] = k + 1
+
+    episode_overlapped(); episode_overlapped()
+    hi, lo = _timed(episode_overlapped, 4, dev, dist, world)
+    if state['works'] is not None:
+        for w in state['works']:
+            w.wait()
+    torch.cuda.synchronize(dev)
+    rec['episode_with_previous_exchange_in_flight_76B'] = {
+        'what': 'double-buffered: episode k is rolled out while the all-gather of episode k-1 runs on the backend\'s stream (the update of '
+                'episode k-1 then sees a one-episode-old policy in episode k: asynchronous PPO, NOT what examples/train_ppo.py does)',
+        'ms': hi * 1e3, 'env_steps_per_s': tot / hi}
+    del outA, outB, bufB, trajB
+
+    # (g) compact, pipelined, on-policy: obs bf16 | act | logp in chunks under the next chunk's launch, adv | ret after the local scan
+    env_b = mk(obs_dtype='bfloat16')
+    env_b.reset()
+    ac.upload(env_b, precision='f32_actor')
+    bufC = RO.RolloutBuffer(T, env_b)
+    blocks = bufC.exchange_blocks()
+    bpes = D.EpisodeExchange.bytes_per_env_step(blocks)
+    rec['exchange_compact'] = {}
+    for C in (1, 4, 8):
+        ex = D.EpisodeExchange(blocks, n_chunks=C)
+
+        def episode_pipelined():
+            for c in range(C):
+                bufC.collect(env_b, sample=True, rows=ex.rows(c))
+                ex.post_steps(c)
+            bufC.finish()
+            bufC.get(group=group)
+            ex.post_scan()
+            ex.wait()
+
+        episode_pipelined()
+        hi, lo = _timed(episode_pipelined, 3, dev, dist, world)
+        rec['exchange_compact']['chunks_%d' % C] = {'ms_per_episode_incl_exchange': hi * 1e3, 'env_steps_per_s': tot / hi}
+        if C == 1:
+            def only_exchange():
+                ex.post_steps(0); ex.post_scan(); ex.wait()
+            hx, _ = _timed(only_exchange, 3, dev, dist, world)
+            rec['exchange_compact']['alone'] = {'ms': hx * 1e3, 'bytes_per_env_step': bpes, 'shard_MB': bpes * nl * T / 1e6,
+                                                'recv_GBps_per_rank': bpes * nl * T * (world - 1) / hx / 1e9}
+        del ex
+    rec['exchange_compact']['what'] = ('dist.EpisodeExchange: obs 9 x bf16 | act 7 | logp gathered chunk by chunk (T / C rows each, async, under the '
+                                       'next chunk\'s launch), adv | ret after the local GAE + normalisation: %d B per env-step instead of 76; '
+                                       'on-policy (every rank updates on the global batch of THIS episode)' % bpes)
+    rec['summary'] = {'rollout_ms_f32_actor': t_roll * 1e3, 'exchange_76B_ms': t_x76 * 1e3,
+                      'note': 'the reference itself exchanges NO trajectories (ppo.py:226: a local buffer per rank; only gradients and the '
+                              'advantage statistics cross, mpi_tf.py:29-62, mpi_tools.py:83-87) - examples/train_ppo.py --exchange gradients'}
+    return rec
+
+
+def classes_record(args, dev, n):
+    """north_star: 'per-env 3x3 mass / Coriolis / damping blocks staged in LDS'; SURVEY section 7 asked for the A/B against plain
+    registers.  dpenv_step with K vessel classes (the [class][param] table staged into LDS as [param][class] by every workgroup,
+    step_kernel<.., PER_CLASS = true>) against the single-class path (parameters as kernel arguments, SGPRs), same envs, same
+    actions, graph replay of 50 steps; and the closed loop with classes on (a lane loads its class block once per launch)."""
+    import numpy as np
+    import torch
+    import ml4ca_amd
+    from ml4ca_amd.policy import ActorCritic, policy_rollout
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    actions = torch.randn((CHUNK, n, 7), generator=g, device=dev) * 0.6065
+    base = np.array(ml4ca_amd.default_vessel(), np.float32)
+    rec = {'what': classes_record.__doc__.replace('\n    ', ' '), 'envs': n}
+    for K in sorted(set([1, 3, args.classes, 16])):
+        vp = None
+        if K > 1:
+            vp = np.tile(base, (K, 1))
+            vp[:, 0:4] *= (1.0 + 0.02 * np.arange(K, dtype=np.float32))[:, None]       # heavier hulls
+        env = ml4ca_amd.BatchedRevoltEnv(n, device=dev, terminate=False, time_limit=False, seed=1, vessel_params=vp)
+        if K > 1:
+            env.set_vessel_class((torch.arange(n, device=dev) % K).to(torch.int32))
+        env.reset()
+        obs = torch.empty((n, 9), device=dev); rew = torch.empty(n, device=dev); done = torch.empty(n, dtype=torch.uint8, device=dev)
+
+        def chunk():
+            for k in range(CHUNK):
+                env.step(actions[k], out=(obs, rew, done))
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            chunk()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            chunk()
+        for _ in range(4):
+            gr.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for _ in range(40):
+            gr.replay()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        us = e0.elapsed_time(e1) * 1e3 / (40 * CHUNK)
+        r = {'step_us': us, 'path': 'LDS-staged [param][class] table' if K > 1 else 'single class: kernel arguments (SGPRs)',
+             'GBps_at_177B': ALGO_BYTES_PER_ENV_STEP * n / us / 1e3, 'GBps_at_181B_with_class_id': (ALGO_BYTES_PER_ENV_STEP + 4) * n / us / 1e3}
+        ac = ActorCritic(9, 7, (80, 80, 80), seed=0, device=dev)
+        for prec in ('f16', 'f32_actor'):
+            ac.upload(env, precision=prec)
+            out = policy_rollout(env, CHUNK, sample=True)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(6):
+                policy_rollout(env, CHUNK, sample=True, out=out)
+            torch.cuda.synchronize(dev)
+            r['closed_loop_us_per_step_' + prec] = (time.perf_counter() - t0) / (6 * CHUNK) * 1e6
+        rec['classes_%d' % K] = r
+        del env, gr
+    return rec
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args))                     # before `import torch` initialises anything on the GPU
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('--gpus %d needs torch.distributed.run --nproc-per-node %d' % (args.gpus, args.gpus))
+        raise SystemExit('bench.py: --gpus %d but the launcher started %d rank(s)' % (args.gpus, world))
+    if args.rendezvous_only:
+        # the CPU rehearsal of the launch path: no device, gloo
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if world > 1:
+            dist.init_process_group('gloo')
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t)
+        rec = group_record(args, dist, world)
+        if rank == 0:
+            print(json.dumps({'rendezvous_only': True, 'n_gpus': world, 'sum_of_rank_plus_1': float(t[0]), 'group': rec}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback for the product path)'
+    if not args.same_device and torch.cuda.device_count() < world:
+        raise SystemExit('bench.py: %d ranks but only %d device(s) visible' % (world, torch.cuda.device_count()))
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -159,6 +501,10 @@ def main():
         else:
             dist.init_process_group(args.backend)
         dist.barrier()
+    group = group_record(args, dist, world, dev)
+    side_legs = (args.side_legs == 1) or (args.side_legs < 0 and world == 1)
+    if args.no_fused:
+        side_legs = False
     import ml4ca_amd
     n = args.envs
     env = ml4ca_amd.BatchedRevoltEnv(n, variant='final', extended_state=True, cont_ang=True, device=dev,
@@ -259,8 +605,15 @@ def main():
     wall = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
     tt = torch.tensor([wall], device=dev, dtype=torch.float64)
+    per_rank = [wall]
     if world > 1:
+        lst = [torch.zeros(2, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(lst, torch.tensor([wall, ev_ms * 1e-3], device=dev, dtype=torch.float64))
+        per_rank = [float(x[0]) for x in lst]
+        per_rank_ev = [float(x[1]) for x in lst]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    else:
+        per_rank_ev = [ev_ms * 1e-3]
     wall = float(tt[0])
     KR = K * R                                          # env steps inside the timed region
     assert bool(torch.isfinite(obs).all()) and bool(torch.isfinite(rew).all()), 'non-finite outputs'
@@ -270,7 +623,7 @@ def main():
 
     # ---- fused-rollout leg (dpenv_rollout): same workload, CHUNK env steps per launch, state in registers -----
     fused = None
-    if not args.no_fused:
+    if side_legs:
         fobs = torch.empty((CHUNK, n, 9), device=dev)
         frew = torch.empty((CHUNK, n), device=dev)
         fdone = torch.empty((CHUNK, n), dtype=torch.uint8, device=dev)
@@ -308,7 +661,7 @@ def main():
     # ---- closed-loop legs (dpenv_policy_rollout): actor-critic 9-80-80-80-7 / -1 evaluated in-kernel on MFMA, exploration noise
     #      drawn in the kernel (core.py:85), both network arithmetics ---------------------------------------------------------
     closed = None
-    if not args.no_fused:
+    if side_legs:
         from ml4ca_amd.policy import ActorCritic, policy_rollout
         ac = ActorCritic(9, 7, (80, 80, 80), seed=0, device=dev)
         flops = 2 * 2 * (9 * 80 + 80 * 80 * 2 + 80 * 7) * n       # actor + critic MACs x 2, per step (critic out 1 ~ 7)
@@ -364,7 +717,7 @@ def main():
     #      (T = 400 = one episode, auto-reset) + GAE scan + advantage normalisation, all on device; every epoch re-packs the
     #      (device-resident) weights and draws fresh exploration noise in the kernel, as a PPO epoch must ---------------------
     cfg5 = None
-    if not args.no_fused:
+    if side_legs:
         from ml4ca_amd import rollout as RO
         env5 = ml4ca_amd.BatchedRevoltEnv(n, variant='final', extended_state=True, cont_ang=True, device=dev, auto_reset=True,
                                           seed=2, env_id_base=rank * n, obs_dtype='bfloat16', current=True, current_drift=True)
@@ -405,32 +758,13 @@ def main():
         cfg5['us_per_step'] = cfg5['policy_dtype_f16']['us_per_step']
         del env5, buf5
 
-    # ---- config-4 leg: episode-boundary all-gather of [T=400, 32768, 19] f32 trajectory blocks ------------
-    gather = None
-    do_gather = (args.gather == 1) or (args.gather < 0 and world > 1)
-    if do_gather and world > 1:
-        T, nl = 400, 32768
-        from ml4ca_amd.dist import gather_rollout
-        traj = {'obs': torch.randn((T, nl, 9), device=dev), 'act': torch.randn((T, nl, 7), device=dev), 'rew': torch.randn((T, nl), device=dev),
-                'val': torch.randn((T, nl), device=dev), 'logp': torch.randn((T, nl), device=dev)}
-        out = gather_rollout(traj)
-        torch.cuda.synchronize(dev)
-        dist.barrier()
-        t1 = time.perf_counter()
-        reps = 3
-        for _ in range(reps):
-            gather_rollout(traj, out=out)
-        torch.cuda.synchronize(dev)
-        gt = torch.tensor([(time.perf_counter() - t1) / reps], device=dev, dtype=torch.float64)
-        dist.all_reduce(gt, op=dist.ReduceOp.MAX)
-        gsec = float(gt[0])
-        shard = sum(v.numel() for v in traj.values()) * 4
-        gather = {'what': 'config 4: all-gather of a [400, 32768] rollout per rank - the five blocks obs 9 | act 7 | rew | val | logp '
-                          '(19 floats per env-step) gathered in place, no packed staging copy; not in `value`',
-                  'ms': gsec * 1e3, 'shard_MB': shard / 1e6,
-                  'recv_GBps_per_rank': shard * (world - 1) / gsec / 1e9,
-                  'env_steps_per_s_step_plus_gather': world * nl * T / (T * (wall / KR) * nl / n + gsec)}
-        del out, traj
+    # ---- config-4 record (BASELINE.json configs[3]): measured at ITS shard size, on every rank ------------------------------
+    cfg4 = None
+    if (args.config4 == 1) or (args.config4 < 0 and world > 1) or args.gather == 1:
+        cfg4 = config4_record(args, dev, rank, world, dist)
+    classes = None
+    if args.classes > 0 and rank == 0:
+        classes = classes_record(args, dev, n)
 
     if rank == 0:
         total_envs = n * world
@@ -454,6 +788,8 @@ def main():
             'config': {'workload': 'BASELINE.json configs[2]: %d parallel envs per GPU, final/ext/cont_ang, 4-corner box '
                                    'setpoint sequence (switch steps 50/300/550/700/950 of 1250), terminate off, fp32' % n,
                        'envs_per_gpu': n, 'total_envs': total_envs, 'integrator': 'semi-implicit Euler 20 x 10 ms',
+                       'math': 'lean call-free sincos / atan2 (<= 9.2e-8 / 2.6e-7 abs), v_rsq / v_exp / v_sqrt hardware transcendentals; no -ffast-math; '
+                               'fp32 state; error against the libm fp32 oracle: cpu_baseline.gpu_vs_cpu',
                        'launch': 'eager' if graph is None else 'hipGraph replay, %d steps per graph' % C,
                        'timed_region': '%d steps x %d repeats back to back (%.1f ms)' % (K, R, wall * 1e3),
                        'sharding': 'independent env shards, no data-path collective',
@@ -471,8 +807,12 @@ def main():
             'reference_context': {'published_derived_env_steps_per_s': 34.3,
                                   'source': 'BASELINE.md: 2.4M interactions / 69930 s, 1 env, laptop + Cybersea'},
         }
-        if gather:
-            res['allgather'] = gather
+        res['group'] = group
+        res['per_rank'] = {'wall_s': per_rank, 'hip_event_s': per_rank_ev, 'ms_per_step_min': min(per_rank) / KR * 1e3, 'ms_per_step_max': max(per_rank) / KR * 1e3}
+        if cfg4:
+            res['config4'] = cfg4
+        if classes:
+            res['vessel_classes'] = classes
         if fused:
             res['fused_rollout'] = fused
         if closed:

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DPENV_ABI_VERSION 2
+#define DPENV_ABI_VERSION 3
 
 typedef struct dpenv_s* dpenv_handle;
 typedef void* dpenv_stream; /* hipStream_t; NULL = the null stream */
@@ -155,6 +155,8 @@ int dpenv_set_vessel_class(dpenv_handle h, const int32_t* class_id, dpenv_stream
 /* vc, beta: device float[n_envs] current speed [m/s] and NED direction [rad].  Copied; they are both the
  * present value and the mean the drift process reverts to. */
 int dpenv_set_current(dpenv_handle h, const float* vc, const float* beta, dpenv_stream s);
+/* Only the PRESENT values (the drift's state), leaving the means alone: restores what dpenv_get_current returned (checkpoints). */
+int dpenv_set_current_present(dpenv_handle h, const float* vc, const float* beta, dpenv_stream s);
 /* present current of every env (differs from the set values only with current_drift) */
 int dpenv_get_current(dpenv_handle h, float* vc_out, float* beta_out, dpenv_stream s);
 
@@ -204,14 +206,16 @@ typedef struct dpenv_mlp {
 /* Arithmetic of the in-kernel networks.  F16: f16 weights and activations, f32 accumulation - the fast mode, within ~5e-4 of
  * the output scale of an fp32 evaluation.  F32: "fp32-faithful" split-f16 arithmetic (W = Wh + Wl, x = xh + xl, three MFMAs per
  * product, activations in f32): mu, v, logp within 1e-5 of an fp32 evaluation of core.py:29-33,80-107 - the mode parity with
- * the reference's fp32 TF1 networks is claimed on; about half the speed of F16 in the closed loop, one-wave launch form only.
+ * the reference's fp32 TF1 networks is claimed on; three times the matrix work of F16.
  * F32_ACTOR: the actor (mu, and with it the sampled action and logp) in the F32 arithmetic, the critic in the F16 arithmetic: what a
  * PPO update needs exactly is the log-likelihood (the ratio exp(logp_new - logp_old) then starts at 1); values carry the F16 mode's
- * ~5e-4 and are bit-identical to the F16 mode's.  About 1.5 x the speed of F32 in the closed loop; one-wave launch form. */
+ * ~5e-4 and are bit-identical to the F16 mode's.  Two thirds of the matrix work of F32. */
 enum { DPENV_POLICY_F16 = 0, DPENV_POLICY_F32 = 1, DPENV_POLICY_F32_ACTOR = 2 };
-/* Launch form of dpenv_policy_rollout.  TWO_WAVE: every 64 envs get an env wave and a network wave (512-thread workgroups,
- * pair-level LDS hand-over); ONE_WAVE: one wave does both.  Both write identical rows.  AUTO picks TWO_WAVE where it exists
- * (F16) and its LDS footprint (networks + 50 KiB of mailboxes) fits, else ONE_WAVE. */
+/* Launch form of dpenv_policy_rollout.  TWO_WAVE: every 64 envs get an env wave and a network wave (pair-level LDS hand-over;
+ * 256-env workgroups with both waves of a pair on one SIMD, or - while one round of them fits the chip, n_envs <= 128 x CUs -
+ * 128-env workgroups with a SIMD per wave); ONE_WAVE: one wave does both.  Both write identical rows.  AUTO picks TWO_WAVE where
+ * it exists (every arithmetic with leaky-relu / relu, F16 also with tanh) and its LDS footprint (the weight images its network wave
+ * reads + 40-50 KiB of mailboxes) fits the 160 KiB, else ONE_WAVE. */
 enum { DPENV_LAUNCH_AUTO = 0, DPENV_LAUNCH_ONE_WAVE = 1, DPENV_LAUNCH_TWO_WAVE = 2 };
 typedef struct dpenv_policy_desc {
     uint32_t struct_size;
@@ -228,9 +232,13 @@ typedef struct dpenv_policy_desc {
                                 PPO update (ppo.py:260-280) costs one small launch. */
     int32_t reserved;
 } dpenv_policy_desc;
-/* Pack the networks into the image the rollout kernels stage into LDS.  Stream-ordered: launches issued on `s` afterwards see
- * the new weights, launches issued before keep the old ones.  Fails with DPENV_EINVAL if the requested launch form cannot
- * hold the networks in the 160 KiB LDS. */
+/* Pack the networks into the image the rollout kernels stage into LDS.  Launches issued (on any stream) before this call keep
+ * the weights they were given: the library holds two images and writes them alternately, and the packing waits (on `s`, by event)
+ * for the last launch that read the image it reuses.  Launches issued afterwards read the new image; they are ordered behind the
+ * packing if they are issued on `s` (or on a stream the caller orders behind `s`).  device_pointers = 1: stream-ordered, no host
+ * synchronisation, graph-capturable.  device_pointers = 0 (host arrays): the call synchronises `s` before it returns, so the
+ * arrays may be freed or changed at once.  Fails with DPENV_EINVAL if the requested launch form cannot hold the networks in the
+ * 160 KiB LDS; after a failed DPENV_ENOMEM no policy is in force. */
 int dpenv_set_policy_desc(dpenv_handle h, const dpenv_policy_desc* d, dpenv_stream s);
 /* Convenience forms (host pointers, F16, AUTO, null stream):
  * pi: obs_dim -> act_dim, v: obs_dim -> 1 (same hidden shape); log_std: host float[act_dim]; leak: hidden
@@ -269,7 +277,12 @@ typedef struct dpenv_policy_rollout_io {
                                 Box-Muller keyed (config.seed; global env id, number of actions that env has sampled so far), so a
                                 trajectory does not depend on the rank count or launch geometry and no [T][n][act_dim] noise block
                                 is generated, stored or read (28 B per env-step).  Ignored when noise != NULL. */
-    int32_t reserved;
+    int32_t reset_at_end;    /* 1: the reference's epoch boundary (ppo.py:305-322, `t == local_steps_per_epoch - 1`): after step T-1
+                                EVERY env is cut - boot[T-1] = V(its last observation), or 0 if it terminated at that step
+                                (ppo.py:311) - and re-drawn with the training sampler (episode counter + 1, step counter 0), so the
+                                next launch starts T-step-aligned fresh episodes like the reference's next epoch; last_obs /
+                                last_value are those of the NEW episodes.  Needs config.auto_reset.  0: episodes continue across
+                                launches (the block still ends with a bootstrap value, like a cut-off path). */
 } dpenv_policy_rollout_io;
 /* Requires AOS layouts.  Vessel classes, drifting current, auto-reset (with reset_acts) and bf16 observation rows all work
  * here as in dpenv_step.  Launch form and arithmetic: dpenv_policy_desc. */
@@ -278,6 +291,19 @@ int dpenv_policy_rollout(dpenv_handle h, const dpenv_policy_rollout_io* io, dpen
 /* Parity/test access to the library-owned state in the canonical format above. */
 int dpenv_get_state(dpenv_handle h, float* state_out, int32_t* counters_out, dpenv_stream s);
 int dpenv_set_state(dpenv_handle h, const float* state_in, const int32_t* counters_in, dpenv_stream s);
+/* The two per-env draw counters that key the streams drawn every env step: exploration noise (sample = 1 rollouts) and the
+ * Gauss-Markov current drift; device uint32[n_envs] each, either pointer may be NULL.  get_state + get_current + these =
+ * everything a checkpoint needs: restoring them reproduces the sampled rollouts that followed the checkpoint, bit for bit. */
+int dpenv_get_rng_counters(dpenv_handle h, uint32_t* noise_ctr_out, uint32_t* drift_ctr_out, dpenv_stream s);
+int dpenv_set_rng_counters(dpenv_handle h, const uint32_t* noise_ctr_in, const uint32_t* drift_ctr_in, dpenv_stream s);
+/* The observation of step t carries the thrust command of step t-1 (customEnv.py:196-205 fills state_ext before :126 updates
+ * prev_thrust); the state block holds the command of step t.  A closed-loop launch that CONTINUES an episode therefore starts from
+ * the observation its predecessor ended with: the library keeps that observation's thrust columns (device float[n_envs][4]: o[6], o[7],
+ * o[8], unused) and uses them while nothing else (reset, step, rollout, set_state) has touched the state in between - dpenv_step
+ * callers hold the returned observation themselves.  get fails with DPENV_EINVAL when there is nothing to continue; set is for
+ * restoring a mid-episode checkpoint (after dpenv_set_state). */
+int dpenv_get_obs_thrust(dpenv_handle h, float* out, dpenv_stream s);
+int dpenv_set_obs_thrust(dpenv_handle h, const float* in, dpenv_stream s);
 
 /* Stateless thruster force map tau = B(alpha) F(n) (SupervisedTau.py:42-83) for n items:
  * n_pct, alpha, tau_out are device float[3][n] (bow, port, star / Fx, Fy, Mz); params host float[DPENV_NPARAM]. */

@@ -20,7 +20,7 @@ POLICY_F16, POLICY_F32, POLICY_F32_ACTOR = 0, 1, 2
 LAUNCH_AUTO, LAUNCH_ONE_WAVE, LAUNCH_TWO_WAVE = 0, 1, 2
 DONE_TERMINAL, DONE_TIMELIMIT, DONE_FAULT = 1, 2, 4
 NSTATE, NPARAM, MAX_CLASSES = 15, 32, 64
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # canonical state rows (dpenv.h DPENV_S_*)
 S = dict(N=0, E=1, PSI=2, U=3, V=4, R=5, REF_N=6, REF_E=7, REF_PSI=8,
@@ -62,7 +62,7 @@ class PolicyRolloutIO(C.Structure):
                 ('act', C.c_void_p), ('reward', C.c_void_p), ('value', C.c_void_p), ('logp', C.c_void_p),
                 ('done', C.c_void_p), ('boot', C.c_void_p), ('last_obs', C.c_void_p), ('last_value', C.c_void_p),
                 ('n_switch', C.c_int32), ('switch_step', C.c_int32 * 8), ('refs', C.c_void_p), ('sample', C.c_int32),
-                ('reserved', C.c_int32)]
+                ('reset_at_end', C.c_int32)]
 
 
 class PolicyDesc(C.Structure):
@@ -85,6 +85,7 @@ SYMBOLS = {
     'dpenv_set_reset_fraction': (C.c_int, [_VP, _F]),
     'dpenv_set_vessel_class': (C.c_int, [_VP, _VP, _VP]),
     'dpenv_set_current': (C.c_int, [_VP, _VP, _VP, _VP]),
+    'dpenv_set_current_present': (C.c_int, [_VP, _VP, _VP, _VP]),
     'dpenv_get_current': (C.c_int, [_VP, _VP, _VP, _VP]),
     'dpenv_reset': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
     'dpenv_step': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
@@ -97,6 +98,10 @@ SYMBOLS = {
     'dpenv_policy_rollout': (C.c_int, [_VP, C.POINTER(PolicyRolloutIO), _VP]),
     'dpenv_get_state': (C.c_int, [_VP, _VP, _VP, _VP]),
     'dpenv_set_state': (C.c_int, [_VP, _VP, _VP, _VP]),
+    'dpenv_get_rng_counters': (C.c_int, [_VP, _VP, _VP, _VP]),
+    'dpenv_set_rng_counters': (C.c_int, [_VP, _VP, _VP, _VP]),
+    'dpenv_get_obs_thrust': (C.c_int, [_VP, _VP, _VP]),
+    'dpenv_set_obs_thrust': (C.c_int, [_VP, _VP, _VP]),
     'dpenv_thrust_map': (C.c_int, [C.POINTER(C.c_float), _VP, _VP, _VP, _I32, _VP]),
     'dpenv_gae': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _F, _F, _VP, _VP, _VP]),
     'dpenv_gae_workspace_bytes': (C.c_int64, [_I32]),

@@ -35,12 +35,17 @@ struct dpenv_s {
     bool current_set;
     uint32_t* noise_ctr;
     PolicyArgs pol;         // persistent part (weights, std) of the policy kernel arguments
-    void* pol_buf;          // fragments | bias tiles | constants, as the kernels stage them
-    size_t pol_buf_bytes;
+    void* pol_buf;          // fragments | bias tiles | constants, as the kernels stage them: TWO images of pol_buf_bytes / 2 each,
+    size_t pol_buf_bytes;   //   written alternately, so that an upload never touches the image the launches before it read
+    int pol_slot;           // image the NEXT upload writes (0 / 1)
+    hipEvent_t pol_read[2]; // recorded behind the last launch that read image k: the upload that reuses it waits for that
+    bool pol_read_valid[2];
+    int n_cus;
     float* pol_raw;         // device staging of raw fp32 weights for the host-pointer form of set_policy
     size_t pol_raw_bytes;
     int pol_form;           // DPENV_LAUNCH_* requested
     bool has_policy;
+    bool lag_valid;         // the state block was last written by a closed-loop launch (PolicyArgs.use_lag)
     int device;
     std::string err;
 };
@@ -240,9 +245,17 @@ extern "C" int dpenv_create(const dpenv_config* cfg, const float* vessel_params,
     h->classes_assigned = false;
     h->current_set = false;
     h->pol_buf = nullptr; h->pol_buf_bytes = 0;
+    h->pol_slot = 0;
+    h->pol_read[0] = h->pol_read[1] = nullptr;
+    h->pol_read_valid[0] = h->pol_read_valid[1] = false;
+    {
+        hipDeviceProp_t prop;
+        h->n_cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
     h->pol_raw = nullptr; h->pol_raw_bytes = 0;
     h->pol_form = DPENV_LAUNCH_AUTO;
     h->has_policy = false;
+    h->lag_valid = false;
     std::memset(&h->pol, 0, sizeof h->pol);
 
     VesselDev tab[MAX_CLASSES];
@@ -272,6 +285,7 @@ extern "C" int dpenv_create(const dpenv_config* cfg, const float* vessel_params,
     const size_t o_dc = off; off += npad * 4;
     const size_t o_ci = off; off += npad * 4;
     const size_t o_nc = off; off += npad * 4;
+    const size_t o_s3 = off; off += npad * 16;
     const size_t o_ct = off; off += align_up(sizeof(VesselDev) * MAX_CLASSES, 256);
     h->blob_bytes = off;
     void* blob = nullptr;
@@ -327,6 +341,7 @@ extern "C" int dpenv_create(const dpenv_config* cfg, const float* vessel_params,
     a.reset_fraction = cfg->reset_fraction;
     a.reset_acts = cfg->reset_acts ? 1 : 0;
     a.noise_ctr = h->noise_ctr;
+    a.S3 = (float4*)(b + o_s3);
     *out = h;
     return DPENV_OK;
 }
@@ -338,6 +353,7 @@ extern "C" int dpenv_destroy(dpenv_handle h)
     if (h->blob) (void)hipFree(h->blob);
     if (h->pol_buf) (void)hipFree(h->pol_buf);
     if (h->pol_raw) (void)hipFree(h->pol_raw);
+    for (int k = 0; k < 2; ++k) if (h->pol_read[k]) (void)hipEventDestroy(h->pol_read[k]);
     delete h;
     return DPENV_OK;
 }
@@ -377,6 +393,17 @@ extern "C" int dpenv_set_current(dpenv_handle h, const float* vc, const float* b
     return DPENV_OK;
 }
 
+extern "C" int dpenv_set_current_present(dpenv_handle h, const float* vc, const float* beta, dpenv_stream s)
+{
+    if (!h || !vc || !beta) return fail(h, DPENV_EINVAL, "dpenv_set_current_present: NULL argument");
+    DeviceGuard dev_guard(h->device);
+    if (!h->cfg.current_enabled) return fail(h, DPENV_EINVAL, "config.current_enabled is 0");
+    const size_t bytes = sizeof(float) * (size_t)h->cfg.n_envs;
+    HIP_TRY(h, hipMemcpyAsync(h->cur_vc, vc, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
+    HIP_TRY(h, hipMemcpyAsync(h->cur_beta, beta, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
+    return DPENV_OK;
+}
+
 extern "C" int dpenv_get_current(dpenv_handle h, float* vc_out, float* beta_out, dpenv_stream s)
 {
     if (!h || !vc_out || !beta_out) return fail(h, DPENV_EINVAL, "dpenv_get_current: NULL argument");
@@ -408,6 +435,7 @@ extern "C" int dpenv_reset(dpenv_handle h, const uint8_t* mask, const float* ini
     bind_optional(h, a);
     a.obs = obs_out;
     HIP_TRY(h, dpenv_dev_launch_reset(&a, h->mode, h->cfg.extended_state, mask, init, ref, (hipStream_t)s));
+    h->lag_valid = false;
     return DPENV_OK;
 }
 
@@ -430,6 +458,7 @@ extern "C" int dpenv_step_ex(dpenv_handle h, const dpenv_step_io* io, dpenv_stre
     a.parts = io->reward_parts;
     a.final_obs = io->final_obs;
     HIP_TRY(h, dpenv_dev_launch_step(&a, h->mode, h->cfg.extended_state, h->n_classes > 1, (hipStream_t)s));
+    h->lag_valid = false;
     return DPENV_OK;
 }
 
@@ -465,6 +494,7 @@ extern "C" int dpenv_rollout(dpenv_handle h, const dpenv_rollout_io* io, dpenv_s
     ra.n_switch = io->n_switch; ra.refs = io->refs;
     for (int k = 0; k < io->n_switch; ++k) ra.switch_step[k] = io->switch_step[k];
     HIP_TRY(h, dpenv_dev_launch_rollout(&a, &ra, h->mode, h->cfg.extended_state, h->n_classes > 1, (hipStream_t)s));
+    h->lag_valid = false;
     return DPENV_OK;
 }
 
@@ -504,28 +534,50 @@ extern "C" int dpenv_set_policy_desc(dpenv_handle h, const dpenv_policy_desc* d,
     if (check_net(v, od, 1, &why) != DPENV_OK) return fail(h, DPENV_EINVAL, "critic: %s", why.c_str());
     const int nl = pi->n_layers, n_hidden = nl - 1, H = pi->sizes[1];
     const int ks = H <= 80 ? 5 : 6;
-    const int nfrag = 3 + 3 * ks * (n_hidden - 1) + ks;
+    const int nent = (128 + (ks == 5 ? 32 : 64)) + (n_hidden - 1) * ks * (128 + (ks == 5 ? 32 : 64)) + ks * 16;   // FragAddr, dpenv_policy_dev.h
     const int nblk = 3 * (n_hidden - 1) + 1;
     const int split = d->precision != DPENV_POLICY_F16;
-    const size_t bytes_frags = (size_t)2 * nfrag * 64 * 16 * (1 + split), bytes_bias = (size_t)2 * nblk * 32 * sizeof(float);
-    // the launch form decides the LDS footprint: refuse here what the rollout could not launch
-    const size_t lds_image = bytes_frags + bytes_bias, lds_max = 160 * 1024;
-    const bool fits_two = !split && lds_image + POLICY_WS_MAILBOX_BYTES <= lds_max;
+    const size_t bytes_frags = (size_t)2 * nent * 16 * (1 + split), bytes_bias = (size_t)2 * nblk * 32 * sizeof(float);
+    // the launch form decides the LDS footprint: refuse here what the rollout could not launch.  The two-wave form stages the
+    // images its network wave reads (f16: actor + critic; F32_ACTOR: + the actor's low image; F32: all four) and a mailbox group
+    // per 64 envs; it exists for leaky-relu / relu in every arithmetic and for tanh in f16.
+    const size_t per_image = (size_t)nent * 16, lds_max = 160 * 1024;
+    const int n_img_two = !split ? 2 : (d->precision == DPENV_POLICY_F32_ACTOR ? 3 : 4);
+    const size_t lds_image = bytes_frags + bytes_bias;
+    const size_t lds_two = n_img_two * per_image + bytes_bias + (split ? POLICY_WS_MAILBOX_X_BYTES : POLICY_WS_MAILBOX_BYTES);
+    const bool form_two = !split || d->activation == DPENV_ACT_LEAKY_RELU;
+    const bool fits_two = form_two && lds_two <= lds_max;
     const bool fits_one = lds_image + (split ? 0 : POLICY_STAGING_BYTES) <= lds_max;
     if (!fits_one) return fail(h, DPENV_EINVAL, "networks do not fit the 160 KiB LDS (%zu bytes of fragments and biases)", lds_image);
     if (d->launch_form == DPENV_LAUNCH_TWO_WAVE && !fits_two)
-        return fail(h, DPENV_EINVAL, split ? "DPENV_POLICY_F32 has no two-wave form (its weight image fills the LDS)"
-                                           : "networks + the two-wave form's mailboxes exceed the 160 KiB LDS: use DPENV_LAUNCH_ONE_WAVE");
-    const size_t need = bytes_frags + bytes_bias + 24 * sizeof(float);
-    if (h->pol_buf && h->pol_buf_bytes < need) {
-        // growing the image: a launch that still reads the old one may be in flight
+        return fail(h, DPENV_EINVAL, form_two ? "networks + the two-wave form's mailboxes exceed the 160 KiB LDS (%zu bytes): use DPENV_LAUNCH_ONE_WAVE"
+                                              : "the split arithmetics have a two-wave form for leaky-relu / relu only (%zu)", lds_two);
+    // two images, written alternately: launches issued before this call keep reading the one they were given (the header's
+    // promise), whatever stream they run on; the image written now was last read by launches issued before the PREVIOUS upload,
+    // and this stream waits for the last of them (an event recorded behind every launch that reads an image).
+    const size_t need = (bytes_frags + bytes_bias + 24 * sizeof(float) + 255) / 256 * 256;
+    if (h->pol_buf && h->pol_buf_bytes < 2 * need) {
+        // growing the images: a launch that still reads the old ones may be in flight
         HIP_TRY(h, hipDeviceSynchronize());
-        (void)hipFree(h->pol_buf); h->pol_buf = nullptr;
+        (void)hipFree(h->pol_buf); h->pol_buf = nullptr; h->pol_buf_bytes = 0;
+        h->has_policy = false;
+        std::memset(&h->pol, 0, sizeof h->pol);
+        h->pol_read_valid[0] = h->pol_read_valid[1] = false;
     }
     if (!h->pol_buf) {
-        if (hipMalloc(&h->pol_buf, need) != hipSuccess) return fail(h, DPENV_ENOMEM, "hipMalloc of the policy image failed");
-        h->pol_buf_bytes = need;
+        if (hipMalloc(&h->pol_buf, 2 * need) != hipSuccess) {
+            h->pol_buf = nullptr; h->pol_buf_bytes = 0; h->has_policy = false;
+            std::memset(&h->pol, 0, sizeof h->pol);
+            return fail(h, DPENV_ENOMEM, "hipMalloc of the policy images failed");
+        }
+        h->pol_buf_bytes = 2 * need;
+        h->pol_slot = 0;
     }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing((hipStream_t)s, &cap);
+    const bool capturing = cap != hipStreamCaptureStatusNone;      // inside a captured graph the graph's own edges order everything
+    const int slot = h->pol_slot;
+    if (!capturing && h->pol_read_valid[slot]) HIP_TRY(h, hipStreamWaitEvent((hipStream_t)s, h->pol_read[slot], 0));
     PackNet pn[2];
     const float* ls_dev = d->log_std;
     if (!d->device_pointers) {
@@ -535,6 +587,8 @@ extern "C" int dpenv_set_policy_desc(dpenv_handle h, const dpenv_policy_desc* d,
             const dpenv_mlp* m = k ? v : pi;
             for (int l = 0; l < nl; ++l) raw += (size_t)m->sizes[l] * m->sizes[l + 1] + m->sizes[l + 1];
         }
+        // the staging area is reused by every host-pointer upload: the previous one's packing kernel must be done with it (this
+        // form is synchronous anyway, see the end of this function)
         if (h->pol_raw && h->pol_raw_bytes < raw * sizeof(float)) { HIP_TRY(h, hipDeviceSynchronize()); (void)hipFree(h->pol_raw); h->pol_raw = nullptr; }
         if (!h->pol_raw) {
             void* p = nullptr;
@@ -564,16 +618,16 @@ extern "C" int dpenv_set_policy_desc(dpenv_handle h, const dpenv_policy_desc* d,
         pn[k].n_layers = nl; pn[k].in_dim = od; pn[k].H = H; pn[k].out_dim = k ? 1 : ad;
         for (int l = nl; l < 5; ++l) { pn[k].W[l] = nullptr; pn[k].b[l] = nullptr; }
     }
-    char* base = (char*)h->pol_buf;
+    char* base = (char*)h->pol_buf + (size_t)slot * (h->pol_buf_bytes / 2);
     float* bias = (float*)(base + bytes_frags);
     float* consts = (float*)(base + bytes_frags + bytes_bias);
-    HIP_TRY(h, dpenv_dev_launch_pack_policy(&pn[0], &pn[1], ls_dev, ad, ks, nfrag, nblk, split, base, bias, consts, (hipStream_t)s));
+    HIP_TRY(h, dpenv_dev_launch_pack_policy(&pn[0], &pn[1], ls_dev, ad, ks, nent, nblk, split, base, bias, consts, (hipStream_t)s));
     PolicyArgs& pa = h->pol;
     std::memset(&pa, 0, sizeof pa);
     pa.frags = (const uint4*)base;
     pa.bias = bias;
     pa.consts = consts;
-    pa.nfrag = nfrag;
+    pa.nent = nent;
     pa.nblk = nblk;
     pa.ks = ks;
     pa.act = d->activation;
@@ -583,8 +637,30 @@ extern "C" int dpenv_set_policy_desc(dpenv_handle h, const dpenv_policy_desc* d,
     pa.leak = d->leak;
     // AUTO: the two-wave form where it exists and fits (the faster one), else one wave per 64 envs
     pa.ws = d->launch_form == DPENV_LAUNCH_TWO_WAVE ? 1 : (d->launch_form == DPENV_LAUNCH_ONE_WAVE ? 0 : (fits_two ? 1 : 0));
+    // two-wave geometry: 128-env workgroups (a SIMD per wave) while one round of them fits the chip, else 256-env workgroups;
+    // tanh has the 256-env form only
+    pa.ws_groups = (d->activation == DPENV_ACT_LEAKY_RELU && (h->cfg.n_envs + 127) / 128 <= h->n_cus) ? 2 : 4;
     h->pol_form = d->launch_form;
     h->has_policy = true;
+    h->pol_slot = slot ^ 1;
+    // host pointers: the caller's arrays (and the shared staging area) must be done with before this returns
+    if (!d->device_pointers && !capturing) HIP_TRY(h, hipStreamSynchronize((hipStream_t)s));
+    return DPENV_OK;
+}
+
+// behind every launch that reads the current image: the event an upload into that image waits for
+static int mark_policy_read(dpenv_handle h, dpenv_stream s)
+{
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing((hipStream_t)s, &cap);
+    if (cap != hipStreamCaptureStatusNone) return DPENV_OK;
+    const int cur = h->pol_slot ^ 1;                        // the image the last upload wrote
+    if (!h->pol_read[cur] && hipEventCreateWithFlags(&h->pol_read[cur], hipEventDisableTiming) != hipSuccess) {
+        h->pol_read[cur] = nullptr;
+        return fail(h, DPENV_EHIP, "hipEventCreate failed");
+    }
+    HIP_TRY(h, hipEventRecord(h->pol_read[cur], (hipStream_t)s));
+    h->pol_read_valid[cur] = true;
     return DPENV_OK;
 }
 
@@ -596,7 +672,13 @@ extern "C" int dpenv_set_policy_ex(dpenv_handle h, const dpenv_mlp* pi, const dp
     d.struct_size = (uint32_t)sizeof d;
     d.pi = pi; d.v = v; d.log_std = log_std; d.activation = activation; d.leak = leak;
     d.precision = DPENV_POLICY_F16; d.launch_form = DPENV_LAUNCH_AUTO; d.device_pointers = 0;
-    return dpenv_set_policy_desc(h, &d, nullptr);
+    const int rc = dpenv_set_policy_desc(h, &d, nullptr);     // host pointers: synchronises the null stream before it returns
+    if (rc != DPENV_OK) return rc;
+    // the convenience forms keep the contract they always had: when they return the new weights are in force for launches on
+    // ANY stream (non-blocking streams do not order themselves behind the null stream)
+    DeviceGuard dev_guard(h->device);
+    HIP_TRY(h, hipDeviceSynchronize());
+    return DPENV_OK;
 }
 
 extern "C" int dpenv_set_policy(dpenv_handle h, const dpenv_mlp* pi, const dpenv_mlp* v, const float* log_std, float leak)
@@ -616,7 +698,7 @@ extern "C" int dpenv_policy_forward(dpenv_handle h, const float* obs, float* mu_
     else
         HIP_TRY(h, dpenv_dev_launch_policy_forward(&h->pol, dpenv_obs_dim(&h->cfg), dpenv_act_dim(&h->cfg), obs, mu_out, v_out, n,
                                                    (hipStream_t)s));
-    return DPENV_OK;
+    return mark_policy_read(h, s);
 }
 
 #ifdef DPENV_WS_SELFCHECK
@@ -658,13 +740,18 @@ extern "C" int dpenv_policy_rollout(dpenv_handle h, const dpenv_policy_rollout_i
     pa.logp = io->logp; pa.done = io->done; pa.boot = io->boot; pa.last_obs = io->last_obs; pa.last_val = io->last_value;
     pa.n_switch = io->n_switch; pa.refs = io->refs;
     pa.sample = io->sample ? 1 : 0;
+    pa.reset_at_end = io->reset_at_end ? 1 : 0;
+    pa.use_lag = h->lag_valid ? 1 : 0;
+    if (pa.reset_at_end && !h->cfg.auto_reset)
+        return fail(h, DPENV_EINVAL, "reset_at_end re-draws every env with the training sampler: it needs config.auto_reset");
     for (int k = 0; k < io->n_switch; ++k) pa.switch_step[k] = io->switch_step[k];
 #ifdef DPENV_WS_SELFCHECK
     pa.dbg = g_selfcheck_buf;
 #endif
     if (pa.split) HIP_TRY(h, dpenv_dev_launch_policy_rollout_x(&a, &pa, h->mode, h->cfg.extended_state, (hipStream_t)s));
     else HIP_TRY(h, dpenv_dev_launch_policy_rollout(&a, &pa, h->mode, h->cfg.extended_state, (hipStream_t)s));
-    return DPENV_OK;
+    h->lag_valid = true;
+    return mark_policy_read(h, s);
 }
 
 extern "C" int dpenv_get_state(dpenv_handle h, float* state_out, int32_t* counters_out, dpenv_stream s)
@@ -680,6 +767,47 @@ extern "C" int dpenv_set_state(dpenv_handle h, const float* state_in, const int3
     if (!h) return DPENV_EINVAL;
     DeviceGuard dev_guard(h->device);
     HIP_TRY(h, dpenv_dev_launch_set_state(&h->args, state_in, counters_in, (hipStream_t)s));
+    h->lag_valid = false;
+    return DPENV_OK;
+}
+
+// exploration-noise and current-drift draw counters: with them a restored state reproduces sampled rollouts (dpenv.h)
+extern "C" int dpenv_get_rng_counters(dpenv_handle h, uint32_t* noise_ctr_out, uint32_t* drift_ctr_out, dpenv_stream s)
+{
+    if (!h || (!noise_ctr_out && !drift_ctr_out)) return fail(h, DPENV_EINVAL, "dpenv_get_rng_counters: NULL argument");
+    DeviceGuard dev_guard(h->device);
+    const size_t bytes = sizeof(uint32_t) * (size_t)h->cfg.n_envs;
+    if (noise_ctr_out) HIP_TRY(h, hipMemcpyAsync(noise_ctr_out, h->noise_ctr, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
+    if (drift_ctr_out) HIP_TRY(h, hipMemcpyAsync(drift_ctr_out, h->drift_ctr, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
+    return DPENV_OK;
+}
+
+extern "C" int dpenv_set_rng_counters(dpenv_handle h, const uint32_t* noise_ctr_in, const uint32_t* drift_ctr_in, dpenv_stream s)
+{
+    if (!h || (!noise_ctr_in && !drift_ctr_in)) return fail(h, DPENV_EINVAL, "dpenv_set_rng_counters: NULL argument");
+    DeviceGuard dev_guard(h->device);
+    const size_t bytes = sizeof(uint32_t) * (size_t)h->cfg.n_envs;
+    if (noise_ctr_in) HIP_TRY(h, hipMemcpyAsync(h->noise_ctr, noise_ctr_in, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
+    if (drift_ctr_in) HIP_TRY(h, hipMemcpyAsync(h->drift_ctr, drift_ctr_in, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
+    return DPENV_OK;
+}
+
+// the thrust columns of the observation the last closed-loop launch ended with (PolicyArgs.use_lag): part of a mid-episode checkpoint
+extern "C" int dpenv_get_obs_thrust(dpenv_handle h, float* out, dpenv_stream s)
+{
+    if (!h || !out) return fail(h, DPENV_EINVAL, "dpenv_get_obs_thrust: NULL argument");
+    if (!h->lag_valid) return fail(h, DPENV_EINVAL, "no closed-loop launch since the last reset / step / set_state: the next launch starts from the state block alone");
+    DeviceGuard dev_guard(h->device);
+    HIP_TRY(h, hipMemcpyAsync(out, h->args.S3, sizeof(float4) * (size_t)h->cfg.n_envs, hipMemcpyDeviceToDevice, (hipStream_t)s));
+    return DPENV_OK;
+}
+
+extern "C" int dpenv_set_obs_thrust(dpenv_handle h, const float* in, dpenv_stream s)
+{
+    if (!h || !in) return fail(h, DPENV_EINVAL, "dpenv_set_obs_thrust: NULL argument");
+    DeviceGuard dev_guard(h->device);
+    HIP_TRY(h, hipMemcpyAsync(h->args.S3, in, sizeof(float4) * (size_t)h->cfg.n_envs, hipMemcpyDeviceToDevice, (hipStream_t)s));
+    h->lag_valid = true;
     return DPENV_OK;
 }
 

@@ -81,6 +81,7 @@ struct StepArgs {
     float reset_fraction;
     int32_t reset_acts;       // customEnv.py:179-188: previous thrust drawn at reset
     uint32_t* noise_ctr;      // per-env count of exploration-noise draws made so far (in-kernel sampling)
+    float4* S3;               // thrust columns (o[6..8]) of the observation the LAST closed-loop launch ended with, see PolicyArgs.use_lag
 };
 
 // fused T-step rollout (dpenv_rollout)
@@ -97,12 +98,12 @@ struct RolloutArgs {
 
 // actor-critic evaluated in-kernel (dpenv_policy.hip, dpenv_policy_x.hip)
 struct PolicyArgs {
-    const uint4* frags;       // LDS image, first part: [2 nets][nfrag][64] x 16 B MFMA A-operand fragments (f16), actor then critic;
+    const uint4* frags;       // LDS image, first part: [2 nets][nent] x 16 B MFMA A-operand fragment entries (f16), actor then critic;
                               // split arithmetic: followed by the same for the LOW parts of the weights (W = hi + lo)
     const float* bias;        // [2][nblk][32] f32: bias tiles of the row-blocks after the first layer, accumulator layout
     const float* consts;      // [24] f32 written by the packing kernel: exp(log_std) (core.py:84) | 1 / (exp(log_std) + 1e-8)
                               // (core.py:45) | -log_std - 0.5 log(2 pi) (core.py:45), 8 slots each
-    int32_t nfrag;            // fragments per net = 3 + 3 ks (n_hidden - 1) + ks
+    int32_t nent;             // 16-byte entries of one weight image of one network (compact fragment layout, FragAddr in dpenv_policy_dev.h)
     int32_t nblk;             // bias blocks per net = 3 (n_hidden - 1) + 1
     int32_t ks;               // k-steps of 16 hidden features: 5 (width <= 80) or 6 (width <= 96)
     int32_t act;              // hidden activation: 0 leaky-relu(leak), 1 tanh
@@ -112,6 +113,12 @@ struct PolicyArgs {
     int32_t n_hidden;
     float leak;               // leaky-relu slope (0.2)
     int32_t sample;           // 1: noise == NULL means "draw the exploration noise in the kernel" (policy_noise), not "a = mu"
+    int32_t reset_at_end;     // 1: every env is cut and re-drawn after step T-1 (ppo.py:305-322), boot = V(last obs) unless terminal
+    int32_t use_lag;          // 1: the state was last touched by a closed-loop launch: its first policy input takes the thrust columns
+                              // from S3.  The observation of step t carries the thrust command of step t-1 (customEnv.py:196-205: state_ext is
+                              // filled BEFORE prev_thrust is updated, :126), the state block only the command of step t; without the lagged
+                              // copy a launch that continues an episode would start from an observation the reference never shows its policy.
+    int32_t ws_groups;        // two-wave form: 4 = 512-thread workgroups of 256 envs, 2 = 256-thread workgroups of 128 envs (a SIMD per wave)
     // rollout I/O
     int32_t T;
     const float* noise;       // [T][n][A] standard normal draws, NULL = deterministic (a = mu)
@@ -138,17 +145,25 @@ struct PackNet {
 };
 
 constexpr int POLICY_WS_MAILBOX_BYTES = 4 * (64 * 9 * 5 + 64 * 4 + 64) * 4;   // two-wave form: four groups of mailboxes
+constexpr int POLICY_WS_MAILBOX_X_BYTES = 4 * (64 * 9 * 4 + 64 * 4 + 64) * 4; // the same for the split arithmetics (no row staging area)
+constexpr int PREC_F16 = 0, PREC_F32 = 1, PREC_F32_ACTOR = 2;                 // = DPENV_POLICY_* of include/dpenv.h
 constexpr int POLICY_STAGING_BYTES = 4 * 64 * 9 * 4;                           // one-wave form: four wave-private row areas
 
 }  // namespace dpenv
 
 extern "C" {
 hipError_t dpenv_dev_launch_pack_policy(const dpenv::PackNet* pi, const dpenv::PackNet* v, const float* log_std, int adim, int ks,
-                                        int nfrag, int nblk, int split, void* frags, float* bias, float* consts, hipStream_t s);
+                                        int nent, int nblk, int split, void* frags, float* bias, float* consts, hipStream_t s);
 hipError_t dpenv_dev_launch_policy_forward_x(const dpenv::PolicyArgs* pa, int od, int adim, const float* obs, float* mu,
                                              float* v, int n, hipStream_t s);
 hipError_t dpenv_dev_launch_policy_rollout_x(const dpenv::StepArgs* a, const dpenv::PolicyArgs* pa, int mode, int ext,
                                              hipStream_t s);
+hipError_t dpenv_dev_launch_policy_rollout_ws(const dpenv::StepArgs* a, const dpenv::PolicyArgs* pa, int mode, int ext, hipStream_t s);
+// two-wave form of the split arithmetics (dpenv_policy_xws1.hip: PREC_F32, dpenv_policy_xws2.hip: PREC_F32_ACTOR)
+hipError_t dpenv_dev_launch_policy_rollout_xws_f32(const dpenv::StepArgs* a, const dpenv::PolicyArgs* pa, int mode, int ext,
+                                                   hipStream_t s);
+hipError_t dpenv_dev_launch_policy_rollout_xws_f32_actor(const dpenv::StepArgs* a, const dpenv::PolicyArgs* pa, int mode, int ext,
+                                                         hipStream_t s);
 hipError_t dpenv_dev_launch_policy_forward(const dpenv::PolicyArgs* pa, int od, int adim, const float* obs, float* mu,
                                            float* v, int n, hipStream_t s);
 hipError_t dpenv_dev_launch_policy_rollout(const dpenv::StepArgs* a, const dpenv::PolicyArgs* pa, int mode, int ext,

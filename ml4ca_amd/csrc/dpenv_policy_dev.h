@@ -20,10 +20,43 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 constexpr int PBLOCK = 256;          // 4 waves share one LDS image of the weights
 constexpr int PWAVES = PBLOCK / 64;
 
-__device__ __forceinline__ half8 ldfrag(const uint4* W, int f, int lane)
+// ---- weight image (one per network; the split arithmetic has a second one for the low parts) -----------------------------------
+// MFMA A-operand fragments of 16 bytes per lane, stored COMPACTLY: a fragment holds 32 output rows (lane & 31) x 8 input slots per
+// lane half, but
+//   * the third row-block of an 80-wide layer (KS = 5) has 16 real rows: rows 80..95 are padding whose products nobody reads
+//     (registers 8..15 of that accumulator tile are never consumed) - stored as 2 x 16 entries, lanes r and r + 16 read the same one;
+//   * the output layer has at most 8 real rows - stored as 2 x 8 entries.
+// 28.75 KiB instead of 38 KiB per image for the shipped 9-80-80-80 shape, which is what lets all four images of the split
+// arithmetic AND the two-wave form's mailboxes share the 160 KiB LDS.  Entry offsets (16-byte units) inside an image:
+//   first layer   [0, L0):        block 0 | block 1 | block 2 (B2 entries)
+//   hidden layer  LH each:        block 0: KS x 64 | block 1: KS x 64 | block 2: KS x B2
+//   output layer  KS x 16
+// pack_policy_kernel (dpenv_policy.hip) writes it, FragAddr reads it.
+template <int KS>
+struct FragAddr {
+    static constexpr int B2 = (KS == 5) ? 32 : 64;          // entries of a block-2 fragment
+    static constexpr int L0 = 128 + B2;                     // first layer
+    static constexpr int LH = KS * (128 + B2);              // a hidden -> hidden layer
+    static constexpr int LO = KS * 16;                      // the output layer
+    int lane, lane2, lane_o;                                // this lane's entry inside a full / block-2 / output fragment
+    __device__ __forceinline__ explicit FragAddr(int l)
+        : lane(l), lane2(KS == 5 ? (((l >> 5) << 4) | (l & 15)) : l), lane_o(((l >> 5) << 3) | (l & 7)) {}
+    __device__ __forceinline__ static half8 ld(const uint4* W, int e) { return __builtin_bit_cast(half8, W[e]); }
+    __device__ __forceinline__ half8 first(const uint4* W, int mo) const { return ld(W, mo < 2 ? mo * 64 + lane : 128 + lane2); }
+    __device__ __forceinline__ half8 hid(const uint4* W, int e0, int mo, int ks) const
+    {
+        return ld(W, mo < 2 ? e0 + (mo * KS + ks) * 64 + lane : e0 + 2 * KS * 64 + ks * B2 + lane2);
+    }
+    __device__ __forceinline__ half8 out(const uint4* W, int e0, int ks) const { return ld(W, e0 + ks * 16 + lane_o); }
+    // block 0 of the layer at e0, which is a hidden layer or the output layer (is_out: uniform)
+    __device__ __forceinline__ half8 blk0(const uint4* W, int e0, bool is_out, int ks) const
+    {
+        return ld(W, is_out ? e0 + ks * 16 + lane_o : e0 + ks * 64 + lane);
+    }
+};
+__host__ __device__ constexpr int frag_image_entries(int ks, int n_hidden)
 {
-    const uint4 q = W[f * 64 + lane];
-    return __builtin_bit_cast(half8, q);
+    return (128 + (ks == 5 ? 32 : 64)) + (n_hidden - 1) * ks * (128 + (ks == 5 ? 32 : 64)) + ks * 16;
 }
 
 // bias tile of one 32-row block in accumulator layout: register r of a lane in half h holds output row
@@ -116,12 +149,14 @@ __device__ __forceinline__ void mlp_eval(const uint4* W, const float* B, int n_h
     const float16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     half8 X[KS][2], Y[KS][2], w[KS], wn[KS];
     float16v cb, cbn, p0, p1, q0, q1;
-    int fbase = 3, bblk = 0;                                                 // fragments / bias tiles of the layer being entered
+    const FragAddr<KS> fa(lane);
+    int e0 = FragAddr<KS>::L0, bblk = 0;                                     // image entry / bias tile of the layer being entered
+    int hleft = n_hidden - 1;                                                // hidden -> hidden layers still to come
     // ---- first layer: one k-step, three row-blocks; the weights of the NEXT layer's block 0 are fetched behind it
 #pragma unroll
-    for (int mo = 0; mo < 3; ++mo) w[mo] = ldfrag(W, mo, lane);
+    for (int mo = 0; mo < 3; ++mo) w[mo] = fa.first(W, mo);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(W, fbase + ks, lane);
+    for (int ks = 0; ks < KS; ++ks) wn[ks] = fa.blk0(W, e0, hleft == 0, ks);
     cbn = ldbias(B, bblk, lane);
     {
         const float16v a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0], in0, zero, 0, 0, 0);
@@ -145,7 +180,7 @@ __device__ __forceinline__ void mlp_eval(const uint4* W, const float* B, int n_h
         cb = cbn;
         if (more) {                                                          // a hidden layer: its block 1 is fetched now
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(W, fbase + KS + ks, lane);
+            for (int ks = 0; ks < KS; ++ks) wn[ks] = fa.hid(W, e0, 1, ks);
             cbn = ldbias(B, bblk + 1, lane);
         }
         p0 = cb; p1 = cb;
@@ -173,6 +208,7 @@ __device__ __forceinline__ void mlp_eval(const uint4* W, const float* B, int n_h
     // hidden(): one hidden -> hidden layer, input fragments I, output fragments O (0..3 packed on return, 4.. owed by q)
     auto hidden = [&](half8 (&I)[KS][2], half8 (&O)[KS][2]) __attribute__((always_inline)) {
         head(I, true);
+        const bool next_out = (--hleft == 0);
 #pragma unroll
         for (int mo = 1; mo < 3; ++mo) {
 #pragma unroll
@@ -180,7 +216,7 @@ __device__ __forceinline__ void mlp_eval(const uint4* W, const float* B, int n_h
             cb = cbn;
             // block 2 is fetched during block 1; during block 2, block 0 of the layer after this one (hidden or output)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(W, fbase + (mo + 1) * KS + ks, lane);
+            for (int ks = 0; ks < KS; ++ks) wn[ks] = (mo == 1) ? fa.hid(W, e0, 2, ks) : fa.blk0(W, e0 + FragAddr<KS>::LH, next_out, ks);
             cbn = ldbias(B, bblk + mo + 1, lane);
             float16v c0 = cb, c1 = cb;
 #pragma unroll
@@ -200,7 +236,7 @@ __device__ __forceinline__ void mlp_eval(const uint4* W, const float* B, int n_h
             p0 = c0; p1 = c1;
         }
         q0 = p0; q1 = p1;
-        fbase += 3 * KS;
+        e0 += FragAddr<KS>::LH;
         bblk += 3;
     };
     auto output = [&](half8 (&I)[KS][2]) __attribute__((always_inline)) {
@@ -218,105 +254,6 @@ __device__ __forceinline__ void mlp_eval(const uint4* W, const float* B, int n_h
     for (; l + 1 < n_hidden; l += 2) { hidden(X, Y); hidden(Y, X); }
     if (l < n_hidden) { hidden(X, Y); output(Y); }
     else output(X);
-}
-
-// One MLP for ONE 32-env tile (the tile-split closed loop, dpenv_policy.hip): `in` is that tile's first-layer B fragment
-// (lanes 0..31 carry slots 0..7 of env lane, lanes 32..63 slots 8..15 of env lane - 32).  out[j], j < 4: output row
-// 4 (lane >> 5) + j of env (lane & 31).  The MFMA chain and the packing of a tile are exactly those of mlp_eval (its c0 / c1
-// never mix), so the results are bit-identical to the two-tile evaluation; half the registers, no cross-lane moves.
-template <int KS>
-__device__ __forceinline__ void interleave_stage_tile()
-{
-    __builtin_amdgcn_sched_group_barrier(0x100, KS + 4, 0);
-#pragma unroll
-    for (int k = 0; k < KS; ++k) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-template <int KA>
-__device__ __forceinline__ void mlp_eval_tile(const uint4* W, const float* B, int n_hidden, half8 in, _Float16 leak, float out[4])
-{
-    constexpr int KS = KA & 15, ACT = KA >> 4;
-    const int lane = threadIdx.x & 63;
-    const float16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    half8 b[KS], bn[KS], w[KS];
-#pragma unroll
-    for (int mo = 0; mo < 3; ++mo) w[mo] = ldfrag(W, mo, lane);
-#pragma unroll
-    for (int mo = 0; mo < 3; ++mo) {
-        const float16v c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[mo], in, zero, 0, 0, 0);
-        b[2 * mo] = act_pack<ACT>(c, 0, leak);
-        if (2 * mo + 1 < KS) b[2 * mo + 1] = act_pack<ACT>(c, 1, leak);
-    }
-    int fbase = 3, bblk = 0;
-    half8 wn[KS];
-    for (int l = 1; l < n_hidden; ++l) {
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) w[ks] = ldfrag(W, fbase + ks, lane);
-        float16v cb = ldbias(B, bblk, lane);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(W, fbase + KS + ks, lane);
-        float16v cbn = ldbias(B, bblk + 1, lane);
-        float16v p = cb;                                                    // block 0
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) p = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks], p, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int mo = 1; mo < 3; ++mo) {
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) w[ks] = wn[ks];
-            cb = cbn;
-            if (mo < 2) {
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(W, fbase + 2 * KS + ks, lane);
-                cbn = ldbias(B, bblk + 2, lane);
-            }
-            float16v c = cb;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks], c, 0, 0, 0);
-            bn[2 * (mo - 1)] = act_pack<ACT>(p, 0, leak);
-            bn[2 * (mo - 1) + 1] = act_pack<ACT>(p, 1, leak);
-            interleave_stage_tile<KS>();
-            p = c;
-        }
-        bn[4] = act_pack<ACT>(p, 0, leak);
-        if (5 < KS) bn[KS - 1] = act_pack<ACT>(p, 1, leak);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) b[ks] = bn[ks];
-        fbase += 3 * KS;
-        bblk += 3;
-    }
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) w[ks] = ldfrag(W, fbase + ks, lane);
-    float16v c = ldbias(B, bblk, lane);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ks], b[ks], c, 0, 0, 0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) out[j] = c[j];
-}
-
-// first-layer B fragment of one 32-env tile straight from an observation mailbox (row stride 9 floats): lane l carries
-// slots 8 (l >> 5) .. + 7 of env (l & 31) of the tile; slot 15 is the bias input.  Same f32 -> f16 rounding of the same
-// f32 values as obs_to_frags.
-template <int OD>
-__device__ __forceinline__ half8 tile_frag_from_mailbox(const float* mb, int tile, int lane)
-{
-    const float* row = mb + (tile * 32 + (lane & 31)) * 9;
-    const bool hi = lane >= 32;
-    half8 r;
-    if (!hi) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) r[k] = (_Float16)(k < OD ? row[k] : 0.0f);
-    } else {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) r[k] = (_Float16)0.0f;
-        if (OD > 8) r[0] = (_Float16)row[8];
-        r[7] = (_Float16)1.0f;
-    }
-    return r;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -361,13 +298,14 @@ __device__ __forceinline__ void mlp_eval2(const uint4* Wp, const uint4* Wv, cons
 {
     constexpr int KS = KA & 15;
     const int lane = threadIdx.x & 63;
+    const FragAddr<KS> fa(lane);
     half8 bP[KS][2], bV[KS][2], nP[KS][2], nV[KS][2], w[KS], wn[KS];
     Acc2 pend;                                   // the block whose activation/packing is still to be issued
     // ---- first layer: one k-step per block (2 MFMAs against ~48 VALU): VALU-bound whatever the order -------------
     {
         half8 wp[3], wv[3];
 #pragma unroll
-        for (int mo = 0; mo < 3; ++mo) { wp[mo] = ldfrag(Wp, mo, lane); wv[mo] = ldfrag(Wv, mo, lane); }
+        for (int mo = 0; mo < 3; ++mo) { wp[mo] = fa.first(Wp, mo); wv[mo] = fa.first(Wv, mo); }
         const float16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         auto first = [&](const half8& wf) {
             Acc2 r;
@@ -385,14 +323,15 @@ __device__ __forceinline__ void mlp_eval2(const uint4* Wp, const uint4* Wv, cons
         }
     }
     // bV[4] (and bV[5]) are still pending in `pend`
-    int fbase = 3, bblk = 0;
+    int e0 = FragAddr<KS>::L0, bblk = 0;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) w[ks] = ldfrag(Wp, fbase + ks, lane);
+    for (int ks = 0; ks < KS; ++ks) w[ks] = fa.blk0(Wp, e0, n_hidden == 1, ks);
     float16v cb = ldbias(Bp, bblk, lane), cbn;
     for (int l = 1; l < n_hidden; ++l) {
+        const bool next_out = (l + 1 == n_hidden);
         // stage P0: needs bP only; the critic's last block of the layer before is packed underneath it
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(Wv, fbase + ks, lane);
+        for (int ks = 0; ks < KS; ++ks) wn[ks] = fa.hid(Wv, e0, 0, ks);
         cbn = ldbias(Bv, bblk, lane);
         Acc2 cur = mfma_block<KS>(w, bP, cb);
         pack_block<KA>(pend, bV, 2, leak);
@@ -406,11 +345,11 @@ __device__ __forceinline__ void mlp_eval2(const uint4* Wp, const uint4* Wv, cons
             cb = cbn;
             if (mo < 2) {
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(Wp, fbase + (mo + 1) * KS + ks, lane);
+                for (int ks = 0; ks < KS; ++ks) wn[ks] = fa.hid(Wp, e0, mo + 1, ks);
                 cbn = ldbias(Bp, bblk + mo + 1, lane);
             } else {
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(Wp, fbase + 3 * KS + ks, lane);   // next layer's (or the output's) P0
+                for (int ks = 0; ks < KS; ++ks) wn[ks] = fa.blk0(Wp, e0 + FragAddr<KS>::LH, next_out, ks);   // next layer's (or the output's) P0
                 cbn = ldbias(Bp, bblk + 3, lane);
             }
             cur = mfma_block<KS>(w, bV, cb);
@@ -423,7 +362,7 @@ __device__ __forceinline__ void mlp_eval2(const uint4* Wp, const uint4* Wv, cons
                 for (int ks = 0; ks < KS; ++ks) w[ks] = wn[ks];
                 cb = cbn;
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(Wv, fbase + (mo + 1) * KS + ks, lane);
+                for (int ks = 0; ks < KS; ++ks) wn[ks] = fa.hid(Wv, e0, mo + 1, ks);
                 cbn = ldbias(Bv, bblk + mo + 1, lane);
                 cur = mfma_block<KS>(w, bP, cb);
                 pack_block<KA>(prev, nV, mo, leak);
@@ -439,12 +378,12 @@ __device__ __forceinline__ void mlp_eval2(const uint4* Wp, const uint4* Wv, cons
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) w[ks] = wn[ks];
         cb = cbn;
-        fbase += 3 * KS;
+        e0 += FragAddr<KS>::LH;
         bblk += 3;
     }
     // ---- output layer: one row-block per network --------------------------------------------------------------
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) wn[ks] = ldfrag(Wv, fbase + ks, lane);
+    for (int ks = 0; ks < KS; ++ks) wn[ks] = fa.out(Wv, e0, ks);
     cbn = ldbias(Bv, bblk, lane);
     const Acc2 op = mfma_block<KS>(w, bP, cb);
     pack_block<KA>(pend, bV, 2, leak);
@@ -551,11 +490,11 @@ __device__ __forceinline__ Vessel launch_vessel(const StepArgs& a, int il)
     return ve;
 }
 
-// LDS image: [2][nfrag][64] weight fragments (16 B each) | [2][nblk][32] bias floats | wave-private row staging
+// LDS image: [2 or 4][nent] weight-fragment entries (16 B each, FragAddr) | [2][nblk][32] bias floats | wave-private row staging
 template <int THREADS>
 __device__ __forceinline__ void stage_weights_n(uint4* lds, const PolicyArgs& pa)
 {
-    const int total = 2 * pa.nfrag * 64 * (1 + pa.split);
+    const int total = 2 * pa.nent * (1 + pa.split);
     for (int k = threadIdx.x; k < total; k += THREADS) lds[k] = pa.frags[k];
     float* lb = (float*)(lds + total);
     for (int k = threadIdx.x; k < 2 * pa.nblk * 32; k += THREADS) lb[k] = pa.bias[k];
@@ -565,7 +504,7 @@ __device__ __forceinline__ void stage_weights(uint4* lds, const PolicyArgs& pa) 
 
 __device__ __forceinline__ int policy_lds_io_offset_floats(const PolicyArgs& pa)      // after fragments and biases
 {
-    return 2 * pa.nfrag * 64 * 4 * (1 + pa.split) + 2 * pa.nblk * 32;
+    return 2 * pa.nent * 4 * (1 + pa.split) + 2 * pa.nblk * 32;
 }
 
 // wave-private AoS row I/O through LDS for a 64-env slice of a 256-thread workgroup
@@ -589,6 +528,23 @@ __device__ __forceinline__ void wave_rows_from_regs(float* lds_w, const float pr
     lds_order<64>();
 #pragma unroll
     for (int k = 0; k < W; ++k) row[k] = lds_w[lane * W + k];
+}
+
+
+// a lane's own row, straight to memory (36 / 28-byte rows: slower stores than the LDS-transposed ones, same bytes) - where the LDS
+// has no room for row staging
+template <int W>
+__device__ __forceinline__ void store_row_direct(void* dst, int64_t row, const float* v, bool bf16)
+{
+    if (bf16) {
+        uint16_t* p = (uint16_t*)dst + row * W;
+#pragma unroll
+        for (int k = 0; k < W; ++k) p[k] = f2bf(v[k]);
+    } else {
+        float* p = (float*)dst + row * W;
+#pragma unroll
+        for (int k = 0; k < W; ++k) p[k] = v[k];
+    }
 }
 
 
@@ -677,10 +633,18 @@ template <int OD>
 __device__ __forceinline__ void obs_to_frags_x(const float o[9], SplitIn& in)
 {
     uint32_t H[8], L[8];
+    // as in obs_to_frags: what is split is the MATERIALISED f32 observation, whichever kernel (or wave) produced it - otherwise the
+    // compiler may fold an observation's last FMA into the f16 conversion in one launch form and not in another
+    float x[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        x[k] = o[k];
+        if (k < OD) asm volatile("" : "+v"(x[k]));
+    }
 #pragma unroll
     for (int k = 0; k < 16; k += 2) {
-        const float x0 = (k < OD) ? o[k < 9 ? k : 8] : 0.0f;
-        const float x1 = (k + 1 < OD) ? o[k + 1 < 9 ? k + 1 : 8] : (k + 1 == 15 ? 1.0f : 0.0f);     // slot 15: the bias input (its low part is 0)
+        const float x0 = (k < OD) ? x[k < 9 ? k : 8] : 0.0f;
+        const float x1 = (k + 1 < OD) ? x[k + 1 < 9 ? k + 1 : 8] : (k + 1 == 15 ? 1.0f : 0.0f);     // slot 15: the bias input (its low part is 0)
         split_pair(x0, x1, H[k >> 1], L[k >> 1]);
     }
     const uint4 ph = {H[0], H[1], H[2], H[3]}, qh = {H[4], H[5], H[6], H[7]}, pl = {L[0], L[1], L[2], L[3]}, ql = {L[4], L[5], L[6], L[7]};
@@ -743,6 +707,8 @@ __device__ __forceinline__ void mlp_eval_x(const uint4* Wh, const uint4* Wl, con
     struct Frag { uint32_t h[4], l[4]; };                 // one B fragment: high and low f16 parts, 8 features each
     Frag X[KS][2], Y[KS][2];
     float16v p0, p1, q0, q1;
+    const float* B2 = B;                                  // the same bias tiles through a pointer the compiler cannot see through:
+    asm volatile("" : "+v"(B2));                          // two reads stay two reads (see head())
     auto FH = [](const Frag& f) { const uint4 q = {f.h[0], f.h[1], f.h[2], f.h[3]}; return __builtin_bit_cast(half8, q); };
     auto FL = [](const Frag& f) { const uint4 q = {f.l[0], f.l[1], f.l[2], f.l[3]}; return __builtin_bit_cast(half8, q); };
     // slot: three MFMAs of accumulator c with weights (wh, wl) and input fragment b; between them, unit `qq` (four activations:
@@ -799,7 +765,8 @@ __device__ __forceinline__ void mlp_eval_x(const uint4* Wh, const uint4* Wl, con
             leaky_split4(x, leak, &d.h[2 * qq], &d.l[2 * qq]);
         }
     };
-    int fbase = 3, bblk = 0;
+    const FragAddr<KS> fa(lane);
+    int e0 = FragAddr<KS>::L0, bblk = 0;
     // ---- first layer (one k-step): blocks 0 and 1, then block 2 beside the split of block 0; the split of block 1 is exposed
     {
         Frag I0, I1;
@@ -807,8 +774,8 @@ __device__ __forceinline__ void mlp_eval_x(const uint4* Wh, const uint4* Wl, con
         const uint4 h1 = __builtin_bit_cast(uint4, in.h1), l1 = __builtin_bit_cast(uint4, in.l1);
         I0.h[0] = h0.x; I0.h[1] = h0.y; I0.h[2] = h0.z; I0.h[3] = h0.w; I0.l[0] = l0.x; I0.l[1] = l0.y; I0.l[2] = l0.z; I0.l[3] = l0.w;
         I1.h[0] = h1.x; I1.h[1] = h1.y; I1.h[2] = h1.z; I1.h[3] = h1.w; I1.l[0] = l1.x; I1.l[1] = l1.y; I1.l[2] = l1.z; I1.l[3] = l1.w;
-        const half8 w0h = ldfrag(Wh, 0, lane), w0l = ldfrag(Wl, 0, lane), w1h = ldfrag(Wh, 1, lane), w1l = ldfrag(Wl, 1, lane);
-        const half8 w2h = ldfrag(Wh, 2, lane), w2l = ldfrag(Wl, 2, lane);
+        const half8 w0h = fa.first(Wh, 0), w0l = fa.first(Wl, 0), w1h = fa.first(Wh, 1), w1l = fa.first(Wl, 1);
+        const half8 w2h = fa.first(Wh, 2), w2l = fa.first(Wl, 2);
         float16v a0 = zero, a1 = zero, c0 = zero, c1 = zero;
         Frag none;
         slot(a0, w0h, w0l, I0, false, zero, 0, 0, none);
@@ -830,48 +797,49 @@ __device__ __forceinline__ void mlp_eval_x(const uint4* Wh, const uint4* Wl, con
     __builtin_amdgcn_sched_barrier(0);
     // head: block 0 of the layer being entered.  I[0..3] are complete; q0 / q1 (the last block of the layer before) still owe I[4]
     // (and I[5]): their units ride on the first k-steps.  Weights: one k-step (wh, wl) is fetched while the one before is multiplied.
-    auto head = [&](Frag (&I)[KS][2]) __attribute__((always_inline)) {
-        const float16v cb = ldbias(B, bblk, lane);
-        p0 = cb; p1 = cb;
-        half8 wh = ldfrag(Wh, fbase, lane), wl = ldfrag(Wl, fbase, lane);
+    auto head = [&](Frag (&I)[KS][2], bool is_out) __attribute__((always_inline)) {
+        // each accumulator starts from its OWN read of the bias tile (a 64-byte LDS broadcast per lane half): a shared copy would
+        // be 16 more live registers for the whole block and 32 v_mov - this evaluation runs at the edge of the register file
+        p0 = ldbias(B, bblk, lane);
+        p1 = ldbias(B2, bblk, lane);
+        half8 wh = fa.blk0(Wh, e0, is_out, 0), wl = fa.blk0(Wl, e0, is_out, 0);
         constexpr int NU = 4 * (KS - 4);                                    // pending units: 4 (KS = 5) or 8 (KS = 6)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             half8 nwh = wh, nwl = wl;
-            if (ks + 1 < KS) { nwh = ldfrag(Wh, fbase + ks + 1, lane); nwl = ldfrag(Wl, fbase + ks + 1, lane); }
+            if (ks + 1 < KS) { nwh = fa.blk0(Wh, e0, is_out, ks + 1); nwl = fa.blk0(Wl, e0, is_out, ks + 1); }
             const int u0 = 2 * ks, u1 = 2 * ks + 1;                          // unit u: tile u & 1, quarter (u >> 1) & 1, half u >> 2
             slot(p0, wh, wl, I[ks][0], ks < 4 && u0 < NU, (u0 & 1) ? q1 : q0, u0 >> 2, (u0 >> 1) & 1, I[4 + (u0 >> 2) < KS ? 4 + (u0 >> 2) : 4][u0 & 1]);
             slot(p1, wh, wl, I[ks][1], ks < 4 && u1 < NU, (u1 & 1) ? q1 : q0, u1 >> 2, (u1 >> 1) & 1, I[4 + (u1 >> 2) < KS ? 4 + (u1 >> 2) : 4][u1 & 1]);
             wh = nwh; wl = nwl;
         }
-        keep_alive(q0); keep_alive(q1); keep_alive(cb);
+        keep_alive(q0); keep_alive(q1);
     };
     auto hidden = [&](Frag (&I)[KS][2], Frag (&O)[KS][2]) __attribute__((always_inline)) {
-        head(I);
+        head(I, false);
 #pragma unroll
         for (int mo = 1; mo < 3; ++mo) {
-            const float16v cb = ldbias(B, bblk + mo, lane);
-            float16v c0 = cb, c1 = cb;
-            half8 wh = ldfrag(Wh, fbase + mo * KS, lane), wl = ldfrag(Wl, fbase + mo * KS, lane);
+            float16v c0 = ldbias(B, bblk + mo, lane), c1 = ldbias(B2, bblk + mo, lane);
+            half8 wh = fa.hid(Wh, e0, mo, 0), wl = fa.hid(Wl, e0, mo, 0);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 half8 nwh = wh, nwl = wl;
-                if (ks + 1 < KS) { nwh = ldfrag(Wh, fbase + mo * KS + ks + 1, lane); nwl = ldfrag(Wl, fbase + mo * KS + ks + 1, lane); }
+                if (ks + 1 < KS) { nwh = fa.hid(Wh, e0, mo, ks + 1); nwl = fa.hid(Wl, e0, mo, ks + 1); }
                 // the eight units of block mo - 1 (p0 / p1) -> O[2 (mo - 1)], O[2 (mo - 1) + 1]
                 const int u0 = 2 * ks, u1 = 2 * ks + 1;
                 slot(c0, wh, wl, I[ks][0], u0 < 8, (u0 & 1) ? p1 : p0, (u0 >> 2) & 1, (u0 >> 1) & 1, O[2 * (mo - 1) + ((u0 >> 2) & 1)][u0 & 1]);
                 slot(c1, wh, wl, I[ks][1], u1 < 8, (u1 & 1) ? p1 : p0, (u1 >> 2) & 1, (u1 >> 1) & 1, O[2 * (mo - 1) + ((u1 >> 2) & 1)][u1 & 1]);
                 wh = nwh; wl = nwl;
             }
-            keep_alive(p0); keep_alive(p1); keep_alive(cb);
+            keep_alive(p0); keep_alive(p1);
             p0 = c0; p1 = c1;
         }
         q0 = p0; q1 = p1;
-        fbase += 3 * KS;
+        e0 += FragAddr<KS>::LH;
         bblk += 3;
     };
     auto output = [&](Frag (&I)[KS][2]) __attribute__((always_inline)) {
-        head(I);
+        head(I, true);
         keep_alive(p0); keep_alive(p1);                  // only rows 0..7 are read below; the next asm statement may be close
 #pragma unroll
         for (int j = 0; j < 4; ++j) {

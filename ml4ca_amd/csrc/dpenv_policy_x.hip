@@ -11,20 +11,6 @@
 
 namespace dpenv {
 
-template <int W>
-__device__ __forceinline__ void store_row_direct(void* dst, int64_t row, const float* v, bool bf16)
-{
-    if (bf16) {
-        uint16_t* p = (uint16_t*)dst + row * W;
-#pragma unroll
-        for (int k = 0; k < W; ++k) p[k] = f2bf(v[k]);
-    } else {
-        float* p = (float*)dst + row * W;
-#pragma unroll
-        for (int k = 0; k < W; ++k) p[k] = v[k];
-    }
-}
-
 struct SplitNets {
     const uint4 *Wpi_h, *Wv_h, *Wpi_l, *Wv_l;
     const float *Bpi, *Bv;
@@ -34,10 +20,10 @@ __device__ __forceinline__ SplitNets split_nets(const uint4* lds_w, const Policy
 {
     SplitNets s;
     s.Wpi_h = lds_w;
-    s.Wv_h = lds_w + pa.nfrag * 64;
-    s.Wpi_l = lds_w + 2 * pa.nfrag * 64;
-    s.Wv_l = lds_w + 3 * pa.nfrag * 64;
-    s.Bpi = (const float*)(lds_w + 4 * pa.nfrag * 64);
+    s.Wv_h = lds_w + pa.nent;
+    s.Wpi_l = lds_w + 2 * pa.nent;
+    s.Wv_l = lds_w + 3 * pa.nent;
+    s.Bpi = (const float*)(lds_w + 4 * pa.nent);
     s.Bv = s.Bpi + pa.nblk * 32;
     return s;
 }
@@ -116,6 +102,10 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_x_kernel(const StepArgs
         bool same_;
         make_obs(s.N, s.E, s.psi, s.u, s.v, s.r, s.refN, s.refE, s.refPsi, s.pt, a.wrap_mode == WRAP_REFERENCE, o, sr_, cr_, same_);
     }
+    if (EXT && pa.use_lag) {                                     // continue the episode with the observation the last launch ended with
+        const float4 lg = a.S3[il];
+        o[6] = lg.x; o[7] = lg.y; o[8] = lg.z;
+    }
     SplitIn in;
     float vout[8], mu[8];
     obs_to_frags_x<OD>(o, in);
@@ -157,7 +147,8 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_x_kernel(const StepArgs
         if (a.current_drift) current_drift_step(a, cur, vc0, beta0, a.env_id_base + i);
 #pragma unroll
         for (int k = 0; k < 9; ++k) o[k] = out.o[k];
-        const bool do_reset = a.auto_reset && out.d != 0u && live;
+        // ppo.py:305-322 with reset_at_end: after the LAST step of the block every env is cut and re-drawn, ended or not
+        const bool do_reset = ((a.auto_reset && out.d != 0u) || (pa.reset_at_end && t == pa.T - 1)) && live;
         float v_pre = 0.0f;
         if (__ballot(do_reset) != 0ull) {                       // wave-uniform
             // the critic once more, on the pre-reset observation - only if an env of the wave was CUT (time limit): a terminated
@@ -193,6 +184,7 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_x_kernel(const StepArgs
         store_row_direct<OD>(pa.last_obs, i, o, a.obs_bf16 != 0);
         pa.last_val[i] = v_t;
         store_env(a, i, s, rf_dirty);
+        if (EXT) a.S3[i] = make_float4(o[6], o[7], o[8], 0.0f);
         if (ep_dirty) a.episode[i] = (int)episode;
         if (a.current_drift) { a.cur_vc[i] = cur.vc; a.cur_beta[i] = cur.beta; a.drift_ctr[i] = cur.ctr; }
         if (draw) a.noise_ctr[i] = nctr;
@@ -203,7 +195,7 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_x_kernel(const StepArgs
 
 using namespace dpenv;
 
-static size_t lds_bytes_x(const PolicyArgs& pa) { return (size_t)4 * pa.nfrag * 64 * 16 + (size_t)2 * pa.nblk * 32 * 4; }
+static size_t lds_bytes_x(const PolicyArgs& pa) { return (size_t)4 * pa.nent * 16 + (size_t)2 * pa.nblk * 32 * 4; }
 
 extern "C" hipError_t dpenv_dev_launch_policy_forward_x(const PolicyArgs* pa, int od, int adim, const float* obs, float* mu, float* v,
                                                         int n, hipStream_t s)
@@ -227,6 +219,9 @@ extern "C" hipError_t dpenv_dev_launch_policy_forward_x(const PolicyArgs* pa, in
     } while (0)
     if ((pa->ks != 5 && pa->ks != 6) || (pa->act != 0 && pa->act != 1) || !pa->split) return hipErrorInvalidValue;
     const int ka = pa->ks + 16 * pa->act;
+#ifdef DPENV_DEV_FAST
+    if (od == 9 && adim == 7 && ka == 5) FWD_K(9, 7, 5);
+#else
     if (od == 9 && adim == 7) FWD(9, 7);
     if (od == 9 && adim == 5) FWD(9, 5);
     if (od == 9 && adim == 6) FWD(9, 6);
@@ -234,6 +229,7 @@ extern "C" hipError_t dpenv_dev_launch_policy_forward_x(const PolicyArgs* pa, in
     if (od == 6 && adim == 5) FWD(6, 5);
     if (od == 6 && adim == 6) FWD(6, 6);
     if (od == 6 && adim == 3) FWD(6, 3);
+#endif
 #undef FWD_K
 #undef FWD
     return hipErrorInvalidValue;
@@ -254,16 +250,26 @@ template <int MODE>
 static hipError_t launch_x_mode(const StepArgs& a, const PolicyArgs& pa, bool ext, hipStream_t s)
 {
     if ((pa.ks != 5 && pa.ks != 6) || (pa.act != 0 && pa.act != 1) || !pa.split) return hipErrorInvalidValue;
+#ifdef DPENV_DEV_FAST
+    if (pa.ks != 5 || pa.act != 0 || !ext) return hipErrorInvalidValue;
+    return launch_x_one<MODE, true, 5>(a, pa, s);
+#else
     switch (pa.ks + 16 * pa.act) {
     case 5: return ext ? launch_x_one<MODE, true, 5>(a, pa, s) : launch_x_one<MODE, false, 5>(a, pa, s);
     case 6: return ext ? launch_x_one<MODE, true, 6>(a, pa, s) : launch_x_one<MODE, false, 6>(a, pa, s);
     case 21: return ext ? launch_x_one<MODE, true, 21>(a, pa, s) : launch_x_one<MODE, false, 21>(a, pa, s);
     default: return ext ? launch_x_one<MODE, true, 22>(a, pa, s) : launch_x_one<MODE, false, 22>(a, pa, s);
     }
+#endif
 }
 
 extern "C" hipError_t dpenv_dev_launch_policy_rollout_x(const StepArgs* a, const PolicyArgs* pa, int mode, int ext, hipStream_t s)
 {
+    if (pa->ws) return pa->critic_f16 ? dpenv_dev_launch_policy_rollout_xws_f32_actor(a, pa, mode, ext, s)
+                                      : dpenv_dev_launch_policy_rollout_xws_f32(a, pa, mode, ext, s);
+#ifdef DPENV_DEV_FAST
+    return mode == MODE_FINAL_CONT ? launch_x_mode<MODE_FINAL_CONT>(*a, *pa, ext, s) : hipErrorInvalidValue;
+#else
     switch (mode) {
     case MODE_FULL: return launch_x_mode<MODE_FULL>(*a, *pa, ext, s);
     case MODE_SIMPLE: return launch_x_mode<MODE_SIMPLE>(*a, *pa, ext, s);
@@ -272,4 +278,5 @@ extern "C" hipError_t dpenv_dev_launch_policy_rollout_x(const StepArgs* a, const
     case MODE_FINAL_CONT: return launch_x_mode<MODE_FINAL_CONT>(*a, *pa, ext, s);
     }
     return hipErrorInvalidValue;
+#endif
 }

@@ -117,3 +117,90 @@ def mean_across_ranks(x, group=None):
         dist.all_reduce(t, group=group)
         t /= dist.get_world_size(group)
     return t
+
+
+# ---- episode exchange, compact and pipelined ------------------------------------------------------------------------
+# The reference never moves trajectories between ranks: every rank fills its own TrajectoryBuffer (ppo.py:226,289-322), only the
+# 24 bytes of mpi_statistics_scalar (mpi_tools.py:83-87) and the gradients (mpi_tf.py:29-62) cross.  BASELINE.json config 4 asks
+# for an all-gather of the trajectory buffers at episode boundaries, so that every rank can update on the global batch; what
+# that update reads is obs | act | adv | ret | logp (ppo.py:93-105) - rew, val and the bootstrap values only feed the LOCAL GAE scan
+# (each rank scans its own env columns; finish_path, ppo.py:65-91, never looks across envs).  So the payload is
+#   obs 9 x bf16 (18 B, the rows config 5 already writes) or f32 (36 B) | act 28 | logp 4   - known as soon as a step is done
+#   adv 4 | ret 4                                                                          - known after the scan
+# = 58 B per env-step with bf16 rows (76 B with f32 rows) instead of 76 B + a remote GAE, and the first group can cross xGMI WHILE the episode is
+# still being rolled out: EpisodeExchange gathers it chunk by chunk (rows [t0, t1) of the blocks are contiguous) on the
+# backend's own stream under the next chunk's launch; only the last chunk and the 8 B of adv | ret are exposed.
+STEP_FIELDS = ('obs', 'act', 'logp')      # complete when the step is
+SCAN_FIELDS = ('adv', 'ret')              # complete after GAE + normalisation
+
+
+class EpisodeExchange(object):
+    """All-gather of one episode's update inputs, issued piecewise.
+
+        ex = EpisodeExchange(buf.exchange_blocks(), n_chunks=4)   # {'obs','act','logp','adv','ret'}: [T, n_local, ...] each
+        for c in range(4): buf.collect(env, rows=ex.rows(c)); ex.post_steps(c)       # async: crosses under the next launch
+        buf.finish(); buf.get(); ex.post_scan()
+        glob = ex.wait()                                          # {'obs': [C, world, T / C, n_local, 9], ...}
+
+    Rows [t0, t1) of a [T, n, ...] block are one contiguous range, so a chunk is gathered straight from where the kernel wrote it
+    with one all_gather_into_tensor into out[name][c] = [world, T / C, n_local, ...] (contiguous: no staging copy on any backend).
+    The output is therefore chunk-major; an update treats the samples as a bag, so the order only has to be the same for every
+    field - ``flat(name)`` gives [C * world * T / C * n_local, ...], ``episode_order(name)`` the [world, T, n_local, ...] view order
+    of gather_rollout (a copy; tests use it: same values bit for bit)."""
+
+    def __init__(self, blocks, n_chunks=1, group=None, out=None):
+        import torch
+        import torch.distributed as dist
+        self.blocks, self.group, self.C = blocks, group, int(n_chunks)
+        self.multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if self.multi else 1
+        self.T = next(iter(blocks.values())).shape[0]
+        if self.T % self.C:
+            raise ValueError('n_chunks must divide T (%d %% %d)' % (self.T, self.C))
+        self.Tc = self.T // self.C
+        self.out = out if out is not None else {
+            k: torch.empty((self.C, self.world, self.Tc) + tuple(b.shape[1:]), dtype=b.dtype, device=b.device) for k, b in blocks.items()}
+        self.works = []
+
+    def rows(self, c):
+        return c * self.Tc, (c + 1) * self.Tc
+
+    def _post(self, names, c):
+        import torch.distributed as dist
+        t0, t1 = self.rows(c)
+        for k in names:
+            src = self.blocks[k][t0:t1]
+            dst = self.out[k][c]
+            if not self.multi:
+                dst[0].copy_(src)
+                continue
+            flat = dst.view((self.world * self.Tc,) + tuple(src.shape[1:]))
+            self.works.append(dist.all_gather_into_tensor(flat, src, group=self.group, async_op=True))
+
+    def post_steps(self, c):
+        """chunk c of obs | act | logp: call right after the launch that wrote those rows was issued (stream-ordered on GPUs)"""
+        self._post([k for k in STEP_FIELDS if k in self.blocks], c)
+
+    def post_scan(self):
+        """adv | ret of the whole episode, after RolloutBuffer.finish() / get()"""
+        for c in range(self.C):
+            self._post([k for k in SCAN_FIELDS if k in self.blocks], c)
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+        return self.out
+
+    def flat(self, name):
+        o = self.out[name]
+        return o.reshape((-1,) + tuple(o.shape[4:]))
+
+    def episode_order(self, name):
+        """[C, world, Tc, n, ...] -> [world, T, n, ...] (copy)"""
+        o = self.out[name]
+        return o.movedim(0, 1).reshape((self.world, self.T) + tuple(o.shape[3:]))
+
+    @staticmethod
+    def bytes_per_env_step(blocks):
+        return sum(b[0, 0].numel() * b.element_size() for b in blocks.values())

@@ -314,12 +314,43 @@ class BatchedRevoltEnv(object):
         counters = self._chk(counters, (2, self.n_envs), torch.int32, 'counters')
         _lib.check(self.lib.dpenv_set_state(self._h, self._ptr(state), self._ptr(counters), self._stream()), self._h)
 
-    def set_current(self, vc, beta):
-        """Per-env constant current: speed [m/s] and NED direction [rad] (results/.../current_box_test/plot_pos.py:78)."""
+    def get_rng_counters(self):
+        """(noise_ctr, drift_ctr): int32 [n] draws made so far of the in-kernel exploration noise and of the current drift (uint32
+        bits).  With get_state() and get_current() a complete checkpoint: restoring all of them reproduces sampled rollouts."""
+        torch = _torch()
+        nc = torch.empty(self.n_envs, dtype=torch.int32, device=self.device)
+        dc = torch.empty(self.n_envs, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.dpenv_get_rng_counters(self._h, self._ptr(nc), self._ptr(dc), self._stream()), self._h)
+        return nc, dc
+
+    def set_rng_counters(self, noise_ctr=None, drift_ctr=None):
+        torch = _torch()
+        self._chk(noise_ctr, (self.n_envs,), torch.int32, 'noise_ctr')
+        self._chk(drift_ctr, (self.n_envs,), torch.int32, 'drift_ctr')
+        _lib.check(self.lib.dpenv_set_rng_counters(self._h, self._ptr(noise_ctr), self._ptr(drift_ctr), self._stream()), self._h)
+
+    def get_obs_thrust(self):
+        """float32 [n, 4]: thrust columns of the observation the last closed-loop launch ended with (a mid-episode checkpoint needs
+        them: the observation lags the stored thrust command by one step, customEnv.py:196-205,126), or None if the next launch would
+        start from the state block alone (after reset / step / set_state)."""
+        torch = _torch()
+        t = torch.empty((self.n_envs, 4), dtype=torch.float32, device=self.device)
+        rc = self.lib.dpenv_get_obs_thrust(self._h, self._ptr(t), self._stream())
+        return t if rc == _lib.OK else None
+
+    def set_obs_thrust(self, t):
+        self._chk(t, (self.n_envs, 4), _torch().float32, 'obs_thrust')
+        _lib.check(self.lib.dpenv_set_obs_thrust(self._h, self._ptr(t), self._stream()), self._h)
+
+    def set_current(self, vc, beta, present_only=False):
+        """Per-env constant current: speed [m/s] and NED direction [rad] (results/.../current_box_test/plot_pos.py:78).  They are
+        both the present value and the mean a drifting current reverts to; present_only=True restores only the present values
+        (what get_current returned: checkpoints of a drifting current)."""
         torch = _torch()
         self._chk(vc, (self.n_envs,), torch.float32, 'vc')
         self._chk(beta, (self.n_envs,), torch.float32, 'beta')
-        _lib.check(self.lib.dpenv_set_current(self._h, self._ptr(vc), self._ptr(beta), self._stream()), self._h)
+        fn = self.lib.dpenv_set_current_present if present_only else self.lib.dpenv_set_current
+        _lib.check(fn(self._h, self._ptr(vc), self._ptr(beta), self._stream()), self._h)
 
     def get_current(self):
         """Present (vc, beta) of every env; differs from what set_current gave only with current_drift."""

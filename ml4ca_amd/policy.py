@@ -176,14 +176,15 @@ def policy_forward(env, obs):
     return mu, v
 
 
-def policy_rollout(env, T, noise=None, switch_steps=(), refs=None, out=None, sample=None):
+def policy_rollout(env, T, noise=None, switch_steps=(), refs=None, out=None, sample=None, reset_at_end=False):
     """T steps of (actor -> sample -> env.step -> critic) in ONE launch: the rollout loop ppo.py:289-322 for every env.
 
     noise: float32 [T, n, act_dim] standard-normal draws (a = mu + exp(log_std) * noise, core.py:85), or None.  With noise None:
     sample=True draws the exploration noise inside the kernel (Philox keyed by the seed, the global env id and the number of
     actions the env has sampled so far - like tf.random_normal inside the reference's graph, core.py:85, but reproducible and
     independent of the rank count); sample=False / None is the deterministic policy a = mu (test_policy.py:90).  Returns a dict of blocks: obs [T,n,od] (policy inputs), act [T,n,ad],
-    rew, val, logp, boot [T,n], done [T,n] uint8, last_obs [n,od], last_val [n].  GAE: rollout.gae(rew, val, end=done, boot=boot)."""
+    rew, val, logp, boot [T,n], done [T,n] uint8, last_obs [n,od], last_val [n].  GAE: rollout.gae(rew, val, end=done, boot=boot).
+    reset_at_end: the reference's epoch boundary (ppo.py:305-322): every env is cut and re-drawn after step T-1 (dpenv.h)."""
     torch = _torch()
     n, od, ad = env.n_envs, env.num_states, env.num_actions
     dev = env.device
@@ -211,5 +212,6 @@ def policy_rollout(env, T, noise=None, switch_steps=(), refs=None, out=None, sam
         io.switch_step[j] = int(st)
     io.refs = refs.data_ptr() if k else None
     io.sample = 1 if (sample and noise is None) else 0
+    io.reset_at_end = 1 if reset_at_end else 0
     _lib.check(env.lib.dpenv_policy_rollout(env._h, C.byref(io), env._stream()), env._h)
     return out

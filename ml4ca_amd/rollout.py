@@ -47,13 +47,15 @@ def _workspace(dev, n):
     return w
 
 
-def gae(rew, val, end=None, boot=None, last_val=None, gamma=0.99, lam=0.97, out=None, stats=None):
+def gae(rew, val, end=None, boot=None, last_val=None, gamma=0.99, lam=0.97, out=None, stats=None, workspace=None):
     """TrajectoryBuffer.finish_path (ppo.py:65-91) for every env column of a [T, n] rollout.
 
     A path ends after step t of env i where end[t, i] != 0, and always after T-1.  The value appended at a path
     end (ppo.py:82-83) is boot[t, i] if boot is given, else 0 at inner ends and last_val[i] (default 0) at T-1.
     Returns (adv, ret), both [T, n] float32.  stats: optional float64[2] cuda tensor that receives (sum adv, sum adv^2) from the
-    same pass (deterministic; feed it to normalize_advantages)."""
+    same pass (deterministic; feed it to normalize_advantages).  workspace: float64 scratch of dpenv_gae_workspace_bytes(n) bytes for
+    the per-workgroup partial sums; default one per device, which two streams of one device must not share - a RolloutBuffer
+    brings its own."""
     torch = _torch()
     lib = _lib.load()
     T, n = rew.shape
@@ -67,7 +69,7 @@ def gae(rew, val, end=None, boot=None, last_val=None, gamma=0.99, lam=0.97, out=
     _req(ret, (T, n), torch.float32, 'ret')
     _req(stats, (2,), torch.float64, 'stats')
     with torch.cuda.device(rew.device):
-        ws = _workspace(rew.device, n) if stats is not None else None
+        ws = (workspace if workspace is not None else _workspace(rew.device, n)) if stats is not None else None
         _lib.check(lib.dpenv_gae_stats(_p(rew), _p(val), _p(end), _p(boot), _p(last_val), T, n, gamma, lam, _p(adv), _p(ret),
                                        _p(ws), _p(stats), _s(rew)))
     return adv, ret
@@ -155,26 +157,63 @@ class RolloutBuffer(object):
         self.adv = torch.zeros((T, n), dtype=f32, device=dev)
         self.ret = torch.zeros((T, n), dtype=f32, device=dev)
         self.stats = torch.zeros(2, dtype=torch.float64, device=dev)
+        self._stats_fresh = False       # True between finish() and the get() that consumes the statistics
+        need = int(_lib.load().dpenv_gae_workspace_bytes(int(n)))
+        self._ws = torch.empty((need + 7) // 8, dtype=torch.float64, device=dev)     # this buffer's own scratch (any stream)
 
-    def collect(self, env, noise=None, switch_steps=(), refs=None, sample=None):
+    def collect(self, env, noise=None, switch_steps=(), refs=None, sample=None, rows=None, reset_at_end=False):
         """Run T policy-in-the-loop steps from the env's current state into the block (the env must have a policy
-        uploaded, policy.ActorCritic.upload).  sample: see policy.policy_rollout."""
+        uploaded, policy.ActorCritic.upload).  sample: see policy.policy_rollout.
+        rows=(t0, t1): fill only rows [t0, t1) with ONE launch of t1 - t0 steps (the pieces of a pipelined episode exchange,
+        dist.EpisodeExchange); the pieces of one episode give the same rows as one launch of T steps, bit for bit, except `boot` at
+        the last row of an inner piece (V of the next observation instead of 0) - which the scan only reads where a path ends
+        (ppo.py:311), i.e. at done rows and at T-1, so adv / ret are the same bits too.
+        reset_at_end: the reference's epoch boundary (ppo.py:305-322) - after the LAST step of the block every env is cut
+        (boot = V(last obs), ppo.py:311) and re-drawn, whether or not its episode had ended."""
         from .policy import policy_rollout
-        return policy_rollout(env, self.T, noise=noise, switch_steps=switch_steps, refs=refs, out=self.blocks, sample=sample)
+        self._stats_fresh = False
+        if rows is None:
+            return policy_rollout(env, self.T, noise=noise, switch_steps=switch_steps, refs=refs, out=self.blocks, sample=sample,
+                                  reset_at_end=reset_at_end)
+        t0, t1 = rows
+        assert 0 <= t0 < t1 <= self.T
+        b = self.blocks
+        part = {k: (b[k] if k in ('last_obs', 'last_val') else b[k][t0:t1]) for k in b}
+        sel = [j for j, st in enumerate(switch_steps) if t0 <= st < t1]
+        policy_rollout(env, t1 - t0, noise=None if noise is None else noise[t0:t1], switch_steps=tuple(switch_steps[j] - t0 for j in sel),
+                       refs=None if not sel else refs[sel[0]:sel[-1] + 1].contiguous(), out=part, sample=sample,
+                       reset_at_end=reset_at_end and t1 == self.T)
+        return b
 
     def finish(self):
         """GAE-lambda advantages and rewards-to-go for every path in the block (ppo.py:65-91); paths end where done != 0
         and at the end of the block, bootstrapped with the values the rollout kernel left in ``boot`` (ppo.py:311).  The same
         pass leaves (sum adv, sum adv^2) in ``self.stats`` for ``get``."""
         b = self.blocks
-        return gae(b['rew'], b['val'], end=b['done'], boot=b['boot'], gamma=self.gamma, lam=self.lam, out=(self.adv, self.ret),
-                   stats=self.stats)
+        res = gae(b['rew'], b['val'], end=b['done'], boot=b['boot'], gamma=self.gamma, lam=self.lam, out=(self.adv, self.ret),
+                  stats=self.stats, workspace=self._ws)
+        self._stats_fresh = True
+        return res
 
     def get(self, group=None):
-        """ppo.py:93-105: obs, act, normalised adv, ret, logp."""
-        normalize_advantages(self.adv, group=group, stats=self.stats)
+        """ppo.py:93-105: obs, act, normalised adv, ret, logp.  The statistics finish() left behind are used ONCE: a second get()
+        (or a get() after adv was edited through another finish-less path) recomputes them with the three-pass form, like the
+        reference's get() which recomputes mean / std every time it is called (ppo.py:99-101)."""
+        if self._stats_fresh:
+            normalize_advantages(self.adv, group=group, stats=self.stats)
+            self._stats_fresh = False
+        else:
+            normalize_advantages(self.adv, group=group)
         b = self.blocks
         return b['obs'], b['act'], self.adv, self.ret, b['logp']
+
+    def exchange_blocks(self):
+        """What an update on ANOTHER rank needs of this rank's episode (ppo.py:93-105): obs | act | logp (complete as the steps
+        are) and adv | ret (after finish() / get(): GAE and the normalisation are local, only the 24-byte statistics cross).
+        58 B per env-step with bf16 observation rows (config 5's obs_dtype), 76 B with f32 rows; views, no copy.
+        rew, val, boot and done stay home."""
+        b = self.blocks
+        return {'obs': b['obs'], 'act': b['act'], 'logp': b['logp'], 'adv': self.adv, 'ret': self.ret}
 
     def trajectory(self):
         """The five blocks of ppo.py:40-46 as they lie in HBM: {'obs': [T, n, 9], 'act': [T, n, 7], 'rew' / 'val' / 'logp': [T, n]}

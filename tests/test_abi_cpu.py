@@ -34,19 +34,19 @@ def test_struct_layout_matches_header(tmp_path):
     from ml4ca_amd import _lib
     src = tmp_path / 'sz.c'
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "dpenv.h"\n'
-                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(dpenv_config), sizeof(dpenv_step_io),'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(dpenv_config), sizeof(dpenv_step_io),'
                    ' offsetof(dpenv_config, seed), offsetof(dpenv_config, reset_fraction),'
                    ' offsetof(dpenv_config, hold_plant), offsetof(dpenv_step_io, final_obs),'
                    ' offsetof(dpenv_config, reset_acts), sizeof(dpenv_policy_desc), offsetof(dpenv_policy_desc, precision),'
                    ' offsetof(dpenv_policy_desc, device_pointers), sizeof(dpenv_policy_rollout_io), offsetof(dpenv_policy_rollout_io, sample),'
-                   ' sizeof(dpenv_mlp));return 0;}\n')
+                   ' sizeof(dpenv_mlp), offsetof(dpenv_policy_rollout_io, reset_at_end));return 0;}\n')
     exe = tmp_path / 'sz'
     subprocess.check_call(['gcc', '-std=c99', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [C.sizeof(_lib.Config), C.sizeof(_lib.StepIO), _lib.Config.seed.offset, _lib.Config.reset_fraction.offset,
             _lib.Config.hold_plant.offset, _lib.StepIO.final_obs.offset, _lib.Config.reset_acts.offset, C.sizeof(_lib.PolicyDesc),
             _lib.PolicyDesc.precision.offset, _lib.PolicyDesc.device_pointers.offset, C.sizeof(_lib.PolicyRolloutIO),
-            _lib.PolicyRolloutIO.sample.offset, C.sizeof(_lib.Mlp)]
+            _lib.PolicyRolloutIO.sample.offset, C.sizeof(_lib.Mlp), _lib.PolicyRolloutIO.reset_at_end.offset]
     assert got == want
 
 
@@ -145,15 +145,23 @@ def test_no_packed_fp32_in_any_translation_unit():
     flags = re.search(r'^CXXFLAGS \?= (.*)$', mk, re.M).group(1).replace('$(BLOCK)', '64').split()
     assert '-fno-slp-vectorize' in flags
     units = re.search(r'^SRC := (.*)$', mk, re.M).group(1).split()
-    assert sorted(units) == ['dpenv_api.hip', 'dpenv_kernels.hip', 'dpenv_policy.hip', 'dpenv_policy_x.hip']
+    assert sorted(units) == ['dpenv_api.hip', 'dpenv_kernels.hip', 'dpenv_policy.hip', 'dpenv_policy_ws.hip', 'dpenv_policy_x.hip',
+                             'dpenv_policy_xws1.hip', 'dpenv_policy_xws2.hip']
 
     def isa(unit):
-        return subprocess.run([hipcc, '--offload-arch=gfx950'] + flags + ['--cuda-device-only', '-S', '-o', '-', os.path.join(csrc, unit)],
+        # the policy units instantiate ~40 kernels each from ONE template (env variant x obs width x layer width x activation) and
+        # take minutes apiece; the scan needs the code, not every copy of it: -DDPENV_DEV_FAST instantiates the shipped configuration
+        # (final / continuous angles / extended state, 80-wide leaky-relu layers, both workgroup geometries) - the kernels the bench
+        # runs.  The whole library, every instantiation, is scanned for packed fp32 by `make` itself (tools/check_isa.py on the
+        # linked libdpenv.so: a hard build step).
+        extra = ['-DDPENV_DEV_FAST'] if unit.startswith('dpenv_policy') else []
+        return subprocess.run([hipcc, '--offload-arch=gfx950'] + flags + extra + ['--cuda-device-only', '-S', '-o', '-', os.path.join(csrc, unit)],
                               check=True, capture_output=True, text=True).stdout
 
     with ThreadPoolExecutor(4) as ex:
         asm = dict(zip(units, ex.map(isa, units)))
     assert 'v_mfma_f32_32x32x16_f16' in asm['dpenv_policy.hip'] and 'step_kernel' in asm['dpenv_kernels.hip']
+    assert 'policy_rollout_ws_kernel' in asm['dpenv_policy_xws1.hip'] and 'policy_rollout_ws_kernel' in asm['dpenv_policy_ws.hip']
     # (a) the exact form: a packed f32 instruction whose op_sel (the LOW result's operand select) picks the high half of src1 / src2
     swz = re.compile(r'^\s*(v_pk_\w+_f32)\b.*\bop_sel:\[\d,(?:1(?:,\d)?|\d,1)\]', re.M)
     for unit, txt in asm.items():
@@ -165,10 +173,14 @@ def test_no_packed_fp32_in_any_translation_unit():
     # look inside asm statements, so no asm instruction may write a register inside the destination tile of an MFMA that can still be
     # running (round 2: dead rows 80..95 of an accumulator were handed to the activation / split asm as temporaries)
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
-    from asm_mfma_waw_scan import asm_writes_into_recent_mfma_dest
-    for unit in ('dpenv_policy.hip', 'dpenv_policy_x.hip'):
+    from asm_mfma_waw_scan import asm_reads_of_unlanded_mfma_dest, asm_writes_into_recent_mfma_dest
+    for unit in ('dpenv_policy.hip', 'dpenv_policy_ws.hip', 'dpenv_policy_x.hip', 'dpenv_policy_xws1.hip', 'dpenv_policy_xws2.hip'):
         hits = asm_writes_into_recent_mfma_dest(asm[unit])
         assert not hits, (unit, len(hits), hits[:4])
+        # (d) and the read side: no asm instruction reads an MFMA result that no compiler-visible VALU instruction has read
+        # first (round 2: reading the accumulators from asm directly lost the last MFMA of the chain, a 2e-5 error)
+        rhits = asm_reads_of_unlanded_mfma_dest(asm[unit])
+        assert not rhits, (unit, len(rhits), rhits[:4])
     bad = """k:
 \tv_mfma_f32_32x32x16_f16 v[32:47], v[76:79], v[92:95], 0
 \t;;#ASMSTART
@@ -176,6 +188,9 @@ def test_no_packed_fp32_in_any_translation_unit():
 \t;;#ASMEND
 """
     assert asm_writes_into_recent_mfma_dest(bad)
+    bad_read = bad.replace('v_max_f32 v40, v58, v28', 'v_max_f32 v100, v33, v28')          # reads v33 of the tile v[32:47] straight from asm
+    assert asm_reads_of_unlanded_mfma_dest(bad_read) and not asm_writes_into_recent_mfma_dest(bad_read)
+    assert not asm_reads_of_unlanded_mfma_dest(bad_read.replace('\t;;#ASMSTART', '\tv_mul_f32_e32 v1, s33, v33\n\t;;#ASMSTART'))
     assert not asm_writes_into_recent_mfma_dest(bad.replace('\t;;#ASMSTART', '\tv_mul_f32_e32 v1, s33, v33\n\t;;#ASMSTART'))   # a visible read first
     assert not asm_writes_into_recent_mfma_dest(bad.replace('v_max_f32 v40', 'v_max_f32 v48'))
     # the pattern itself must be what the check looks for: the reproducer's instruction text matches, the safe form does not

@@ -15,6 +15,7 @@ from tests import helpers as H
 from tests import tolerances as TOL
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 ALL_MODES = ['full', 'simple', 'limited', 'final_wrap', 'final_cont']
 
@@ -72,17 +73,25 @@ def compare(g, o, od, bounds):
     assert done_agrees(g['done'], o['done'], o['obs'], bounds).all(), 'done bits'
 
 
-def done_agrees(gdone, odone, oobs, bounds):
-    """done bits must be equal, except where an observation sits within fp32 rounding of a termination
-    bound (strict > on a value 1 ulp either side may legitimately flip).  Returns the mask of envs that agree."""
-    same = gdone == odone
-    if not same.all():
-        b = np.asarray(bounds, np.float64)
-        margin = np.abs(np.abs(oobs[:, :6].astype(np.float64)) - b[None, :]) / b[None, :]
-        borderline = margin.min(1) < 2e-6
-        bad = ~same & ~borderline
-        assert not bad.any(), 'done bits differ away from any bound at envs %s' % np.nonzero(bad)[0][:8]
-    return same
+NU_FIXTURE_SLACK = 3.0       # fp32 kernel against a float64 fixture (one fp32 side only gets the whole tolerance) x lean transcendentals
+
+
+def _record_need(name, a, b, floor):
+    """worst |a - b| / (1e-5 max(|b|, floor)) of a comparison, appended to gpurun_out/tolerance_need.json (what the floors cost)"""
+    import json
+    need = float((np.abs(np.asarray(a, np.float64) - b) / (TOL.RTOL_F32 * np.maximum(np.abs(b), floor))).max())
+    path = os.path.join(ROOT, 'gpurun_out', 'tolerance_need.json')
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    try:
+        rec = json.load(open(path))
+    except Exception:
+        rec = {}
+    rec[name] = need
+    json.dump(rec, open(path, 'w'), indent=1)
+    return need
+
+
+done_agrees = TOL.done_agrees          # equal done bits, except within fp32 rounding of a termination bound (raises otherwise)
 
 
 # --------------------------------------------------------------------------------------------
@@ -187,7 +196,13 @@ def test_reference_closed_loop_through_kernel(mode):
     # reward: its position terms inherit the position rounding: d r / d x <= 2 per metre (Gaussian) + 0.1 (linear part)
     TOL.assert_close(rew.cpu().numpy(), d['reward'].reshape(M), np.maximum(TOL.REWARD_FLOOR, 2.1 * pos), what='reward vs reference')
     TOL.assert_close(st2[0:3].T, eta_a, np.stack([pos, pos, yaw], 1), what='eta after')
-    TOL.assert_close(st2[3:6].T, d['nu_after'].reshape(M, 3), np.array([1.0, 0.3, 0.5]), what='nu after')
+    # nu after one step: these fixtures drive the hull with hard-over commands to 20-43 % beyond the termination bounds (|u| up to
+    # 2.2 m/s), so the input scale of the coupled velocity triple is the transition's own largest speed, not the 1.4 m/s of
+    # tolerances.DERIVATION: floor = NU_FLOOR scaled by max(|nu|) / 1.4, never below NU_FLOOR (was a blanket [1.0, 0.3, 0.5])
+    nu_a = d['nu_after'].reshape(M, 3)
+    nu_scale = np.maximum(1.0, np.maximum(np.abs(st[3:6]).max(0), np.abs(nu_a).max(1)) / 1.4)
+    _record_need('closedloop_%s_nu' % mode, st2[3:6].T, nu_a, TOL.NU_FLOOR[None, :] * nu_scale[:, None])
+    TOL.assert_close(st2[3:6].T, nu_a, TOL.NU_FLOOR[None, :] * nu_scale[:, None] * NU_FIXTURE_SLACK, what='nu after')
     # termination bits: equal, except where an observation sits within fp32 rounding of a bound (strict > may flip there)
     obs6 = np.zeros((M, 6)); obs6[:, :min(od, 6)] = d['obs'].reshape(M, od)[:, :6]
     done_agrees(done.cpu().numpy() & 1, d['done'].reshape(M).astype(np.uint8), obs6, env.real_ss_bounds)
@@ -227,7 +242,7 @@ def test_other_agent_rates_match_oracle(n_steps):
         oo, orw, od_ = orc.step(ost, octr, A)
         TOL.assert_close(o.cpu().numpy(), oo, TOL.OBS_FLOOR, what='obs n_steps=%d t=%d' % (n_steps, t))
         TOL.assert_close(r.cpu().numpy(), orw, TOL.REWARD_FLOOR, what='reward n_steps=%d t=%d' % (n_steps, t))
-        assert (d.cpu().numpy() != od_).sum() <= 1
+        done_agrees(d.cpu().numpy(), od_, oo, env.real_ss_bounds)      # raises if a done bit differs away from every bound
         s2, _ = env.get_state()
         ost[:] = s2.cpu().numpy()                      # re-synchronise: fp32 vs fp32 but different operation order
     if n_steps == 1:
@@ -1003,3 +1018,41 @@ def test_config3_box_sequence_65536_envs():
     assert torch.equal(s1, s2) and torch.equal(c1, c2)
     assert torch.equal(s1[6:9], refs[-1])          # the last setpoint of the box is in force
     assert int(c1[0].min()) == T and float(d_r.float().abs().max()) == 0.0
+
+
+def test_error_against_the_survey_floor():
+    """the HIP step against the fp32 oracle per quantity - under SURVEY section 7's blanket floor of 1e-2, under
+    the floors of tests/tolerances.py (derived from the ulp argument there), and in ulps of the largest input.  Asserted: every
+    quantity inside the test tolerance; every quantity that is NOT a cancelled difference of metre-sized inputs inside 1e-5 under
+    SURVEY's own floor too; x~ / y~ / the reward's pose part reported (fp32 cannot meet 1e-5 * max(|ref|, 1e-2) there: the float32
+    ORACLE itself misses it against the float64 oracle, tests/test_oracle_golden.py).  The table goes to gpurun_out/error_ledger.json."""
+    import json
+    torch = torch_()
+    n = 16384
+    env, orc = H.make_pair('final_cont', n)
+    rng = np.random.RandomState(77)
+    st = H.random_state(rng, n)
+    st[12] = np.pi / 2
+    ctr = np.zeros((2, n), np.int32)
+    env.set_state(H.to_dev(st), H.to_dev(ctr))
+    parts = torch.zeros((4, n), device=env.device)
+    led = TOL.ErrorLedger()
+    for t in range(5):
+        gs, gc = env.get_state()
+        ost, octr = gs.cpu().numpy().copy(), gc.cpu().numpy().copy()
+        pre = ost.copy()
+        A = H.random_actions(rng, n, 7, scale=0.6065)
+        o, r, d, _ = env.step(H.to_dev(A), reward_parts=parts)
+        oo, orw, od_, op = orc.step(ost, octr, A, want_parts=True)
+        gs2, _ = env.get_state()
+        led.add_step(o.cpu().numpy(), r.cpu().numpy(), parts.cpu().numpy().T, gs2.cpu().numpy(), oo, orw, op, ost, pre)
+        done_agrees(d.cpu().numpy(), od_, oo, env.real_ss_bounds)
+    rep = led.report()
+    out = os.path.join(ROOT, 'gpurun_out')
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, 'error_ledger.json'), 'w') as f:
+        json.dump(rep, f, indent=1)
+    for name, r in rep.items():
+        assert r['rel_err_test_floor'] <= TOL.RTOL_F32, (name, r)
+    for name in ('obs.u', 'obs.v', 'obs.r', 'obs.thrust/100', 'reward.vel', 'reward.thr', 'reward.der', 'state.thrust_cmd'):
+        assert rep[name]['rel_err_floor_1e-2'] <= TOL.RTOL_F32, (name, rep[name])

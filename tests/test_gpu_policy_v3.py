@@ -1,0 +1,353 @@
+"""Round-3 GPU tests of the closed-loop kernels:
+two-wave launch form of the split ("fp32-faithful") arithmetics, the 128-env workgroup geometry, the reference's
+epoch boundary (reset_at_end, ppo.py:305-322), pieces of one episode (pipelined exchange), checkpoint of the draw counters,
+uploads that do not disturb launches in flight."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+from tests import tolerances as TOL
+
+pytestmark = pytest.mark.gpu
+
+ROWS = ('obs', 'act', 'rew', 'done', 'logp', 'val', 'boot', 'last_obs', 'last_val')
+
+
+def torch_():
+    import torch
+    return torch
+
+
+def make_ac(*a, **kw):
+    from ml4ca_amd.policy import ActorCritic
+    return ActorCritic(*a, **kw)
+
+
+def _pair_of_launches(n, T, precision, forms=('two_wave', 'one_wave'), seed=12, hidden=(80, 80, 80), mode='final_cont', ext=True, **extra):
+    """the same sampled rollout (drifting current, reset_acts, auto-reset through a short time limit) in two launch forms"""
+    from ml4ca_amd.policy import policy_rollout
+    torch = torch_()
+    kw = dict(auto_reset=True, max_ep_len=6, seed=seed, reset_acts=True, current=True, current_drift=True, ext=ext)
+    kw.update(extra)
+    outs, states = [], []
+    for form in forms:
+        env, _ = H.make_pair(mode, n, **kw)
+        env.set_current(torch.full((n,), 0.15, device=env.device), torch.full((n,), 1.0, device=env.device))
+        env.reset()
+        make_ac(env.num_states, env.num_actions, hidden, seed=5, device=env.device).upload(env, precision=precision, launch_form=form)
+        outs.append(policy_rollout(env, T, sample=True))
+        states.append(env.get_state() + env.get_rng_counters() + env.get_current())
+    return outs, states
+
+
+@pytest.mark.parametrize('precision', ['f32_actor', 'f32', 'f16'])
+@pytest.mark.parametrize('n', [2000 + 9, 65536])
+def test_two_wave_form_writes_the_one_wave_rows(precision, n):
+    """DPENV_LAUNCH_TWO_WAVE for every arithmetic (round 3: the split ones too) against DPENV_LAUNCH_ONE_WAVE: every row of a
+    sampled closed-loop launch with in-kernel noise, drifting current, reset_acts and cut episodes, the final state, the draw
+    counters - bit for bit.  2 009 envs run in the 128-env workgroup geometry (a SIMD per wave), 65 536 in the 256-env one."""
+    from ml4ca_amd import DpenvError
+    torch = torch_()
+    T = 14
+    try:
+        (a, b), (sa, sb) = _pair_of_launches(n, T, precision)
+    except DpenvError as e:
+        if precision == 'f32' and 'exceed the 160 KiB' in str(e):
+            pytest.skip('DPENV_POLICY_F32 two-wave does not fit the LDS in this build: %s' % e)
+        raise
+    for k in ROWS:
+        assert torch.equal(a[k], b[k]), (precision, n, k)
+    for x, y in zip(sa, sb):
+        assert torch.equal(x, y)
+    done = a['done']
+    assert int(((done & 2) != 0).sum()) >= n and bool(torch.isfinite(a['boot']).all()) and bool((a['boot'] != 0).any())
+
+
+@pytest.mark.parametrize('precision,form', [('f32_actor', 'two_wave'), ('f32', 'two_wave')])
+def test_two_wave_split_evaluations_equal_the_forward_kernel_at_full_size(precision, form):
+    """65 536 envs, deterministic actions: every stored action and value of the two-wave launch equals what the forward kernel computes
+    from the stored observation row, bit for bit - every inlined copy of the split evaluation in the network wave (first, in-loop,
+    pre-reset critic).  The check that catches a register-level fault in ONE copy (round 2's asm-temporary / MFMA overlap)."""
+    import ml4ca_amd
+    from ml4ca_amd import DpenvError
+    from ml4ca_amd.policy import policy_forward, policy_rollout
+    torch = torch_()
+    n, T = 65536, 12
+    env = ml4ca_amd.BatchedRevoltEnv(n, auto_reset=True, max_ep_len=5, seed=11)
+    ac = make_ac(9, 7, (80, 80, 80), seed=6, device=env.device)
+    try:
+        ac.upload(env, precision=precision, launch_form=form)
+    except DpenvError as e:
+        pytest.skip(str(e))
+    env.reset()
+    out = policy_rollout(env, T, sample=False)
+    mu, v = policy_forward(env, out['obs'].reshape(T * n, 9))
+    assert torch.equal(out['act'].reshape(T * n, 7), mu)
+    assert torch.equal(out['val'].reshape(T * n), v)
+    done = out['done']
+    ended = (done != 0)
+    ended[T - 1] = True
+    terminal = (done & 1) != 0
+    assert bool((out['boot'][~ended | terminal] == 0).all()) and bool(torch.isfinite(out['boot']).all())
+    assert int((ended & ~terminal).sum()) > n
+
+
+@pytest.mark.parametrize('mode,ext,hidden,activation,precision', [
+    ('final_cont', True, (96, 96), 'leaky', 'f32_actor'),
+    ('limited', False, (64,), 'relu', 'f32_actor'),
+    ('simple', False, (33, 33, 33), 'leaky', 'f32'),
+    ('full', True, (48, 48), 'relu', 'f32'),
+    ('final_wrap', True, (80, 80, 80), 'leaky', 'f16'),
+])
+def test_two_wave_forms_for_other_shapes(mode, ext, hidden, activation, precision):
+    """the shapes the two-wave kernels are templated on (5 / 6 k-steps, one to three hidden layers, every env variant's action
+    width; 705 envs = the 128-env workgroup geometry with a ragged last group): rows equal to the one-wave form bit for bit"""
+    from ml4ca_amd import DpenvError
+    from ml4ca_amd.policy import policy_rollout
+    torch = torch_()
+    n, T = 700 + 5, 9
+    outs = []
+    for form in ('two_wave', 'one_wave'):
+        env, _ = H.make_pair(mode, n, ext=ext, auto_reset=True, max_ep_len=4, seed=13)
+        ac = make_ac(env.num_states, env.num_actions, hidden, seed=9, device=env.device, activation=activation)
+        try:
+            ac.upload(env, precision=precision, launch_form=form)
+        except DpenvError as e:
+            pytest.skip(str(e))
+        env.reset()
+        outs.append(policy_rollout(env, T, sample=True))
+    for k in ROWS:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+
+
+@pytest.mark.parametrize('precision,form', [('f32_actor', 'auto'), ('f16', 'auto'), ('f32', 'one_wave')])
+def test_reset_at_end_is_the_reference_epoch_boundary(precision, form):
+    """dpenv_policy_rollout_io.reset_at_end (ppo.py:305-322: at t == local_steps_per_epoch - 1 EVERY env is cut and reset): rows
+    0..T-1 equal the launch without it bit for bit except boot[T-1]; boot[T-1] = V(observation after step T-1) unless the env
+    terminated there (then 0, ppo.py:311); afterwards every env is a fresh episode - the state equals what an explicit
+    Revolt.reset of the not-yet-reset envs gives (same Philox draw: episode + 1), checked against the single-step path and the
+    ORACLE's reset; the next launch starts from those states."""
+    from ml4ca_amd.policy import policy_forward, policy_rollout
+    torch = torch_()
+    n, T = 3000 + 7, 11
+    kw = dict(auto_reset=True, max_ep_len=400, seed=41)
+    envA, orc = H.make_pair('final_cont', n, **kw)
+    envB, _ = H.make_pair('final_cont', n, **kw)
+    ac = make_ac(9, 7, (80, 80, 80), seed=3, device=envA.device)
+    for e in (envA, envB):
+        ac.upload(e, precision=precision, launch_form=form)
+        e.reset()
+    a = policy_rollout(envA, T, sample=True, reset_at_end=True)
+    b = policy_rollout(envB, T, sample=True)
+    for k in ('obs', 'act', 'rew', 'done', 'logp', 'val'):
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(a['boot'][:T - 1], b['boot'][:T - 1])
+    # the last step: B's last_obs is the observation after step T-1 (post auto-reset for envs that ended there)
+    done_last = b['done'][T - 1]
+    terminal = (done_last & 1) != 0
+    ended = done_last != 0
+    cont = ~ended                                                  # envs the epoch boundary cuts
+    assert int(cont.sum()) > n // 2 and int(terminal.sum()) > 0
+    _, v_last = policy_forward(envB, b['last_obs'])
+    assert torch.equal(a['boot'][T - 1][cont], v_last[cont])       # V(o_T) of a running episode
+    assert torch.equal(a['boot'][T - 1][cont], b['boot'][T - 1][cont])   # which is what the end of a launch leaves anyway
+    assert bool((a['boot'][T - 1][terminal] == 0).all())
+    assert torch.equal(a['boot'][T - 1][ended], b['boot'][T - 1][ended])
+    # state after: B + an explicit reset of the envs that had NOT just been re-drawn = A
+    stB, ctrB = envB.get_state()
+    envB.reset(mask=cont.to(torch.uint8))
+    sa, ca = envA.get_state()
+    sb, cb = envB.get_state()
+    assert torch.equal(sa, sb) and torch.equal(ca, cb)
+    assert int(ca[0].max()) == 0 and bool((ca[1] == ctrB[1] + cont.to(ctrB.dtype)).all())
+    # ... and the oracle's reset of those envs from B's pre-reset state gives the same draw (fp32, bit for bit: a sample, no arithmetic)
+    ost, octr = stB.cpu().numpy().copy(), ctrB.cpu().numpy().copy()
+    oobs = orc.reset(ost, octr, mask=cont.cpu().numpy().astype(np.uint8))
+    assert np.array_equal(ost[0:6], sa.cpu().numpy()[0:6]) and np.array_equal(octr, ca.cpu().numpy())
+    TOL.assert_close(a['last_obs'].float().cpu().numpy(), oobs, TOL.OBS_FLOOR, what='first observation of the new episodes')
+    # the next launch runs from the fresh episodes
+    a2 = policy_rollout(envA, 3, sample=True, reset_at_end=True)
+    assert torch.equal(a2['obs'][0], a['last_obs']) and torch.equal(a2['val'][0], a['last_val'])
+    # without auto_reset the flag is refused
+    from ml4ca_amd import DpenvError
+    envC, _ = H.make_pair('final_cont', 64, auto_reset=False)
+    ac.upload(envC, precision='f16')
+    envC.reset()
+    with pytest.raises(DpenvError):
+        policy_rollout(envC, 2, sample=True, reset_at_end=True)
+
+
+@pytest.mark.parametrize('precision', ['f32_actor', 'f16'])
+def test_pieces_of_one_episode_equal_one_launch(precision):
+    """RolloutBuffer.collect(rows=...) (the pieces dist.EpisodeExchange posts while the next one runs): four launches of T / 4 steps
+    write the rows of one launch of T steps bit for bit, except `boot` at the last row of an inner piece - which the scan does not
+    read there: advantages, returns and their statistics are the same bits."""
+    from ml4ca_amd import rollout as RO
+    torch = torch_()
+    n, T = 4096 + 64, 40
+    bufs = []
+    for pieces in (1, 4):
+        env, _ = H.make_pair('final_cont', n, auto_reset=True, max_ep_len=25, seed=8, obs_dtype='bfloat16')
+        make_ac(9, 7, (80, 80, 80), seed=4, device=env.device).upload(env, precision=precision)
+        env.reset()
+        buf = RO.RolloutBuffer(T, env)
+        if pieces == 1:
+            buf.collect(env, sample=True)
+        else:
+            for c in range(pieces):
+                buf.collect(env, sample=True, rows=(c * T // pieces, (c + 1) * T // pieces))
+        buf.finish()
+        bufs.append((buf, env.get_state()))
+    (b1, s1), (b4, s4) = bufs
+    for k in ('obs', 'act', 'rew', 'done', 'logp', 'val', 'last_obs', 'last_val'):
+        assert torch.equal(b1.blocks[k], b4.blocks[k]), k
+    inner = torch.zeros(T, dtype=torch.bool, device=b1.adv.device)
+    inner[[T // 4 - 1, T // 2 - 1, 3 * T // 4 - 1]] = True
+    assert torch.equal(b1.blocks['boot'][~inner], b4.blocks['boot'][~inner])
+    assert torch.equal(b1.adv, b4.adv) and torch.equal(b1.ret, b4.ret) and torch.equal(b1.stats, b4.stats)
+    assert torch.equal(s1[0], s4[0]) and torch.equal(s1[1], s4[1])
+    assert b1.blocks['obs'].dtype == torch.bfloat16
+    # get() consumes the statistics once; a second get() recomputes them (three-pass form) instead of re-applying stale ones
+    adv_raw = b1.adv.clone()
+    _, _, adv_n, _, _ = b1.get()
+    m1, s1_ = float(adv_n.mean()), float(adv_n.std())
+    assert abs(m1) < 1e-4 and abs(s1_ - 1.0) < 1e-3
+    b1.adv.mul_(3.0).add_(1.0)                                    # someone edits adv between two get() calls
+    _, _, adv_n2, _, _ = b1.get()
+    assert abs(float(adv_n2.mean())) < 1e-4 and abs(float(adv_n2.std()) - 1.0) < 1e-3
+    del adv_raw
+
+
+def test_checkpoint_with_draw_counters_reproduces_sampled_rollouts():
+    """dpenv_get_state alone did not restore the exploration-noise / drift counters.  get_state + get_current +
+    get_rng_counters + get_obs_thrust after a launch, restored into a FRESH handle (set_state, set_obs_thrust, set_current(mean) +
+    set_current(present_only), set_rng_counters): the next sampled launch - in-kernel noise, drifting current, reset_acts, cut episodes - is the
+    original's, bit for bit; without the counters it is not."""
+    from ml4ca_amd.policy import policy_rollout
+    torch = torch_()
+    n, T = 1500 + 1, 9
+    kw = dict(auto_reset=True, max_ep_len=7, seed=77, current=True, current_drift=True, reset_acts=True)
+    mean = lambda e: (torch.full((n,), 0.2, device=e.device), torch.full((n,), 2.3, device=e.device))
+    envA, _ = H.make_pair('final_cont', n, **kw)
+    envA.set_current(*mean(envA))
+    ac = make_ac(9, 7, (80, 80, 80), seed=1, device=envA.device)
+    ac.upload(envA, precision='f32_actor')
+    envA.reset()
+    policy_rollout(envA, T, sample=True)
+    st, ctr = envA.get_state()
+    nc, dc = envA.get_rng_counters()
+    vc, beta = envA.get_current()
+    lag = envA.get_obs_thrust()
+    assert int(nc.min()) == T and int(dc.min()) == T and not torch.equal(vc, mean(envA)[0]) and lag is not None
+    want = policy_rollout(envA, T, sample=True)
+    restored = {}
+    for with_counters in (True, False):
+        envB, _ = H.make_pair('final_cont', n, **kw)
+        envB.set_current(*mean(envB))                             # the means the drift reverts to
+        envB.set_current(vc, beta, present_only=True)             # the drifted values of the checkpoint
+        ac.upload(envB, precision='f32_actor')
+        envB.reset()
+        assert envB.get_obs_thrust() is None                      # nothing to continue after a reset
+        envB.set_state(st, ctr)
+        envB.set_obs_thrust(lag)                                  # the observation lags the stored thrust command by one step
+        if with_counters:
+            envB.set_rng_counters(nc, dc)
+        restored[with_counters] = policy_rollout(envB, T, sample=True)
+    for k in ROWS:
+        assert torch.equal(restored[True][k], want[k]), k
+    assert not torch.equal(restored[False]['act'], want['act'])
+
+
+def test_upload_does_not_disturb_a_launch_in_flight_on_another_stream():
+    """dpenv_set_policy_desc used to repack the single weight image in place.  A long launch on a side stream,
+    then TWO uploads of other weights on the current stream while it runs (the second reuses the first image and must wait for
+    the launch by event): the launch's rows are those of the weights it was given; a launch after the uploads uses the new ones."""
+    from ml4ca_amd.policy import policy_forward, policy_rollout
+    torch = torch_()
+    n, T = 65536, 60
+    env, _ = H.make_pair('final_cont', n, auto_reset=True, seed=5)
+    acs = [make_ac(9, 7, (80, 80, 80), seed=s_, device=env.device) for s_ in (1, 2, 3)]
+    acs[0].upload(env, precision='f16')
+    env.reset()
+    st, ctr = env.get_state()
+    ref = policy_rollout(env, T, sample=False)
+    torch.cuda.synchronize()
+    env.set_state(st, ctr)
+    side = torch.cuda.Stream(device=env.device)
+    side.wait_stream(torch.cuda.current_stream(env.device))
+    with torch.cuda.stream(side):
+        out = policy_rollout(env, T, sample=False)             # ~0.5 ms of kernel on the side stream
+    acs[1].upload(env, precision='f16')                         # current stream: other image
+    acs[2].upload(env, precision='f16')                         # reuses the image `out` is reading: waits for the launch (event)
+    obs = ref['obs'][0].float().contiguous()
+    mu3, _ = policy_forward(env, obs)
+    torch.cuda.synchronize()
+    for k in ('obs', 'act', 'val', 'rew'):
+        assert torch.equal(out[k], ref[k]), k
+    env.set_state(st, ctr)
+    acs[0].upload(env, precision='f16')
+    mu1, _ = policy_forward(env, obs)
+    assert torch.equal(mu1, ref['act'][0]) and not torch.equal(mu3, mu1)
+
+
+@pytest.mark.parametrize('changes', [False, True])
+def test_run_RL_policy_against_the_reference_harness_fixture(changes):
+    """SURVEY 8 f-2 / VERDICT r02 item 3: tests/golden/run_rl_policy.npz is the reference's OWN run_RL_policy
+    (spinup/utils/test_policy.py:97-186, imported and executed by tests/golden/gen_run_rl_policy.py) with the thesis' trained actor
+    (NumPy float64 MLP from the checkpoint tensors) on the reference's RevoltFinal(testing=True) over oracle/twin_shim - per step
+    ned_pos, ned_ref, action_vec, observation, reward, and EpRet / EpLen per episode, without and with test_setpoint_changes.
+    evaluate.run_RL_policy (HIP env in fp32, fp32-faithful in-kernel actor) must reproduce it: EpLen exactly, everything else at the
+    tolerance of an fp32 closed loop against a float64 one over 400 steps (a stabilising feedback policy: the error does not grow;
+    measured worst cases are written to gpurun_out/run_rl_policy_errors.json)."""
+    import json
+    import os
+    import ml4ca_amd
+    from ml4ca_amd import evaluate as EV
+    from ml4ca_amd.policy import ActorCritic
+    torch = torch_()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = np.load(os.path.join(root, 'tests', 'golden', 'run_rl_policy.npz'))
+    d = np.load(os.path.join(root, 'tests', 'golden', 'final_policy.npz'))
+    tensors = {k.replace('.', '/'): d[k] for k in d.files if '.' in k}
+    tag = 'setpoints' if changes else 'plain'
+    E = len(g[tag + '_EpLen'])
+    T = int(g['max_ep_len'])
+    env = ml4ca_amd.BatchedRevoltEnv(E, testing=True, time_limit=False, vessel_params=g['vessel'].astype(np.float32))
+    assert env.max_ep_len == T
+    ac = ActorCritic.from_tensors(tensors, device=env.device).upload(env, precision='f32')
+    res = EV.run_RL_policy(env, ac, num_episodes=E, test_setpoint_changes=changes)
+    eplen = res['EpLen'].cpu().numpy()
+    assert np.array_equal(eplen, g[tag + '_EpLen']), (eplen, g[tag + '_EpLen'])
+    assert np.array_equal(g[tag + '_n_recorded'], eplen + 1)
+    worst = {}
+    for k in range(E):
+        L = int(eplen[k]) + 1                                       # records 0 .. EpLen
+        for name, key, tol in (('ned_pos', '_ned_pos', 2e-3), ('ned_ref', '_ned_ref', 1e-6), ('action_vec', '_action_vec', None),
+                               ('obs', '_obs', 2e-3), ('rew', '_rew', 2e-3)):
+            got = res[name][:L, k].double().cpu().numpy()
+            want = g[tag + key][k, :L]
+            assert not np.isnan(want).any()
+            err = np.abs(got - want)
+            if name == 'action_vec':
+                # thrust columns in percent (scale 100), azimuth columns in rad; an azimuth command may sit on the +-pi seam of atan2
+                e_thr = err[:, 0:3].max()
+                da = np.abs(np.angle(np.exp(1j * (got[:, 3:6] - want[:, 3:6])))).max()
+                worst['thrust_pct'] = max(worst.get('thrust_pct', 0.0), float(e_thr))
+                worst['azimuth_rad'] = max(worst.get('azimuth_rad', 0.0), float(da))
+                assert e_thr < 0.5 and da < 5e-3, (k, e_thr, da)
+            else:
+                worst[name] = max(worst.get(name, 0.0), float(err.max()))
+                assert err.max() < tol, (name, k, float(err.max()), np.unravel_index(err.argmax(), err.shape))
+    ret = res['EpRet'].double().cpu().numpy()
+    worst['EpRet'] = float(np.abs(ret - g[tag + '_EpRet']).max())
+    assert worst['EpRet'] < 0.2, (ret, g[tag + '_EpRet'])
+    out = os.path.join(root, 'gpurun_out')
+    os.makedirs(out, exist_ok=True)
+    path = os.path.join(out, 'run_rl_policy_errors.json')
+    try:
+        rec = json.load(open(path))
+    except Exception:
+        rec = {}
+    rec[tag] = worst
+    json.dump(rec, open(path, 'w'), indent=1)
+    env.close()

@@ -114,6 +114,21 @@ def _gloo_worker(rank, world, port, total, T, q):
     for k_, lo, hi in (('obs', 0, 9), ('act', 9, 16)):
         assert torch.equal(D.to_global_env_order(gr[k_]), torch.from_numpy(full[..., lo:hi])) and torch.equal(gr[k_], gr2[k_])
     assert torch.equal(D.to_global_env_order(gr['rew']), torch.from_numpy(full[..., 16]))
+    # the compact, pipelined exchange (dist.EpisodeExchange): obs as bf16 rows | act | logp posted chunk by chunk (async), adv | ret
+    # after the scan; chunk-major output = the one-piece gather of the same blocks, bit for bit
+    xb = {'obs': blocks['obs'].to(torch.bfloat16), 'act': blocks['act'], 'logp': blocks['logp'], 'adv': blocks['rew'].clone(), 'ret': blocks['val'].clone()}
+    whole = D.gather_rollout(xb)
+    for C in (1, 3, 4):
+        ex = D.EpisodeExchange(xb, n_chunks=C)
+        for c in range(C):
+            ex.post_steps(c)
+        ex.post_scan()
+        got = ex.wait()
+        for k_ in xb:
+            assert got[k_].shape[:3] == (C, world, T // C)
+            assert torch.equal(ex.episode_order(k_), whole[k_]), (C, k_)
+            assert ex.flat(k_).shape[0] == world * T * n_local
+    assert D.EpisodeExchange.bytes_per_env_step(xb) == 9 * 2 + 7 * 4 + 4 + 4 + 4
     # scalar statistics the way mpi_statistics_scalar does them: two all-reduces
     acc = torch.tensor([block[..., 16].sum(dtype=np.float64), block[..., 16].size], dtype=torch.float64)
     dist.all_reduce(acc)
@@ -310,3 +325,40 @@ def test_default_hull_open_loop_against_recorded_cybersea_commands():
     # the current run is predicted as well as the calm-water one: the relative-velocity current model is in the right place
     sel = W['run'] == W['names'].index('current_box_test_QP')
     assert RC.errors(pred, W, sel)[50][0] < 0.5
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_is_around():
+    """bench.py --gpus 2 without torch.distributed.run around it: the ranks are started as a CHILD process before anything touches a
+    GPU (never os.exec), rank 0's single JSON line comes through, the exit code is the child's.  --rendezvous-only keeps it on the
+    CPU (gloo): what is tested is the launch path the driver's N > 1 runs depend on."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--rendezvous-only'], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout
+    r = json.loads(lines[0])
+    assert r['n_gpus'] == 2 and r['sum_of_rank_plus_1'] == 3.0
+    assert r['group']['world_size'] == 2 and r['group']['backend'] == 'gloo' and len(r['group']['ranks']) == 2
+    assert sorted(x['rank'] for x in r['group']['ranks']) == [0, 1] and len({x['pid'] for x in r['group']['ranks']}) == 2
+    assert 'starting 2 ranks as a child process' in p.stderr
+    # under a launcher with the wrong rank count it refuses instead of measuring something else
+    env2 = dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    q = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--rendezvous-only'], env=env2, capture_output=True,
+                       text=True, timeout=600)
+    assert q.returncode != 0 and 'started 1 rank' in (q.stderr + q.stdout)
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """fewer devices than --gpus: non-zero exit with a message, nothing measured, no rank started"""
+    import subprocess
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('this host has the devices')
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 3 and 'only' in p.stderr and 'device(s) visible' in p.stderr and p.stdout.strip() == ''

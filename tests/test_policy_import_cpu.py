@@ -170,3 +170,22 @@ def test_iae_matches_the_reference_function_on_the_recorded_box_test():
         e = torch.stack([obs[:, i, 0], obs[:, i, 1], torch.rad2deg(obs[:, i, 2])], -1).double()
         _, c = EV.iae_series(e, torch.zeros_like(e), torch.arange(T, dtype=torch.float64) * 0.2)
         assert abs(float(tot[i]) - float(c[-1])) < 1e-4 * float(c[-1])
+
+
+def test_energy_metric_matches_the_reference_power_fixture():
+    """SURVEY 8 f-2 / VERDICT r02 item 4: evaluate.thruster_power / evaluate.work against tests/golden/energy.npz, produced by the
+    reference's own power() (results/all_plots/box_test/plot_act.py:133-135, taken out of the plotting script's syntax tree by
+    tests/golden/gen_run_rl_policy.py) and its trapezoid (:184-211): a random command series on a non-uniform time base and a
+    smooth one on the 5 Hz grid the rollout blocks have.  float64, 1e-12 relative."""
+    import torch
+    from ml4ca_amd import evaluate as EV
+    d = np.load(os.path.join(G, 'energy.npz'))
+    assert np.allclose(d['const_rps_max'], [EV.RPS_MAX['bow'], EV.RPS_MAX['stern']]) and np.allclose(d['const_diameters'], [EV.DIAMETER['bow'], EV.DIAMETER['stern']])
+    assert np.allclose(d['const_KQ_0'], [EV.KQ0['bow'], EV.KQ0['stern']]) and float(d['const_rho']) == EV.RHO
+    n = torch.from_numpy(d['n_rand'])
+    p = np.stack([EV.thruster_power(n[:, 0], 'bow').numpy(), EV.thruster_power(n[:, 1], 'stern').numpy(), EV.thruster_power(n[:, 2], 'stern').numpy()], 1)
+    assert np.abs(p - d['p_rand']).max() <= 1e-12 * np.abs(d['p_rand']).max()
+    cum = EV.work(n, time=torch.from_numpy(d['t_rand']), cumulative=True).numpy()
+    assert cum.shape == d['w_rand'].shape and np.abs(cum - d['w_rand']).max() <= 1e-12 * np.abs(d['w_rand']).max()
+    tot = EV.work(torch.from_numpy(d['n_grid'])[:, None, :], dt=0.2).numpy()[0]
+    assert np.abs(tot - d['w_grid'][-1]).max() <= 1e-12 * np.abs(d['w_grid'][-1]).max()

@@ -73,7 +73,7 @@ def compare(g, o, od, bounds):
     assert done_agrees(g['done'], o['done'], o['obs'], bounds).all(), 'done bits'
 
 
-NU_FIXTURE_SLACK = 3.0       # fp32 kernel against a float64 fixture (one fp32 side only gets the whole tolerance) x lean transcendentals
+NU_FIXTURE_SLACK = 1.0       # measured need (gpurun_out/tolerance_need.json, round 3): 0.06-0.08 of the tolerance at slack 3, i.e. ~0.25 at 1
 
 
 def _record_need(name, a, b, floor):

@@ -190,8 +190,14 @@ def test_launch_form_and_lds_footprint_validation():
     assert bool(torch.isfinite(out['val']).all())
     with pytest.raises(DpenvError):
         wide.upload(env, precision='f32')                      # 2 x 138 KiB of split fragments do not fit at all
+    # round 3: the compact weight image (28.75 KiB per network and image for 9-80-80-80) lets all four images of the split arithmetic
+    # share the LDS with the two-wave form's mailboxes; tanh has no two-wave form in the split arithmetics
+    ActorCritic(9, 7, (80, 80, 80), device=env.device).upload(env, precision='f32', launch_form='two_wave')
+    out = policy_rollout(env, 3)
+    assert bool(torch.isfinite(out['val']).all())
     with pytest.raises(DpenvError):
-        ActorCritic(9, 7, (80, 80, 80), device=env.device).upload(env, precision='f32', launch_form='two_wave')
+        ActorCritic(9, 7, (80, 80, 80), device=env.device, activation='tanh').upload(env, precision='f32', launch_form='two_wave')
+    ActorCritic(9, 7, (80, 80, 80), device=env.device, activation='tanh').upload(env, precision='f32')     # auto: one wave
     ac = ActorCritic(9, 7, (80, 80, 80), leak=1.5, device=env.device)
     with pytest.raises(DpenvError):
         ac.upload(env)                                          # slope outside [0, 1]

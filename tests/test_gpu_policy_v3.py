@@ -297,8 +297,9 @@ def test_run_RL_policy_against_the_reference_harness_fixture(changes):
     (NumPy float64 MLP from the checkpoint tensors) on the reference's RevoltFinal(testing=True) over oracle/twin_shim - per step
     ned_pos, ned_ref, action_vec, observation, reward, and EpRet / EpLen per episode, without and with test_setpoint_changes.
     evaluate.run_RL_policy (HIP env in fp32, fp32-faithful in-kernel actor) must reproduce it: EpLen exactly, everything else at the
-    tolerance of an fp32 closed loop against a float64 one over 400 steps (a stabilising feedback policy: the error does not grow;
-    measured worst cases are written to gpurun_out/run_rl_policy_errors.json)."""
+    tolerance of an fp32 closed loop against a float64 one over 400 steps (a stabilising feedback policy: the error does not grow).
+    Measured worst cases (gpurun_out/run_rl_policy_errors.json, round 3): position 1.7e-6 m, observation / reward 1.8e-6, thrust command
+    1.8e-4 %, azimuth 7e-7 rad, episode return 4e-4 of ~1 000; asserted at about ten times that."""
     import json
     import os
     import ml4ca_amd
@@ -322,25 +323,32 @@ def test_run_RL_policy_against_the_reference_harness_fixture(changes):
     worst = {}
     for k in range(E):
         L = int(eplen[k]) + 1                                       # records 0 .. EpLen
-        for name, key, tol in (('ned_pos', '_ned_pos', 2e-3), ('ned_ref', '_ned_ref', 1e-6), ('action_vec', '_action_vec', None),
-                               ('obs', '_obs', 2e-3), ('rew', '_rew', 2e-3)):
+        for name, key, tol in (('ned_pos', '_ned_pos', 2e-5), ('ned_ref', '_ned_ref', 1e-6), ('action_vec', '_action_vec', None),
+                               ('obs', '_obs', 2e-5), ('rew', '_rew', 2e-5)):
             got = res[name][:L, k].double().cpu().numpy()
             want = g[tag + key][k, :L]
             assert not np.isnan(want).any()
             err = np.abs(got - want)
             if name == 'action_vec':
-                # thrust columns in percent (scale 100), azimuth columns in rad; an azimuth command may sit on the +-pi seam of atan2
-                e_thr = err[:, 0:3].max()
-                da = np.abs(np.angle(np.exp(1j * (got[:, 3:6] - want[:, 3:6])))).max()
+                # thrust columns in percent (scale 100), azimuth columns in rad; an azimuth command may sit on the +-pi seam of atan2.
+                # Record 0 of episode 0 is not the initial action vector in the reference: test_policy.py:125 appends the live
+                # `action_vec` array itself (no copy), which :146 then keeps overwriting in place - the entry aliases whatever the
+                # vector held when the run ended (or when :152 rebound the name).  Later episodes append a copy (:176).  Skipped here,
+                # checked to BE that alias instead.
+                lo = 1 if k == 0 else 0
+                if k == 0:
+                    assert not np.allclose(want[0], [0, 0, 0, np.pi / 2, 0, 0]) and np.allclose(got[0], [0, 0, 0, np.pi / 2, 0, 0], atol=1e-6)
+                e_thr = err[lo:, 0:3].max()
+                da = np.abs(np.angle(np.exp(1j * (got[lo:, 3:6] - want[lo:, 3:6])))).max()
                 worst['thrust_pct'] = max(worst.get('thrust_pct', 0.0), float(e_thr))
                 worst['azimuth_rad'] = max(worst.get('azimuth_rad', 0.0), float(da))
-                assert e_thr < 0.5 and da < 5e-3, (k, e_thr, da)
+                assert e_thr < 2e-3 and da < 1e-5, (k, e_thr, da)
             else:
                 worst[name] = max(worst.get(name, 0.0), float(err.max()))
                 assert err.max() < tol, (name, k, float(err.max()), np.unravel_index(err.argmax(), err.shape))
     ret = res['EpRet'].double().cpu().numpy()
     worst['EpRet'] = float(np.abs(ret - g[tag + '_EpRet']).max())
-    assert worst['EpRet'] < 0.2, (ret, g[tag + '_EpRet'])
+    assert worst['EpRet'] < 5e-3, (ret, g[tag + '_EpRet'])
     out = os.path.join(root, 'gpurun_out')
     os.makedirs(out, exist_ok=True)
     path = os.path.join(out, 'run_rl_policy_errors.json')

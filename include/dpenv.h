@@ -240,6 +240,9 @@ typedef struct dpenv_policy_desc {
  * arrays may be freed or changed at once.  Fails with DPENV_EINVAL if the requested launch form cannot hold the networks in the
  * 160 KiB LDS; after a failed DPENV_ENOMEM no policy is in force. */
 int dpenv_set_policy_desc(dpenv_handle h, const dpenv_policy_desc* d, dpenv_stream s);
+/* What DPENV_LAUNCH_AUTO resolved to for the policy in force: *two_wave_out = 1 for the two-wave form, *envs_per_workgroup_out = 256 or
+ * 128 (host ints, either may be NULL). */
+int dpenv_get_policy_launch(dpenv_handle h, int32_t* two_wave_out, int32_t* envs_per_workgroup_out);
 /* Convenience forms (host pointers, F16, AUTO, null stream):
  * pi: obs_dim -> act_dim, v: obs_dim -> 1 (same hidden shape); log_std: host float[act_dim]; leak: hidden
  * leaky-relu slope (0.2 = tf.nn.leaky_relu default; 0 = relu).  Packs and uploads; may be called again after

@@ -101,6 +101,7 @@ SYMBOLS = {
     'dpenv_get_rng_counters': (C.c_int, [_VP, _VP, _VP, _VP]),
     'dpenv_set_rng_counters': (C.c_int, [_VP, _VP, _VP, _VP]),
     'dpenv_get_obs_thrust': (C.c_int, [_VP, _VP, _VP]),
+    'dpenv_get_policy_launch': (C.c_int, [_VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     'dpenv_set_obs_thrust': (C.c_int, [_VP, _VP, _VP]),
     'dpenv_thrust_map': (C.c_int, [C.POINTER(C.c_float), _VP, _VP, _VP, _I32, _VP]),
     'dpenv_gae': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _F, _F, _VP, _VP, _VP]),

@@ -686,6 +686,15 @@ extern "C" int dpenv_set_policy(dpenv_handle h, const dpenv_mlp* pi, const dpenv
     return dpenv_set_policy_ex(h, pi, v, log_std, DPENV_ACT_LEAKY_RELU, leak);
 }
 
+extern "C" int dpenv_get_policy_launch(dpenv_handle h, int32_t* two_wave_out, int32_t* envs_per_workgroup_out)
+{
+    if (!h) return DPENV_EINVAL;
+    if (!h->has_policy) return fail(h, DPENV_EINVAL, "dpenv_set_policy has not been called");
+    if (two_wave_out) *two_wave_out = h->pol.ws ? 1 : 0;
+    if (envs_per_workgroup_out) *envs_per_workgroup_out = h->pol.ws ? 64 * h->pol.ws_groups : 256;
+    return DPENV_OK;
+}
+
 extern "C" int dpenv_policy_forward(dpenv_handle h, const float* obs, float* mu_out, float* v_out, int32_t n, dpenv_stream s)
 {
     if (!h) return DPENV_EINVAL;

@@ -165,6 +165,13 @@ class ActorCritic(object):
         return self
 
 
+def policy_launch_form(env):
+    """('two_wave' | 'one_wave', envs per workgroup) that the uploaded policy's rollouts run in (what 'auto' resolved to)."""
+    tw, epw = C.c_int32(0), C.c_int32(0)
+    _lib.check(env.lib.dpenv_get_policy_launch(env._h, C.byref(tw), C.byref(epw)), env._h)
+    return ('two_wave' if tw.value else 'one_wave'), int(epw.value)
+
+
 def policy_forward(env, obs):
     """Deterministic actor mean and critic value for obs [n, obs_dim] on the env's device (dpenv_policy_forward)."""
     torch = _torch()

@@ -34,6 +34,14 @@ def main():
     ap.add_argument('--activation', default='leaky', choices=('leaky', 'relu', 'tanh'), help='hidden activation (train.py:24,31)')
     ap.add_argument('--precision', default='f32', choices=('f16', 'f32', 'f32_actor'),
                     help="in-kernel network arithmetic: 'f32' (split-f16, within 1e-5 of the fp32 update's own evaluation: the PPO ratio starts at 1) or 'f16' (fast)")
+    ap.add_argument('--exchange', default='gradients', choices=('gradients', 'rollout'),
+                    help="multi-rank runs: 'gradients' = every rank updates on ITS OWN episode and the gradients are averaged, exactly the "
+                         "reference (ppo.py:226, mpi_tf.py:29-62: no trajectory ever crosses); 'rollout' = BASELINE.json config 4: the ranks "
+                         "all-gather the episode (dist.EpisodeExchange: obs | act | logp chunk by chunk under the next chunk's launch, adv | ret "
+                         "after the local scan) and every rank runs the identical update on the global batch - no gradient all-reduce")
+    ap.add_argument('--chunks', type=int, default=4, help="--exchange rollout: pieces the episode is rolled out and posted in")
+    ap.add_argument('--reset-at-end', action='store_true', help='the reference\'s epoch boundary (ppo.py:305-322): every env is cut and re-drawn '
+                                                                'after the last step of an epoch (matters when --steps < max_ep_len)')
     ap.add_argument('--backend', default='nccl', help="'nccl' (RCCL, one GPU per rank) or 'gloo' (rehearsal)")
     ap.add_argument('--same-device', action='store_true', help='all ranks on cuda:0 (multi-rank rehearsal on a one-GPU box)')
     args = ap.parse_args()
@@ -62,6 +70,10 @@ def main():
     buf = rollout.RolloutBuffer(T, env, gamma=0.99, lam=0.97)
     ac.upload(env, precision=args.precision)          # device pointers: one packing kernel, no host copy
     env.reset()
+    gather = world > 1 and args.exchange == 'rollout'
+    ex = D.EpisodeExchange(buf.exchange_blocks(), n_chunks=args.chunks) if gather else None
+    if gather:
+        torch.manual_seed(args.seed)                  # identical minibatch draws on every rank: the updates stay identical without a broadcast
     if rank == 0:
         print('epoch  mean_reward/step(max 3.5)  terminated/1k-steps  pi_iters  KL      V-loss    rollout_ms  update_s')
     for epoch in range(args.epochs):
@@ -69,9 +81,22 @@ def main():
         t0 = time.perf_counter()
         # exploration noise is drawn inside the kernel (core.py:85), keyed by seed / global env id / draw index: no [T, n, 7]
         # noise block, and the trajectories do not depend on how many ranks share the envs
-        blk = buf.collect(env, sample=True)
-        buf.finish()
-        obs, act, adv, ret, logp_old = buf.get()
+        if gather:
+            # on-policy and overlapped: a piece of the episode crosses xGMI while the next piece is being rolled out; the advantages
+            # are scanned and normalised locally (24 bytes of statistics cross) and follow as 8 B per env-step
+            for c in range(ex.C):
+                blk = buf.collect(env, sample=True, rows=ex.rows(c), reset_at_end=args.reset_at_end)
+                ex.post_steps(c)
+            buf.finish()
+            buf.get()
+            ex.post_scan()
+            ex.wait()
+            obs, act, adv, ret, logp_old = (ex.flat(k) for k in ('obs', 'act', 'adv', 'ret', 'logp'))
+            obs = obs.float()
+        else:
+            blk = buf.collect(env, sample=True, reset_at_end=args.reset_at_end)
+            buf.finish()
+            obs, act, adv, ret, logp_old = buf.get()
         torch.cuda.synchronize()
         t_roll = time.perf_counter() - t0
         obs, act = obs.reshape(-1, 9), act.reshape(-1, 7)
@@ -87,12 +112,14 @@ def main():
             ratio = torch.exp(logp - logp_old[idx])
             a = adv[idx]
             pi_loss = -torch.min(ratio * a, torch.clamp(ratio, 1 - clip, 1 + clip) * a).mean()   # ppo.py:238-240
-            kl = float(D.mean_across_ranks((logp_old[idx] - logp).mean().detach()))   # mpi_avg(kl), ppo.py:267
+            kl_t = (logp_old[idx] - logp).mean().detach()
+            kl = float(kl_t if gather else D.mean_across_ranks(kl_t))             # mpi_avg(kl), ppo.py:267 (identical on every rank when gathered)
             if kl > 1.5 * target_kl:                                            # ppo.py:267-270
                 break
             pi_opt.zero_grad()
             pi_loss.backward()
-            D.average_gradients(pi_params)                                     # mpi_tf.py:59-62 (no-op on one rank)
+            if not gather:
+                D.average_gradients(pi_params)                                 # mpi_tf.py:59-62 (no-op on one rank)
             pi_opt.step()
             pi_iters += 1
         for i in range(80):                                                     # ppo.py:272-273
@@ -101,7 +128,8 @@ def main():
             v_loss = ((ret[idx] - v) ** 2).mean()                               # ppo.py:241
             v_opt.zero_grad()
             v_loss.backward()
-            D.average_gradients(v_params)
+            if not gather:
+                D.average_gradients(v_params)
             v_opt.step()
         with torch.no_grad():
             ac.log_std.clamp_(-4.0, 1.0)

@@ -13,16 +13,12 @@ pytestmark = pytest.mark.gpu
 
 
 def ref64(ac, obs):
-    """float64 evaluation of core.py:29-33 with the fp32 parameters: the yardstick for the 1e-5 claims."""
+    """float64 evaluation of core.py:29-33 with the fp32 parameters: the yardstick for the 1e-5 claims (oracle/policy_ref.py:
+    a restatement - TensorFlow is not in this image, so it is unpinned against the reference's own graph)."""
+    from oracle import policy_ref as PR
     torch = torch_()
-
-    def mlp(x, Ws, bs):
-        for W, b in zip(Ws[:-1], bs[:-1]):
-            z = x @ W.double() + b.double()
-            x = torch.tanh(z) if ac.activation == 'tanh' else torch.where(z > 0, z, ac.leak * z)
-        return x @ Ws[-1].double() + bs[-1].double()
-    x = obs.double()
-    return mlp(x, ac.pi_W, ac.pi_b), mlp(x, ac.v_W, ac.v_b)[:, 0]
+    mu, v = PR.actor_critic(ac.state_dict(), obs.detach().double().cpu().numpy(), activation=ac.activation, leak=ac.leak)
+    return torch.from_numpy(mu).to(obs.device), torch.from_numpy(v).to(obs.device)
 
 
 @pytest.mark.parametrize('mode,ext,hidden,activation', [

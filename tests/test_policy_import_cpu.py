@@ -189,3 +189,23 @@ def test_energy_metric_matches_the_reference_power_fixture():
     assert cum.shape == d['w_rand'].shape and np.abs(cum - d['w_rand']).max() <= 1e-12 * np.abs(d['w_rand']).max()
     tot = EV.work(torch.from_numpy(d['n_grid'])[:, None, :], dt=0.2).numpy()[0]
     assert np.abs(tot - d['w_grid'][-1]).max() <= 1e-12 * np.abs(d['w_grid'][-1]).max()
+
+
+def test_policy_yardstick_reproduces_the_checkpoint_fixture():
+    """oracle/policy_ref.py (the float64 restatement of core.py:29-46,80-107 that the network-arithmetic tests measure against) on the
+    thesis' shipped checkpoint: mu and v of tests/golden/final_policy.npz (an independent NumPy evaluation made when the checkpoint
+    bundle was read, tools/gen_golden.py), and the log-likelihood formula against a direct evaluation."""
+    from oracle import policy_ref as PR
+    d = np.load(os.path.join(G, 'final_policy.npz'))
+    params = {k.replace('.', '/'): d[k] for k in d.files if '.' in k}
+    mu, v = PR.actor_critic(params, d['obs'])
+    assert np.abs(mu - d['mu']).max() < 1e-5 * (np.abs(d['mu']).max() + 1) and np.abs(v - d['v']).max() < 1e-5 * (np.abs(d['v']).max() + 1)
+    rng = np.random.RandomState(0)
+    x = mu + np.exp(params['pi/log_std']) * rng.standard_normal(mu.shape)
+    lp = PR.gaussian_likelihood(x, mu, params['pi/log_std'])
+    z = (x - mu) / (np.exp(params['pi/log_std'].astype(np.float64)) + 1e-8)
+    want = (-0.5 * z * z - params['pi/log_std'] - 0.5 * np.log(2 * np.pi)).sum(1)
+    assert np.abs(lp - want).max() < 1e-12
+    # relu = leaky with slope 0, tanh: the other --activation choices (train.py:24,31)
+    assert np.all(PR.mlp(np.array([[-1.0]]), [np.eye(1), np.eye(1)], [np.zeros(1), np.zeros(1)], 'relu') == 0.0)
+    assert abs(PR.mlp(np.array([[0.5]]), [np.eye(1), np.eye(1)], [np.zeros(1), np.zeros(1)], 'tanh')[0, 0] - np.tanh(0.5)) < 1e-15

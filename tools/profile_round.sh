@@ -7,7 +7,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.p
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 250 --warmup 50 --no-cpu-baseline > $O/bench_pf.json 2> $O/pf.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 250 --warmup 50 --no-cpu-baseline > $O/bench_pw.json 2> $O/pw.err
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $O/pmc_sq -- python3 bench.py --steps 250 --warmup 50 --no-cpu-baseline > $O/bench_sq.json 2> $O/sq.err
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_INSTS_VALU --output-format csv -d $O/pmc_mfma -- python3 bench.py --steps 250 --warmup 50 --no-cpu-baseline > $O/bench_mf.json 2> $O/mf.err
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_mfma -- python3 bench.py --steps 250 --warmup 50 --no-cpu-baseline > $O/bench_mf.json 2> $O/mf.err
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_l2 -- python3 bench.py --steps 250 --warmup 50 --no-cpu-baseline > $O/bench_l2.json 2> $O/l2.err
 python3 bench.py > $O/bench_plain.json 2> $O/plain.err
 # condense on the box (the raw traces exceed what gpurun copies back), keep the summaries only

@@ -190,6 +190,18 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
                 else WS_EVAL(Wpi, Bpi, in0, in1);
 #pragma unroll
                 for (int k = 0; k < A; ++k) mu_mb[lane * 9 + k] = outv[k];
+#ifndef DPENV_WS_X_CARRY_FRAGS      // A/B switch (tools/): carry the fragments in registers across the actor's evaluation instead
+                if constexpr (SPLIT && !M_NOISE) {
+                    // The critic needs the fragments of o_t again.  Carried across the actor's evaluation they are 16 registers the
+                    // evaluation does not have (the 256-env geometry leaves a wave 256 registers and no AGPRs: they were spilled to
+                    // scratch and reloaded, ~30 scratch loads per step).  The row is still in the mailbox - the env wave overwrites it
+                    // with o_t+1 only after it has been given mu_t, which is posted below - so it is read and split a second time
+                    // here.  (The compiler barrier keeps the two reads two: the mailbox belongs to both waves.)
+                    asm volatile("" ::: "memory");
+                    row_from(obs_mb + (t & (OBS_SLOTS - 1)) * (64 * 9));
+                    obs_to_frags_x<OD>(o, inx);
+                }
+#endif
                 ws_post(&seq[1], t + 1, lane);                               // mu_t posted
 #ifdef DPENV_WS_M_PRIO_CRITIC
                 __builtin_amdgcn_s_setprio(DPENV_WS_M_PRIO_CRITIC);

@@ -5,7 +5,8 @@ Needs a library built with -DDPENV_WS_PROFILE (the kernel then accumulates s_mem
 leaves the totals in rows 0-4 of the logp block):
 
     cd ml4ca_amd/csrc && hipcc --offload-arch=gfx950 $(grep -m1 '^CXXFLAGS' Makefile | cut -d= -f2- | sed 's/$(BLOCK)/64/') \
-        -DDPENV_WS_PROFILE -shared -o ../../build/ab/prof.so dpenv_kernels.hip dpenv_policy.hip dpenv_api.hip
+        -DDPENV_WS_PROFILE -shared -o ../../build/ab/prof.so dpenv_kernels.hip dpenv_policy.hip dpenv_policy_ws.hip dpenv_policy_x.hip dpenv_policy_xws1.hip dpenv_policy_xws2.hip dpenv_api.hip
+    (add -DDPENV_DEV_FAST to build the shipped configuration only: seconds instead of minutes)
     DPENV_LIB=$PWD/build/ab/prof.so python tools/ws_profile.py
 """
 import sys
@@ -17,9 +18,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ml4ca_amd
 from ml4ca_amd.policy import ActorCritic, policy_rollout
 
-n, T = 65536, 50
+n, T = int(os.environ.get('WS_PROFILE_ENVS', 65536)), 50
+prec = os.environ.get('WS_PROFILE_PRECISION', 'f16')           # f16 | f32_actor | f32 (round 3: every arithmetic has the two-wave form)
 env = ml4ca_amd.BatchedRevoltEnv(n, auto_reset=True)
-ActorCritic(9, 7, (80, 80, 80), device=env.device).upload(env)
+ActorCritic(9, 7, (80, 80, 80), device=env.device).upload(env, precision=prec, launch_form='two_wave')
+print('%d envs, %s' % (n, prec))
 env.reset()
 for _ in range(3):
     out = policy_rollout(env, T, sample=True)

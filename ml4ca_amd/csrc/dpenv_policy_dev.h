@@ -707,8 +707,12 @@ __device__ __forceinline__ void mlp_eval_x(const uint4* Wh, const uint4* Wl, con
     struct Frag { uint32_t h[4], l[4]; };                 // one B fragment: high and low f16 parts, 8 features each
     Frag X[KS][2], Y[KS][2];
     float16v p0, p1, q0, q1;
-    const float* B2 = B;                                  // the same bias tiles through a pointer the compiler cannot see through:
-    asm volatile("" : "+v"(B2));                          // two reads stay two reads (see head())
+    // the same bias tiles through an offset the compiler cannot see through: two reads stay two reads (see head()).  The OFFSET is
+    // laundered, not the pointer: an asm-laundered pointer loses its LDS address space and every read through it becomes a
+    // flat_load (seen as 28 VMEM reads per evaluation in the PMC counters of the first round-3 build)
+    int b2_off = 0;
+    asm volatile("" : "+v"(b2_off));
+    const float* B2 = B + b2_off;
     auto FH = [](const Frag& f) { const uint4 q = {f.h[0], f.h[1], f.h[2], f.h[3]}; return __builtin_bit_cast(half8, q); };
     auto FL = [](const Frag& f) { const uint4 q = {f.l[0], f.l[1], f.l[2], f.l[3]}; return __builtin_bit_cast(half8, q); };
     // slot: three MFMAs of accumulator c with weights (wh, wl) and input fragment b; between them, unit `qq` (four activations:

@@ -13,8 +13,11 @@ import ml4ca_amd
 from ml4ca_amd.policy import ActorCritic, policy_rollout
 
 launches = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-n, T = 65536, 50
-for prec, form in (('f16', 'two_wave'), ('f16', 'one_wave'), ('f32', 'auto'), ('f32_actor', 'auto')):
+T = 50
+# round 3: every arithmetic in both launch forms, at 65 536 envs (256-env workgroups) and 32 768 envs (128-env workgroups); the one-wave form
+# of an arithmetic must also give the digests of its two-wave form (same rows bit for bit)
+ref = {}
+for n, prec, form in [(nn, p, f) for nn in (65536, 32768) for p in ('f16', 'f32_actor', 'f32') for f in ('two_wave', 'one_wave')]:
     digests = []
     for run in range(2):
         env = ml4ca_amd.BatchedRevoltEnv(n, auto_reset=True, seed=5, current=True, current_drift=True, max_ep_len=120)
@@ -31,7 +34,11 @@ for prec, form in (('f16', 'two_wave'), ('f16', 'one_wave'), ('f32', 'auto'), ('
         dig.append((int(st.view(torch.int32).to(torch.int64).sum()), int(ctr.to(torch.int64).sum())))
         digests.append(dig)
     same = digests[0] == digests[1]
-    print('%-9s %-8s %d launches x %d steps x %d envs: two runs %s' % (prec, form, launches, T, n, 'IDENTICAL' if same else 'DIFFER'))
+    cross = ref.setdefault((n, prec), digests[0]) == digests[0]
+    print('%-9s %-8s %d launches x %d steps x %d envs: two runs %s%s' % (prec, form, launches, T, n, 'IDENTICAL' if same else 'DIFFER',
+                                                                        '' if form == 'two_wave' else (', = the two-wave form' if cross else ', DIFFERS from the two-wave form')))
+    if not cross:
+        sys.exit(1)
     if not same:
         bad = [i for i, (a, b) in enumerate(zip(*digests)) if a != b]
         print('  first differing launch:', bad[0])

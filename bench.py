@@ -790,9 +790,16 @@ def main():
         del env5, buf5
 
     # ---- config-4 record (BASELINE.json configs[3]): measured at ITS shard size, on every rank ------------------------------
+    # (the headline above is what the driver's scaling curve is computed from: a failure in a side record must not take the line down.
+    # The same deterministic error is raised on every rank at the same point, so no rank is left waiting in a collective.)
     cfg4 = None
     if (args.config4 == 1) or (args.config4 < 0 and world > 1) or args.gather == 1:
-        cfg4 = config4_record(args, dev, rank, world, dist)
+        try:
+            cfg4 = config4_record(args, dev, rank, world, dist)
+        except Exception as e:       # pragma: no cover - reported, not hidden
+            import traceback
+            cfg4 = {'error': '%s: %s' % (type(e).__name__, e), 'traceback': traceback.format_exc()[-1500:]}
+            sys.stderr.write('bench.py: config-4 record failed on rank %d: %s\n' % (rank, cfg4['error']))
     classes = None
     if args.classes > 0 and rank == 0:
         classes = classes_record(args, dev, n)

@@ -231,3 +231,44 @@ def test_two_wave_policy_rollout_full_size_soak():
     s1, c1 = envs['two_wave'].get_state()
     assert torch.equal(s0, s1) and torch.equal(c0, c1)
     assert int(c1[1].min()) >= 1                    # every env went through at least one in-kernel reset
+
+
+def test_bench_line_with_every_record_at_reduced_size():
+    """bench.py end to end on one GPU at reduced size: the contract keys, roofline, cpu_baseline with its legs and the per-quantity error
+    ledger, the side legs, the config-4 record (every leg present, no error) and the vessel-class record.  The N > 1 runs of the driver
+    execute exactly this code plus the collectives (rehearsed over gloo in tests/test_host_cpu.py and profiles/r03c_rehearsal_*)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--envs', '8192', '--steps', '100', '--warmup', '50', '--cpu-seconds', '1.5',
+                        '--config4', '1', '--config4-envs', '4096', '--classes', '3'], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config'):
+        assert k in r, k
+    assert r['n_gpus'] == 1 and r['steps'] == 100 and r['warmup'] == 50 and r['dtype'] == 'f32' and r['vs_baseline'] is None
+    assert abs(r['value'] - 8192 / (r['ms_per_step'] * 1e-3)) < 1e-6 * r['value'] and 'math' in r['config']
+    rf = r['roofline']
+    assert rf['bound'] == 'hbm' and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-12 and rf['achieved'] < rf['peak']
+    cb = r['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['value'] == max(l['env_steps_per_s'] for l in cb['legs']) and cb['cores'] >= 1
+    led = cb['gpu_vs_cpu']
+    assert led['done_mismatches_elsewhere'] == 0 and led['max_rel_err_obs'] < 1e-5 and led['max_rel_err_reward'] < 1e-5
+    assert set(led['per_quantity']) >= {'obs.x~', 'obs.u', 'reward', 'reward.pos'}
+    assert r['group']['world_size'] == 1 and len(r['per_rank']['wall_s']) == 1
+    for leg in ('fused_rollout', 'policy_rollout', 'config5_ppo_rollout'):
+        assert leg in r, leg
+    assert 'two_wave' in r['policy_rollout']['policy_dtype_f32']['launch_form']
+    c4 = r['config4']
+    assert 'error' not in c4, c4
+    for leg in ('step_only', 'fused_rollout', 'closed_loop', 'exchange_76B', 'episode_plus_sync_exchange_76B',
+                'episode_with_previous_exchange_in_flight_76B', 'exchange_compact', 'summary'):
+        assert leg in c4, leg
+    assert c4['envs_per_rank'] == 4096 and c4['exchange_compact']['alone']['bytes_per_env_step'] == 58
+    assert set(c4['closed_loop']) >= {'policy_dtype_f16', 'policy_dtype_f32_actor', 'policy_dtype_f32'}
+    vc = r['vessel_classes']
+    assert {'classes_1', 'classes_3', 'classes_16'} <= set(vc) and vc['classes_3']['step_us'] > 0

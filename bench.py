@@ -17,11 +17,11 @@ env.step of every env = one launch of step_kernel.  Envs shard across ranks with
 (weak scaling: 65 536 envs per GPU); the episode-boundary trajectory all-gather of config 4 is timed as a
 separate, clearly labelled leg and is NOT part of `value`.
 
-The step loop is captured into a HIP graph so that host launch overhead does not sit between kernels: chunks of 50 steps
-(the gcd of the box sequence's segment lengths) when --steps is a multiple of 50, otherwise one graph of exactly --steps
-(<= 100) or of the largest divisor of --steps that is <= 50.  Exactly --warmup steps run untimed first.  The timed region is
-exactly --steps env steps, repeated `repeats` times back to back (reported; chosen so that the region lasts >= 10 ms, because a
-single 50-step graph is 0.3 ms and host replay / sync latency would otherwise be a tenth of it); ms_per_step = time / (steps x repeats).
+The step loop is captured into ONE HIP graph of lcm(--steps, 1250) env steps - a whole number of --steps regions AND of box sequences, with
+the setpoint switches inside the graph - so that neither host launch overhead nor graph seams nor per-replay setpoint copies sit between
+the kernels (round 3; tools/graph_chunk_sweep.py measures what they cost).  Exactly --warmup steps run untimed first.  The timed region is
+exactly --steps env steps, repeated `repeats` times back to back (reported; a multiple of the graph's own repeat count, chosen so that the
+region lasts >= 10 ms); ms_per_step = time / (steps x repeats).
 """
 import argparse
 import json
@@ -545,15 +545,8 @@ def main():
     g.manual_seed(1234 + rank)
     K = max(1, args.steps)
     W = max(0, args.warmup)
-    # steps per captured graph: 50 (the box schedule's granule) when it divides K, else K itself (small) or its largest divisor <= 50
-    if K % CHUNK == 0:
-        C = CHUNK
-    elif K <= 100:
-        C = K
-    else:
-        C = max(d for d in range(1, CHUNK + 1) if K % d == 0)
     # synthetic inputs, resident in HBM before the timed region
-    actions = torch.randn((max(C, CHUNK), n, 7), generator=g, device=dev) * 0.6065
+    actions = torch.randn((CHUNK, n, 7), generator=g, device=dev) * 0.6065
     # testing-style start (simtools.py:81-88 radius/heading) with the setpoint at the start pose: the box is relative
     init = torch.zeros((6, n), device=dev)
     init[0:2] = (torch.rand((2, n), generator=g, device=dev) - 0.5) * 4.0
@@ -567,68 +560,89 @@ def main():
     rew = torch.empty(n, device=dev)
     done = torch.empty(n, dtype=torch.uint8, device=dev)
 
-    def chunk(c=None):
-        # first step of a chunk (re-)applies the setpoint in force: a no-op unless the sequence switched
-        c = C if c is None else c
-        env.step(actions[0], new_ref=ref_buf, out=(obs, rew, done))
-        for k in range(1, c):
-            env.step(actions[k], out=(obs, rew, done))
+    SEQ = 1250                                         # length of the box sequence in env steps
+    NA = actions.shape[0]
 
+    def ref_for(t):
+        """the setpoint handed to env.step as new_ref at step t of the box sequence: the new one at a switch step, the start pose when the
+        sequence wraps, nothing otherwise (customEnv.py:131: applied after that step's observation, visible from the next)"""
+        t %= SEQ
+        if t == 0:
+            return start
+        return refs[BOX_SWITCH_STEPS.index(t)] if t in BOX_SWITCH_STEPS else None
+
+    def step_at(t):
+        env.step(actions[t % NA], new_ref=ref_for(t), out=(obs, rew, done))
+
+    # Launch form of the timed region.  One HIP graph holds G = lcm(K, 1250) env steps = G / K back-to-back repeats of the K-step region,
+    # with the setpoint switches INSIDE the graph (new_ref at the switch steps): every replay then starts at the same point of the box
+    # sequence, the host issues nothing between the kernels, and the seam between two graph replays - 0.1-0.6 us per step for graphs of
+    # 10-50 steps plus a setpoint copy before every replay (tools/graph_chunk_sweep.py: 5.29 us per step for 50-step graphs with the copy,
+    # 5.10 for >= 250-step graphs without) - is host launch overhead, not env.step.  For a K whose lcm with 1250 is too long, or with
+    # --no-graph, the steps are launched one by one (slower: the host is then in the loop).
+    from math import gcd
+    G = K * SEQ // gcd(K, SEQ)
+    aligned = G <= 7500
+    if not aligned:
+        # an awkward --steps: the graph holds the smallest whole number of K-step regions that covers one box sequence, and the sequence
+        # restarts with every replay (its last leg - back at the start pose - is up to K - 1 steps longer); said in config.launch
+        G = K * (-(-SEQ // K))
+    use_graph = not args.no_graph
+    pos = {'t': 0}
+    for t in range(W):                                 # exactly W untimed warm-up steps, eager
+        step_at(t)
+    pos['t'] = W
     graph = None
-    if not args.no_graph:
-        s = torch.cuda.Stream(device=dev)
-        s.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(s):
-            chunk()                                   # warm the launch path before capture
-        torch.cuda.current_stream(dev).wait_stream(s)
+    if use_graph:
+        s_ = torch.cuda.Stream(device=dev)
+        s_.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s_):
+            step_at(W)                                # warm the launch path before capture (one extra untimed step, state only)
+        torch.cuda.current_stream(dev).wait_stream(s_)
         torch.cuda.synchronize(dev)
+        env.reset(init=init, new_ref=start.clone())   # back to the start pose: the graph is captured from sequence position W
+        for t in range(W):
+            step_at(t)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            chunk()
+            for s_i in range(G):
+                step_at(W + s_i)
 
-    state = {'t': 0}
+    def run_region():
+        """G env steps (= G / K repeats of the K-step region) from sequence position W (mod 1250)"""
+        if graph is not None:
+            graph.replay()
+        else:
+            for s_i in range(G):
+                step_at(pos['t'] + s_i)
+        pos['t'] += G
 
-    def apply_schedule():
-        """setpoint in force at env step t of the 1250-step box sequence (switches take effect at the next chunk start)"""
-        t = state['t'] % 1250
-        k = sum(1 for sw in BOX_SWITCH_STEPS if sw <= t)
-        ref_buf.copy_(start if k == 0 else refs[k - 1])
-
-    def run_steps(k):
-        """advance exactly k env steps: whole chunks by graph replay, a remainder (warm-up only) by eager launches"""
-        for _ in range(k // C):
-            apply_schedule()
-            if graph is not None:
-                graph.replay()
-            else:
-                chunk()
-            state['t'] += C
-        if k % C:
-            apply_schedule()
-            chunk(k % C)
-            state['t'] += k % C
-
-    run_steps(W)
-    # how often to repeat the K-step region so that it lasts >= MIN_TIMED_MS: from one untimed pass (also a warm-up of the graph)
+    # how often to replay so that the timed region lasts >= MIN_TIMED_MS: from one untimed pass (also a warm-up of the graph)
     cal0, cal1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(dev)
     cal0.record()
-    run_steps(K)
+    run_region()
     cal1.record()
     torch.cuda.synchronize(dev)
-    R = args.repeats if args.repeats > 0 else max(1, int(-(-MIN_TIMED_MS // max(cal0.elapsed_time(cal1), 1e-3))))
+    per_region = G // K                                 # repeats of the K-step region inside one graph
+    if args.repeats > 0:
+        RG = max(1, -(-args.repeats // per_region))
+    else:
+        RG = max(1, int(-(-MIN_TIMED_MS // max(cal0.elapsed_time(cal1), 1e-3))))
     if world > 1:
-        rt = torch.tensor([R], device=dev, dtype=torch.int64)
+        rt = torch.tensor([RG], device=dev, dtype=torch.int64)
         dist.all_reduce(rt, op=dist.ReduceOp.MAX)      # every rank times the same amount of work
-        R = int(rt[0])
+        RG = int(rt[0])
+    R = RG * per_region
+    C = G
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(R):
-        run_steps(K)
+    for _ in range(RG):
+        run_region()
     ev1.record()
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -828,8 +842,11 @@ def main():
                        'envs_per_gpu': n, 'total_envs': total_envs, 'integrator': 'semi-implicit Euler 20 x 10 ms',
                        'math': 'lean call-free sincos / atan2 (<= 9.2e-8 / 2.6e-7 abs), v_rsq / v_exp / v_sqrt hardware transcendentals; no -ffast-math; '
                                'fp32 state; error against the libm fp32 oracle: cpu_baseline.gpu_vs_cpu',
-                       'launch': 'eager' if graph is None else 'hipGraph replay, %d steps per graph' % C,
-                       'timed_region': '%d steps x %d repeats back to back (%.1f ms)' % (K, R, wall * 1e3),
+                       'launch': 'one launch per step from the host (no graph)' if graph is None else
+                                 ('hipGraph replay: %d env steps per graph = lcm(steps, 1250) = %d repeats of the %d-step region, setpoint switches inside the graph' % (G, per_region, K)
+                                  if aligned else 'hipGraph replay: %d env steps per graph = %d repeats of the %d-step region covering one box sequence '
+                                  '(lcm(steps, 1250) is too long: the sequence restarts with every replay), setpoint switches inside the graph' % (G, per_region, K)),
+                       'timed_region': '%d steps x %d repeats back to back = %d graph replay(s) (%.1f ms)' % (K, R, RG, wall * 1e3),
                        'sharding': 'independent env shards, no data-path collective',
                        'backend': args.backend if world > 1 else None},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',

@@ -22,8 +22,8 @@ namespace dpenv {
 //      draw xi_t+1 (Philox + Box-Muller) while waiting       logp, action / reward / done / observation rows; wait V; val, boot rows
 //  The chain actor(o_t) -> env.step(t) -> actor(o_t+1) stays serial; the critic - half of the network work - and the exploration
 //  noise run beside the env step, the row bookkeeping beside the actor.  Same mlp_eval chains and same env_step as
-//  policy_rollout_kernel: every row is bit-identical.  (ROLES = 2 is the product; ROLES = 3 below is a measured
-//  alternative kept behind -DDPENV_WS3.)
+//  policy_rollout_kernel: every row is bit-identical.  (ROLES = 2: an env wave and a network wave.  Two three-wave forms - a critic wave
+//  of its own; the network wave split by env tile - were built and measured in round 2, were slower, and are gone: DESIGN.md section 4.)
 // =============================================================================================
 //  Arithmetic (PREC): PREC_F16 - the fast mode; PREC_F32 - actor and critic in the split-f16 arithmetic of mlp_eval_x (the network
 //  wave reads a second, LOW image of the weights); PREC_F32_ACTOR - actor split, critic plain f16 on the high image.  The split
@@ -39,13 +39,6 @@ static_assert(4 * WS_GROUP_FLOATS * 4 == POLICY_WS_MAILBOX_BYTES, "dpenv_dev.h: 
 static_assert(4 * WS_GROUP_FLOATS_X * 4 == POLICY_WS_MAILBOX_X_BYTES, "dpenv_dev.h: POLICY_WS_MAILBOX_X_BYTES out of step with the mailbox layout");
 __host__ __device__ constexpr int ws_images(int prec) { return prec == PREC_F16 ? 2 : (prec == PREC_F32_ACTOR ? 3 : 4); }
 
-//  ROLES = 3 (768-thread workgroups, three waves per SIMD) splits the NETWORK wave by env tile: wave 4 + g evaluates actor and
-//  critic for envs 0..31 of group g, wave 8 + g for envs 32..63 (mlp_eval_tile: half the MFMAs, half the packing, half the
-//  registers per wave, no cross-lane moves: a tile's fragments are read from the mailbox in operand layout and its outputs go back
-//  in accumulator layout).  The serial chain env.step(t) -> actor(o_t+1) -> env.step(t+1) then holds HALF an actor evaluation,
-//  and the two network streams of a SIMD fill each other's MFMA / dependency stalls.  (An env / actor / critic split of the
-//  three waves was measured first and is slower than two roles: each network wave still runs a full two-tile evaluation on the
-//  chain, at 168 VGPRs it spills; profiles/r02_closed_loop_forms.txt.)
 // pair-level hand-over inside a workgroup: a sequence word in LDS, released by one wave and acquired by its partner.
 // Both waves of a pair belong to the same workgroup, so they are always co-resident; the waiter sleeps between polls.
 __device__ __forceinline__ void ws_post(int* p, int v, int lane)
@@ -100,7 +93,7 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
 #ifdef DPENV_WS_SWAP_ROLES
     const int role = (ROLES - 1) - (wave / GROUPS); // diagnostic: the network waves are the first-dispatched (older) ones
 #else
-    const int role = wave / GROUPS;                 // 0 = env wave, 1 = network wave (ROLES 2) / network wave of tile 0 (ROLES 3), 2 = of tile 1
+    const int role = wave / GROUPS;                 // 0 = env wave, 1 = network wave
 #endif
     const int g = wave % GROUPS;
     constexpr int OBS_SLOTS = 1;
@@ -112,7 +105,6 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
     float* v_mb = mu_mb + 64 * 9;                // [2][64] V(o_t), by step parity
     float* vpre_mb = v_mb + 128;                 // [2][64] V(pre-reset o_t), by step parity
     int* seq = (int*)(vpre_mb + 128);            // [0] observations posted, [1] means posted, [2] values posted, [4..5] pre flags,
-                                                 // [6] / [7] means / values posted by the network wave of tile 1 (ROLES 3)
     int* flag = seq + 4;
     // Two roles: the NETWORK wave draws the exploration noise (Philox + Box-Muller, ~300 VALU per step) while it waits for the
     // next observation - with the noise in the env wave that wave was the busy one (tools/ws_profile.py).  xi_t travels in the

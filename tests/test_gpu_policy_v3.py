@@ -63,6 +63,20 @@ def test_two_wave_form_writes_the_one_wave_rows(precision, n):
     assert int(((done & 2) != 0).sum()) >= n and bool(torch.isfinite(a['boot']).all()) and bool((a['boot'] != 0).any())
 
 
+@pytest.mark.parametrize('n', [1, 63, 64, 65, 127, 129, 257])
+def test_two_wave_forms_at_ragged_batch_sizes(n):
+    """batch sizes around the group (64 envs) and workgroup (128 envs) boundaries of the two-wave geometry, in every arithmetic: a group
+    without envs leaves, a partial group clamps its lanes, and the rows are those of the one-wave form"""
+    torch = torch_()
+    for precision in ('f16', 'f32_actor', 'f32'):
+        (a, b), (sa, sb) = _pair_of_launches(n, 7, precision, seed=3 + n)
+        for k in ROWS:
+            assert torch.equal(a[k], b[k]), (precision, n, k)
+        for x, y in zip(sa, sb):
+            assert torch.equal(x, y)
+        assert bool(torch.isfinite(a['val']).all())
+
+
 @pytest.mark.parametrize('precision,form', [('f32_actor', 'two_wave'), ('f32', 'two_wave')])
 def test_two_wave_split_evaluations_equal_the_forward_kernel_at_full_size(precision, form):
     """65 536 envs, deterministic actions: every stored action and value of the two-wave launch equals what the forward kernel computes

@@ -238,7 +238,9 @@ typedef struct dpenv_policy_desc {
  * packing if they are issued on `s` (or on a stream the caller orders behind `s`).  device_pointers = 1: stream-ordered, no host
  * synchronisation, graph-capturable.  device_pointers = 0 (host arrays): the call synchronises `s` before it returns, so the
  * arrays may be freed or changed at once.  Fails with DPENV_EINVAL if the requested launch form cannot hold the networks in the
- * 160 KiB LDS; after a failed DPENV_ENOMEM no policy is in force. */
+ * 160 KiB LDS; after a failed DPENV_ENOMEM no policy is in force.  While `s` is being captured into a graph the event bookkeeping is
+ * skipped (the graph's own edges order its nodes): a captured rollout keeps reading the image that was current at capture time, so do
+ * not upload more than once between two replays of a graph that does not contain the upload itself. */
 int dpenv_set_policy_desc(dpenv_handle h, const dpenv_policy_desc* d, dpenv_stream s);
 /* What DPENV_LAUNCH_AUTO resolved to for the policy in force: *two_wave_out = 1 for the two-wave form, *envs_per_workgroup_out = 256 or
  * 128 (host ints, either may be NULL). */
@@ -304,7 +306,9 @@ int dpenv_set_rng_counters(dpenv_handle h, const uint32_t* noise_ctr_in, const u
  * the observation its predecessor ended with: the library keeps that observation's thrust columns (device float[n_envs][4]: o[6], o[7],
  * o[8], unused) and uses them while nothing else (reset, step, rollout, set_state) has touched the state in between - dpenv_step
  * callers hold the returned observation themselves.  get fails with DPENV_EINVAL when there is nothing to continue; set is for
- * restoring a mid-episode checkpoint (after dpenv_set_state). */
+ * restoring a mid-episode checkpoint (after dpenv_set_state).  Whether a launch continues or rebuilds is decided on the host when
+ * dpenv_policy_rollout is CALLED: inside a captured graph the first closed-loop launch keeps the decision made at capture time on
+ * every replay (capture a graph that starts with a continuing launch after one such launch has run). */
 int dpenv_get_obs_thrust(dpenv_handle h, float* out, dpenv_stream s);
 int dpenv_set_obs_thrust(dpenv_handle h, const float* in, dpenv_stream s);
 

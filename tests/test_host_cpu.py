@@ -362,3 +362,27 @@ def test_bench_refuses_more_ranks_than_devices():
     env.pop('WORLD_SIZE', None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 3 and 'only' in p.stderr and 'device(s) visible' in p.stderr and p.stdout.strip() == ''
+
+
+def test_episode_exchange_single_process_is_a_copy():
+    """dist.EpisodeExchange without a process group (one rank): the 'gather' degenerates to copies into the chunk-major output; the views
+    flat() / episode_order() address the same samples as the blocks themselves."""
+    import torch
+    from ml4ca_amd import dist as D
+    T, n = 12, 5
+    g = torch.Generator().manual_seed(0)
+    blocks = {'obs': torch.randn((T, n, 9), generator=g).to(torch.bfloat16), 'act': torch.randn((T, n, 7), generator=g),
+              'logp': torch.randn((T, n), generator=g), 'adv': torch.randn((T, n), generator=g), 'ret': torch.randn((T, n), generator=g)}
+    for C in (1, 3, 4, 12):
+        ex = D.EpisodeExchange(blocks, n_chunks=C)
+        assert [ex.rows(c) for c in range(C)] == [(c * T // C, (c + 1) * T // C) for c in range(C)]
+        for c in range(C):
+            ex.post_steps(c)
+        ex.post_scan()
+        out = ex.wait()
+        for k, b in blocks.items():
+            assert out[k].shape[:3] == (C, 1, T // C)
+            assert torch.equal(ex.episode_order(k)[0], b)
+            assert torch.equal(ex.flat(k), b.reshape((T * n,) + tuple(b.shape[2:])))
+    with pytest.raises(ValueError):
+        D.EpisodeExchange(blocks, n_chunks=5)

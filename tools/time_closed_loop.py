@@ -15,7 +15,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--envs', default='65536,32768')
     ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--reps', type=int, default=8)
+    ap.add_argument('--reps', type=int, default=30)
+    ap.add_argument('--warm', type=int, default=40, help='untimed launches first: the MFMA-heavy forms wobble by 10-30 %% for the first ~20 launches of a process (clock / power ramp)')
     ap.add_argument('--out', default='')
     ap.add_argument('--forms', default='f16:two_wave,f16:one_wave,f32_actor:two_wave,f32_actor:one_wave,f32:two_wave,f32:one_wave')
     args = ap.parse_args()
@@ -38,7 +39,7 @@ def main():
                 continue
             env.reset()
             out = policy_rollout(env, args.steps, sample=True)
-            for _ in range(2):
+            for _ in range(args.warm):
                 policy_rollout(env, args.steps, sample=True, out=out)
             torch.cuda.synchronize()
             best = 1e9

@@ -47,8 +47,11 @@ __device__ __forceinline__ void ws_post(int* p, int v, int lane)
 }
 __device__ __forceinline__ void ws_wait(int* p, int v)
 {
+#ifndef DPENV_WS_POLL_SLEEP
+#define DPENV_WS_POLL_SLEEP 2      // x 64 cycles between polls (A/B'd in round 3: 0 / 1 / 2 / 4 within noise in both geometries)
+#endif
     while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < v)
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(DPENV_WS_POLL_SLEEP);
 }
 #ifdef DPENV_WS_PROFILE
 #define WS_WAIT_T(acc, p, v) do { const uint64_t t0_ = __builtin_amdgcn_s_memtime(); ws_wait(p, v); acc += __builtin_amdgcn_s_memtime() - t0_; } while (0)

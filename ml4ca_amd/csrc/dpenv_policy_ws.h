@@ -79,7 +79,10 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
     constexpr int OD = EXT ? 9 : 6;
     constexpr int THREADS = 64 * GROUPS * ROLES;
     constexpr bool SPLIT = PREC != PREC_F16;
-    constexpr bool STAGE = !SPLIT;                  // env-wave rows through LDS transposes (else per lane)
+#ifndef DPENV_WS_STAGE_ACTOR
+#define DPENV_WS_STAGE_ACTOR 0
+#endif
+    constexpr bool STAGE = !SPLIT || (PREC == PREC_F32_ACTOR && DPENV_WS_STAGE_ACTOR);   // env-wave rows through LDS transposes (else per lane)
     constexpr int NIMG = ws_images(PREC);           // weight images staged: pi_hi, v_hi (, pi_lo (, v_lo))
     static_assert(ROLES == 2, "an env wave and a network wave per 64 envs (the three-wave forms of round 2 were measured, rejected and removed: DESIGN.md section 4)");
     static_assert(GROUPS == 4 || GROUPS == 2, "workgroups of 256 or 128 envs");
@@ -464,6 +467,9 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
 // Two-wave launches exist for hidden activation leaky-relu / relu in every arithmetic; tanh only in PREC_F16 with four groups
 // (dpenv_set_policy_desc routes the others to the one-wave kernels).  -DDPENV_DEV_FAST (development builds only, never shipped)
 // instantiates the shipped configuration alone: final / continuous angles / extended state, width <= 80.
+#ifndef DPENV_WS_STAGE_ACTOR
+#define DPENV_WS_STAGE_ACTOR 0
+#endif
 namespace dpenv_ws_launch {
 using namespace dpenv;
 
@@ -473,7 +479,7 @@ static hipError_t go(const StepArgs& a, const PolicyArgs& pa, hipStream_t s)
     constexpr int ROLES = 2;
     const dim3 grid((a.n + 64 * GROUPS - 1) / (64 * GROUPS));
     const size_t lds = (size_t)ws_images(PREC) * pa.nent * 16 + (size_t)2 * pa.nblk * 32 * 4 +
-                       (size_t)GROUPS * (PREC == PREC_F16 ? WS_GROUP_FLOATS : WS_GROUP_FLOATS_X) * 4;
+                       (size_t)GROUPS * ((PREC == PREC_F16 || (PREC == PREC_F32_ACTOR && DPENV_WS_STAGE_ACTOR)) ? WS_GROUP_FLOATS : WS_GROUP_FLOATS_X) * 4;
     hipError_t e = hipFuncSetAttribute((const void*)policy_rollout_ws_kernel<MODE, EXT, KA, ROLES, PREC, GROUPS>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

@@ -272,3 +272,37 @@ def test_bench_line_with_every_record_at_reduced_size():
     assert set(c4['closed_loop']) >= {'policy_dtype_f16', 'policy_dtype_f32_actor', 'policy_dtype_f32'}
     vc = r['vessel_classes']
     assert {'classes_1', 'classes_3', 'classes_16'} <= set(vc) and vc['classes_3']['step_us'] > 0
+
+
+def test_bench_two_ranks_started_by_bench_itself_on_one_gpu():
+    """The N > 1 bench line end to end, as far as one GPU allows: `python bench.py --gpus 2` with no launcher around it starts its two
+    ranks as a child process, both use this GPU (--same-device) and talk over gloo; the line must carry the headline (2 x envs), the
+    process-group record (2 ranks, their pids) and every leg of the config-4 record, collectives included.  What the driver's N > 1 runs
+    add is RCCL instead of gloo and a GPU per rank."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--same-device', '--envs', '4096',
+                        '--steps', '20', '--warmup', '5', '--config4-envs', '1024'], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r['n_gpus'] == 2 and r['config']['total_envs'] == 8192 and r['scaling'] == 'weak' and r['cpu_baseline'] is None
+    assert r['group']['world_size'] == 2 and r['group']['backend'] == 'gloo' and len({x['pid'] for x in r['group']['ranks']}) == 2
+    assert len(r['per_rank']['wall_s']) == 2 and r['per_rank']['ms_per_step_max'] >= r['per_rank']['ms_per_step_min'] > 0
+    assert abs(r['value'] - 8192 / (r['ms_per_step'] * 1e-3)) < 1e-6 * r['value']
+    assert 'fused_rollout' not in r                               # the single-GPU side legs stay home when there is more than one rank
+    c4 = r['config4']
+    assert 'error' not in c4, c4
+    assert c4['ranks'] == 2 and c4['total_envs'] == 2048
+    for leg in ('step_only', 'fused_rollout', 'closed_loop', 'exchange_76B', 'episode_plus_sync_exchange_76B',
+                'episode_with_previous_exchange_in_flight_76B', 'exchange_compact'):
+        assert leg in c4, leg
+    assert c4['exchange_76B']['recv_GBps_per_rank'] > 0 and c4['exchange_compact']['alone']['recv_GBps_per_rank'] > 0
+    assert {'chunks_1', 'chunks_4', 'chunks_8'} <= set(c4['exchange_compact'])

@@ -373,3 +373,39 @@ def test_run_RL_policy_against_the_reference_harness_fixture(changes):
     rec[tag] = worst
     json.dump(rec, open(path, 'w'), indent=1)
     env.close()
+
+
+def test_new_entry_points_validate_their_arguments():
+    """round-3 additions to the C ABI fail loudly on misuse: NULL buffers, no policy in force, nothing to continue"""
+    import ctypes as C
+    import ml4ca_amd
+    from ml4ca_amd import _lib
+    from ml4ca_amd.policy import policy_launch_form, policy_rollout
+    torch = torch_()
+    env = ml4ca_amd.BatchedRevoltEnv(300, auto_reset=True, current=False)
+    lib, h = env.lib, env._h
+    tw, epw = C.c_int32(-1), C.c_int32(-1)
+    assert lib.dpenv_get_policy_launch(h, C.byref(tw), C.byref(epw)) == _lib.EINVAL and b'set_policy' in lib.dpenv_last_error(h)
+    with pytest.raises(_lib.DpenvError):
+        policy_launch_form(env)
+    assert lib.dpenv_get_rng_counters(h, None, None, None) == _lib.EINVAL
+    assert lib.dpenv_set_rng_counters(h, None, None, None) == _lib.EINVAL
+    assert lib.dpenv_set_obs_thrust(h, None, None) == _lib.EINVAL
+    buf = torch.zeros((300, 4), device=env.device)
+    assert lib.dpenv_get_obs_thrust(h, C.c_void_p(buf.data_ptr()), None) == _lib.EINVAL       # nothing to continue yet
+    assert lib.dpenv_set_current_present(h, C.c_void_p(buf.data_ptr()), C.c_void_p(buf.data_ptr()), None) == _lib.EINVAL   # current not enabled
+    make_ac(9, 7, (80, 80, 80), device=env.device).upload(env, precision='f32_actor')
+    assert policy_launch_form(env) == ('two_wave', 128)             # 300 envs: the 128-env workgroup geometry
+    env.reset()
+    out = policy_rollout(env, 3, sample=True)
+    lag = env.get_obs_thrust()
+    assert lag is not None and torch.equal(lag[:, 0:3], out['last_obs'][:, 6:9])
+    nc, dc = env.get_rng_counters()
+    assert int(nc.min()) == 3 and int(dc.max()) == 0
+    env.step(out['act'][0].contiguous())
+    assert env.get_obs_thrust() is None                              # a single step invalidates the continuation
+    big = ml4ca_amd.BatchedRevoltEnv(40000)
+    make_ac(9, 7, (80, 80, 80), device=big.device).upload(big, precision='f16')
+    assert policy_launch_form(big) == ('two_wave', 256)
+    make_ac(9, 7, (80, 80, 80), device=big.device, activation='tanh').upload(big, precision='f32')
+    assert policy_launch_form(big) == ('one_wave', 256)

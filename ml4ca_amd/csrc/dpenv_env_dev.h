@@ -636,21 +636,40 @@ __device__ __forceinline__ void env_step(const StepArgs& a, const Vessel& ve, En
     env_observe<MODE, EXT>(a, s, act, w, pt_old, ang_prev, has_ref, nrN, nrE, nrP, out);
 }
 
-// auto-reset of one finished env: ENV:135-194 with the training sampler; returns the new episode's first obs
+// auto-reset of one finished env: ENV:135-194 with the training sampler; returns the new episode's first obs.
+// Two pieces, so that a kernel with idle time can take the draw off its critical path: reset_draw (the Philox / Box-Muller part, a
+// pure function of (seed, global env id, episode)) and reset_apply (state assignment + first observation).
+struct ResetDraw {
+    float eta[3], nu[3], pt[3];
+};
+
 template <int MODE>
-__device__ __forceinline__ void env_auto_reset(const StepArgs& a, Env& s, int64_t gid, uint32_t episode, float o_new[9])
+__device__ __forceinline__ void reset_draw(const StepArgs& a, int64_t gid, uint32_t episode, ResetDraw& d)
 {
-    float eta[3], nu[3];
-    sample_reset<MODE>(a, gid, episode, eta, nu);
-    s.N = eta[0]; s.E = eta[1]; s.psi = eta[2]; s.u = nu[0]; s.v = nu[1]; s.r = nu[2];
-    s.pt[0] = s.pt[1] = s.pt[2] = 0.0f;                         // ENV:190
-    if (a.reset_acts) sample_reset_thrust(a, gid, episode, s.pt);   // ENV:179-188
+    sample_reset<MODE>(a, gid, episode, d.eta, d.nu);
+    d.pt[0] = d.pt[1] = d.pt[2] = 0.0f;                         // ENV:190
+    if (a.reset_acts) sample_reset_thrust(a, gid, episode, d.pt);   // ENV:179-188
+}
+
+template <int MODE>
+__device__ __forceinline__ void reset_apply(const StepArgs& a, Env& s, const ResetDraw& d, float o_new[9])
+{
+    s.N = d.eta[0]; s.E = d.eta[1]; s.psi = d.eta[2]; s.u = d.nu[0]; s.v = d.nu[1]; s.r = d.nu[2];
+    s.pt[0] = d.pt[0]; s.pt[1] = d.pt[1]; s.pt[2] = d.pt[2];
     default_angles<MODE>(s.ang[0], s.ang[1], s.ang[2]);         // ENV:173-177,192
     s.steps = 0;
     bool same;
     make_obs(s.N, s.E, s.psi, s.u, s.v, s.r, s.refN, s.refE, s.refPsi, s.pt, a.wrap_mode == WRAP_REFERENCE, o_new, s.sn, s.cs,
              same);
     if (!same) sincos_lean(s.psi, s.sn, s.cs);
+}
+
+template <int MODE>
+__device__ __forceinline__ void env_auto_reset(const StepArgs& a, Env& s, int64_t gid, uint32_t episode, float o_new[9])
+{
+    ResetDraw d;
+    reset_draw<MODE>(a, gid, episode, d);
+    reset_apply<MODE>(a, s, d, o_new);
 }
 
 __device__ __forceinline__ void load_env(const StepArgs& a, int il, Env& s)

@@ -294,6 +294,16 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
     // envs.  The rows of step t (action, log-likelihood, reward, done, the observation row of t+1) are written after the
     // hand-over, while the network wave evaluates mu_t+1.
     put_rows_o(pa.obs_out, 0, o);
+    // Pre-drawn reset sample.  A reset sits on the serial chain of the step (o_t+1 of a re-drawn env is its first observation), and with
+    // termination on some env of a 64-env wave ends in about every fourth step, so the whole wave pays the Philox draw there.  The
+    // draw is a pure function of (seed, global env id, episode): it is made while this wave waits for the actor's answer, for the episode
+    // that would start next, and a reset on the chain is an assignment plus the first observation.  Same values, same rows.
+#ifndef DPENV_WS_PREDRAW
+#define DPENV_WS_PREDRAW 1
+#endif
+    constexpr bool PREDRAW = DPENV_WS_PREDRAW != 0;      // measured (round 3, same call): 1-2 % in every form, e.g. f16 7.28 -> 7.18 us at 65 536 envs
+    ResetDraw rdraw;
+    bool need_draw = PREDRAW && (a.auto_reset || pa.reset_at_end);
     for (int t = 0; t < pa.T; ++t) {
         const bool q_boot_wanted = boot_wanted, q_was_reset = was_reset;     // flags of step t-1
         // the exploration noise of this step does not depend on the actor's answer: it is drawn while the network wave is
@@ -311,6 +321,10 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
         } else if (draw) {
             if (!M_NOISE) policy_noise<A>(a, a.env_id_base + i, nctr, xi);
             ++nctr;
+        }
+        if (PREDRAW && __ballot(need_draw) != 0ull) {                        // wave-uniform; lanes whose episode did not move redraw the same values
+            reset_draw<MODE>(a, a.env_id_base + i, episode, rdraw);
+            need_draw = false;
         }
         WS_TOC(t_noi, tn_);
         WS_WAIT_T(w_mu, &seq[1], t + 1);                                     // mu_t posted
@@ -402,7 +416,8 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
         if (lane == 0) flag[t & 1] = post_pre ? 1 : 0;
         if (__ballot(do_reset) != 0ull) {
             if (do_reset) {
-                env_auto_reset<MODE>(a, s, a.env_id_base + i, episode, o);
+                if constexpr (PREDRAW) { reset_apply<MODE>(a, s, rdraw, o); need_draw = true; }
+                else env_auto_reset<MODE>(a, s, a.env_id_base + i, episode, o);
                 ++episode; ep_dirty = true; rf_dirty = true;
             }
         }

@@ -447,7 +447,7 @@ struct StepOut {
 };
 
 // ENV:104-133 for one env in three pieces, so that a launch can give them to different waves (rollout_ws_kernel):
-// env_decode (action -> commands and wrench), env_plant (the integrator), env_observe (observation, reward, termination,
+// env_decode (action -> commands and wrench), env_plant (the integrator), env_done / env_reward (termination, reward,
 // late new_ref).  env_step is their composition.
 struct Wrench {
     float thr[3];         // thrust commands, percent
@@ -455,7 +455,10 @@ struct Wrench {
 };
 
 // ---- action decode ENV:104-110, scale_and_clip ENV:215-225, command map ENV:117-122, force map --------------
-template <int MODE>
+// DEFER_ANG (MODE_FINAL_CONT only): the two atan2 of the stern azimuths are NOT evaluated here - the force map uses the normalised
+// heads directly, the angles themselves are only bookkeeping (next step's ang_prev) and reward (azimuth-rate penalty) - so a kernel
+// whose next observation is on a critical path takes them later with stern_angles() (env_step_finish); ang[1], ang[2] are left alone.
+template <int MODE, bool DEFER_ANG = false>
 __device__ __forceinline__ void env_decode(const Vessel& ve, float ang[3], const float* act, Wrench& w)
 {
     w.thr[0] = clipf(act[0] * 100.0f, 100.0f);
@@ -472,7 +475,7 @@ __device__ __forceinline__ void env_decode(const Vessel& ve, float ang[3], const
         ang[1] = clipf(w3 * kPi, kPi); ang[2] = clipf(w4 * kPi, kPi);
     } else if (MODE == MODE_FINAL_CONT) {
         // ENV:227-235: atan2(sin_head, cos_head)/pi, then *pi and clip
-        ang[1] = clipf(atan2_lean(act[3], act[4]), kPi); ang[2] = clipf(atan2_lean(act[5], act[6]), kPi);
+        if (!DEFER_ANG) { ang[1] = clipf(atan2_lean(act[3], act[4]), kPi); ang[2] = clipf(atan2_lean(act[5], act[6]), kPi); }
     }
     if (MODE == MODE_FINAL_CONT) {
         // the azimuth is atan2 of the two heads, so its sine and cosine are the normalised heads themselves:
@@ -553,14 +556,13 @@ __device__ __forceinline__ void env_plant_finish(bool cur, float vcN, float vcE,
     }
 }
 
-// ---- reward ENV:253-325, termination ENV:207-213, fault check, late new_ref ENV:131, bookkeeping ENV:126 ---------
-// o[0..2], o[6..8] filled by make_obs for the new pose; o[3..5] = the new velocity; act only for the non-finite check
+// ---- reward ENV:253-325 -------------------------------------------------------------------------------------------
+// o = the observation of this step (o[0..5] used), thr = this step's thrust commands, pt_old / ang_prev = the commands in force before
+// it, ang_new = the azimuths commanded by it
 template <int MODE, bool EXT>
-__device__ __forceinline__ void env_observe(const StepArgs& a, Env& s, const float* act, const Wrench& w, const float pt_old[3],
-                                            const float ang_prev[3], bool has_ref, float nrN, float nrE, float nrP, StepOut& out)
+__device__ __forceinline__ void env_reward(const StepArgs& a, const float* o, const float thr[3], const float pt_old[3],
+                                           const float ang_new[3], const float ang_prev[3], StepOut& out)
 {
-    float* o = out.o;
-    const float* thr = w.thr;
     float p_der = 0.0f;
     const float p_vel = -sqrt_hw(fmaf(o[3] * o[3], 0.5f, fmaf(o[4] * o[4], 0.5f, o[5] * o[5])));   // ENV:267-273
     const float rr2 = fmaf(o[0], o[0], o[1] * o[1]);
@@ -576,13 +578,20 @@ __device__ __forceinline__ void env_observe(const StepArgs& a, Env& s, const flo
 #pragma unroll
         for (int k = 0; k < 3; ++k) pen -= fabsf((thr[k] - pt_old[k]) * inv_dt * 0.01f) * 0.05f;   // ENV:310-313
         const float inv_bnd = (MODE == MODE_LIMITED) ? (2.0f / kPi) : (1.0f / kPi);               // ENV:319
-        const float angpen = -(fabsf((s.ang[1] - ang_prev[1]) * inv_dt * inv_bnd) * 0.01f +
-                               fabsf((s.ang[2] - ang_prev[2]) * inv_dt * inv_bnd) * 0.01f);       // ENV:315-320 (bow coeff 0)
+        const float angpen = -(fabsf((ang_new[1] - ang_prev[1]) * inv_dt * inv_bnd) * 0.01f +
+                               fabsf((ang_new[2] - ang_prev[2]) * inv_dt * inv_bnd) * 0.01f);     // ENV:315-320 (bow coeff 0)
         p_der = pen + fmaxf(-1.0f, angpen);                                                       // ENV:322-323
     }
     out.parts[0] = p_vel; out.parts[1] = p_pos; out.parts[2] = p_thr; out.parts[3] = p_der;
     out.reward = p_vel + p_pos + p_thr + p_der;   // ENV:263
+}
 
+// ---- termination ENV:207-213, fault check, late new_ref ENV:131, bookkeeping ENV:126 -----------------------------------
+// o[0..5] = the observation of this step; act only for the non-finite check
+template <int MODE>
+__device__ __forceinline__ void env_done(const StepArgs& a, Env& s, const float* act, const float* o, const float thr[3], bool has_ref,
+                                         float nrN, float nrE, float nrP, StepOut& out)
+{
     uint32_t d = 0;
     if (a.terminate) {
         float b[6];
@@ -607,16 +616,24 @@ __device__ __forceinline__ void env_observe(const StepArgs& a, Env& s, const flo
     out.d = d;
 }
 
-// ENV:104-133 for one env: decode, command map, plant, observation, reward, termination, late new_ref.
-// cur = constant current (vcN, vcE in NED) present.
-template <int MODE, bool EXT>
-__device__ __forceinline__ void env_step(const StepArgs& a, const Vessel& ve, Env& s, const float* act, bool has_ref,
-                                         float nrN, float nrE, float nrP, bool cur, float vcN, float vcE, StepOut& out)
+// what the reward of a step still needs once its observation and done bits are out (env_step_chain -> env_step_finish)
+struct StepRest {
+    float thr[3], pt_old[3], ang_prev[3], ang_new[3];
+};
+
+// ENV:104-133 up to and including the observation and the termination bits - everything the NEXT policy input depends on.
+// DEFER: leave the reward (and, for the continuous-angle variant, the two atan2 behind the azimuth bookkeeping) to env_step_finish,
+// so that a kernel can hand the observation over first.  cur = constant current (vcN, vcE in NED) present.
+template <int MODE, bool EXT, bool DEFER>
+__device__ __forceinline__ void env_step_chain(const StepArgs& a, const Vessel& ve, Env& s, const float* act, bool has_ref,
+                                               float nrN, float nrE, float nrP, bool cur, float vcN, float vcE, StepOut& out, StepRest& rest)
 {
-    const float ang_prev[3] = {s.ang[0], s.ang[1], s.ang[2]};   // ENV:102
-    const float pt_old[3] = {s.pt[0], s.pt[1], s.pt[2]};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { rest.ang_prev[k] = s.ang[k]; rest.pt_old[k] = s.pt[k]; }   // ENV:102
     Wrench w;
-    env_decode<MODE>(ve, s.ang, act, w);
+    env_decode<MODE, DEFER>(ve, s.ang, act, w);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { rest.thr[k] = w.thr[k]; rest.ang_new[k] = s.ang[k]; }      // ang_new[1..2] still the old ones if deferred
     float N = s.N, E = s.E, psi = s.psi, u = s.u, v = s.v, r = s.r;
     env_plant(a, ve, w.tx, w.ty, w.tn, cur, vcN, vcE, N, E, psi, u, v, r, s.sn, s.cs);
     // exact sin/cos of the heading reached: needed by the observation, by the current term and by the next step
@@ -626,14 +643,38 @@ __device__ __forceinline__ void env_step(const StepArgs& a, const Vessel& ve, En
     float se, ce;
     {
         // the observation only depends on nu through o[3..5]; compute the frame first, patch nu after
-        make_obs(N, E, psi, 0.0f, 0.0f, 0.0f, s.refN, s.refE, s.refPsi, pt_old, deg, o, se, ce, same);
+        make_obs(N, E, psi, 0.0f, 0.0f, 0.0f, s.refN, s.refE, s.refPsi, rest.pt_old, deg, o, se, ce, same);
         if (!same) sincos_lean(psi, se, ce);
     }
     env_plant_finish(cur, vcN, vcE, se, ce, u, v);
     o[3] = u; o[4] = v; o[5] = r;
     s.N = N; s.E = E; s.psi = psi; s.u = u; s.v = v; s.r = r;
     s.sn = se; s.cs = ce;
-    env_observe<MODE, EXT>(a, s, act, w, pt_old, ang_prev, has_ref, nrN, nrE, nrP, out);
+    env_done<MODE>(a, s, act, o, rest.thr, has_ref, nrN, nrE, nrP, out);
+}
+
+// the rest of the step: azimuth bookkeeping of the continuous-angle variant (if it was deferred) and the reward.  `untouched`: the env was
+// NOT re-drawn since env_step_chain (a reset has put the default azimuths into s.ang: they stay).  out.o must still hold the
+// observation env_step_chain produced.
+template <int MODE, bool EXT, bool DEFER>
+__device__ __forceinline__ void env_step_finish(const StepArgs& a, Env& s, const float* act, StepRest& rest, bool untouched, StepOut& out)
+{
+    if (DEFER && MODE == MODE_FINAL_CONT) {
+        rest.ang_new[1] = clipf(atan2_lean(act[3], act[4]), kPi);       // ENV:227-235
+        rest.ang_new[2] = clipf(atan2_lean(act[5], act[6]), kPi);
+        if (untouched) { s.ang[1] = rest.ang_new[1]; s.ang[2] = rest.ang_new[2]; }
+    }
+    env_reward<MODE, EXT>(a, out.o, rest.thr, rest.pt_old, rest.ang_new, rest.ang_prev, out);
+}
+
+// ENV:104-133 for one env: decode, command map, plant, observation, reward, termination, late new_ref.
+template <int MODE, bool EXT>
+__device__ __forceinline__ void env_step(const StepArgs& a, const Vessel& ve, Env& s, const float* act, bool has_ref,
+                                         float nrN, float nrE, float nrP, bool cur, float vcN, float vcE, StepOut& out)
+{
+    StepRest rest;
+    env_step_chain<MODE, EXT, false>(a, ve, s, act, has_ref, nrN, nrE, nrP, cur, vcN, vcE, out, rest);
+    env_step_finish<MODE, EXT, false>(a, s, act, rest, true, out);
 }
 
 // auto-reset of one finished env: ENV:135-194 with the training sampler; returns the new episode's first obs.

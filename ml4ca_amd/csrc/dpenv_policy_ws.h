@@ -368,7 +368,17 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
 #endif
         WS_TOC(t_pre, tp_);
         WS_TIC(te_);
-        env_step<MODE, EXT>(a, ve, s, act, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out);
+        // only what o_t+1 and the reset decision depend on stays on the chain; the reward and the azimuth bookkeeping follow the hand-over
+#if defined(DPENV_WS_SELFCHECK) && !defined(DPENV_WS_DEFER_REWARD)
+#define DPENV_WS_DEFER_REWARD 0      // the diagnostic double evaluation compares whole steps
+#endif
+#ifndef DPENV_WS_DEFER_REWARD
+#define DPENV_WS_DEFER_REWARD 1
+#endif
+        constexpr bool DEFER = DPENV_WS_DEFER_REWARD != 0;
+        StepRest rest;
+        env_step_chain<MODE, EXT, DEFER>(a, ve, s, act, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out, rest);
+        if constexpr (!DEFER) env_step_finish<MODE, EXT, false>(a, s, act, rest, true, out);
         WS_TOC(t_env, te_);
         WS_TIC(tq_);
 #ifdef DPENV_WS_SELFCHECK
@@ -436,6 +446,7 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
         __builtin_amdgcn_s_setprio(0);
 #endif
         __builtin_amdgcn_sched_barrier(0);                                   // nothing of the rows below moves up into the chain
+        if constexpr (DEFER) env_step_finish<MODE, EXT, true>(a, s, act, rest, !do_reset, out);   // reward, azimuths of a continuing env
         logp = action_logp<A>(pc, mu, act);                                  // core.py:42-46 on (a_t, mu_t)
         if (a.current_drift) current_drift_step(a, cur, vc0, beta0, a.env_id_base + i);   // the current of step t+1: not needed by o_t+1
         put_rows_a(pa.act_out, (int64_t)t * stride_a, act);

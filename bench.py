@@ -662,8 +662,9 @@ def main():
     wall = float(tt[0])
     KR = K * R                                          # env steps inside the timed region
     assert bool(torch.isfinite(obs).all()) and bool(torch.isfinite(rew).all()), 'non-finite outputs'
-    # the other legs run whole 50-step launches: at least 250 steps each, more when --steps asks for more
-    KL = max(5 * CHUNK, (K // CHUNK) * CHUNK)
+    # the other legs run whole 50-step launches: at least 1 250 steps each (25 launches: a 5-launch leg is dominated by launch latency
+    # and clock ramp), more when --steps asks for more
+    KL = max(25 * CHUNK, (K // CHUNK) * CHUNK)
     WL = CHUNK
 
     # ---- fused-rollout leg (dpenv_rollout): same workload, CHUNK env steps per launch, state in registers -----

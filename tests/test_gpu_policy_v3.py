@@ -63,6 +63,38 @@ def test_two_wave_form_writes_the_one_wave_rows(precision, n):
     assert int(((done & 2) != 0).sum()) >= n and bool(torch.isfinite(a['boot']).all()) and bool((a['boot'] != 0).any())
 
 
+def test_epoch_boundary_in_both_launch_forms():
+    """reset_at_end with drifting current, reset_acts and vessel classes, every arithmetic: the two-wave form (pre-drawn reset sample, reward
+    behind the hand-over) writes the one-wave form's rows, boot row of the cut included, and leaves the same state behind"""
+    from ml4ca_amd import _lib as L
+    from ml4ca_amd.policy import policy_rollout
+    torch = torch_()
+    n, T = 2000 + 9, 9
+    base = L.default_vessel()
+    vp = np.stack([base, base * np.where(np.arange(L.NPARAM) < 4, 1.3, 1.0)]).astype(np.float32)
+    for precision in ('f16', 'f32_actor', 'f32'):
+        outs, states = [], []
+        for form in ('two_wave', 'one_wave'):
+            env, _ = H.make_pair('final_cont', n, auto_reset=True, max_ep_len=6, seed=19, reset_acts=True, current=True, current_drift=True,
+                                 vessel_params=vp)
+            env.set_vessel_class((torch.arange(n, device=env.device) % 2).to(torch.int32))
+            env.set_current(torch.full((n,), 0.15, device=env.device), torch.full((n,), 1.0, device=env.device))
+            env.reset()
+            make_ac(9, 7, (80, 80, 80), seed=5, device=env.device).upload(env, precision=precision, launch_form=form)
+            o1 = policy_rollout(env, T, sample=True, reset_at_end=True)
+            o2 = policy_rollout(env, T, sample=True, reset_at_end=True)       # the epoch after: starts from fresh episodes
+            outs.append((o1, o2))
+            states.append(env.get_state() + env.get_rng_counters())
+        for a, b in zip(outs[0], outs[1]):
+            for k in ROWS:
+                assert torch.equal(a[k], b[k]), (precision, k)
+        for x, y in zip(states[0], states[1]):
+            assert torch.equal(x, y)
+        o1, o2 = outs[0]
+        assert int(states[0][1][0].max()) == 0                            # every env starts the next epoch at step 0
+        assert torch.equal(o2['obs'][0], o1['last_obs']) and bool((o1['boot'][T - 1] != 0).any())
+
+
 @pytest.mark.parametrize('n', [1, 63, 64, 65, 127, 129, 257])
 def test_two_wave_forms_at_ragged_batch_sizes(n):
     """batch sizes around the group (64 envs) and workgroup (128 envs) boundaries of the two-wave geometry, in every arithmetic: a group

@@ -84,6 +84,21 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
 #endif
     constexpr bool STAGE = !SPLIT || (PREC == PREC_F32_ACTOR && DPENV_WS_STAGE_ACTOR);   // env-wave rows through LDS transposes (else per lane)
     constexpr int NIMG = ws_images(PREC);           // weight images staged: pi_hi, v_hi (, pi_lo (, v_lo))
+    // All-exact arithmetic with a SIMD per wave (GROUPS = 2): the CRITIC runs on the ENV wave (round 3).  Two exact evaluations one after
+    // the other in the network wave bound the step at 10.8 us while the env wave idles for most of it; with the critic behind the env
+    // wave's rows the two networks are evaluated at the same time on two SIMDs' matrix pipes (10.3 -> 9.7 us at 32 768 envs, same call).
+    // Same mlp_eval_x on the same fragments: rows unchanged.  NOT for two waves per SIMD (GROUPS = 4), measured: there the critic's
+    // MFMAs beside the actor's contend for ONE matrix pipe (today's order pairs matrix work with vector work: critic beside env.step,
+    // rows beside the actor) and env state + evaluation do not fit 256 registers (10.0 -> 11.4 us exact actor, 13.5 -> 17.2 all exact,
+    // with the vessel block and policy constants re-fetched per step and 268 / 412 B of scratch left); and not for the exact-actor
+    // mode with its f16 critic, which gains nothing (7.36 vs 7.34 us).  -DDPENV_WS_ECRITIC=0: the network wave's critic everywhere.
+#if defined(DPENV_WS_SELFCHECK) && !defined(DPENV_WS_ECRITIC)
+#define DPENV_WS_ECRITIC 0           // the diagnostic double evaluation waits for the network wave's critic
+#endif
+#ifndef DPENV_WS_ECRITIC
+#define DPENV_WS_ECRITIC 1
+#endif
+    constexpr bool ECRITIC = PREC == PREC_F32 && GROUPS == 2 && (DPENV_WS_ECRITIC != 0);
     static_assert(ROLES == 2, "an env wave and a network wave per 64 envs (the three-wave forms of round 2 were measured, rejected and removed: DESIGN.md section 4)");
     static_assert(GROUPS == 4 || GROUPS == 2, "workgroups of 256 or 128 envs");
     extern __shared__ uint4 lds_dyn[];
@@ -119,7 +134,10 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
 #ifndef DPENV_WS_X_MNOISE
 #define DPENV_WS_X_MNOISE 0      // split arithmetics: the ENV wave draws (it idles ~4 us per step while the network wave evaluates the actor)
 #endif
-    constexpr bool M_NOISE = (ROLES == 2) && (!SPLIT || DPENV_WS_X_MNOISE);
+#ifndef DPENV_WS_ECRITIC_MNOISE
+#define DPENV_WS_ECRITIC_MNOISE 1  // ... unless the env wave carries the critic: then the network wave (actor only) has the time
+#endif
+    constexpr bool M_NOISE = (ROLES == 2) && (!SPLIT || DPENV_WS_X_MNOISE || (ECRITIC && DPENV_WS_ECRITIC_MNOISE));
     float* xi_mb = obs_mb;
     const uint4* Wpi = lds_w;
     const uint4* Wv = lds_w + pa.nent;
@@ -147,7 +165,7 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
 #ifndef DPENV_WS_NO_SETPRIO
         __builtin_amdgcn_s_setprio(DPENV_WS_M_PRIO);
 #endif
-        const bool do_actor = true, do_critic = true;
+        constexpr bool do_actor = true, do_critic = !ECRITIC;
         half8 in0, in1;                                                      // PREC_F16: first-layer fragments of o_t
         SplitIn inx;                                                         // SPLIT: their high and low parts
         float o[9], outv[8];
@@ -189,7 +207,7 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
 #pragma unroll
                 for (int k = 0; k < A; ++k) mu_mb[lane * 9 + k] = outv[k];
 #ifndef DPENV_WS_X_CARRY_FRAGS      // A/B switch (tools/): carry the fragments in registers across the actor's evaluation instead
-                if constexpr (SPLIT && !M_NOISE) {
+                if constexpr (SPLIT && !M_NOISE && do_critic) {
                     // The critic needs the fragments of o_t again.  Carried across the actor's evaluation they are 16 registers the
                     // evaluation does not have (the 256-env geometry leaves a wave 256 registers and no AGPRs: they were spilled to
                     // scratch and reloaded, ~30 scratch loads per step).  The row is still in the mailbox - the env wave overwrites it
@@ -286,6 +304,19 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
         if constexpr (STAGE) wave_store_rows<A>(lds_io, dst, t_off + w_a, rem_a, v, lane);
         else if (live) store_row_direct<A>(dst, (t_off + w_a) / A + lane, v, false);
     };
+    // ECRITIC: V of an observation this wave holds (one env per lane, like the one-wave kernels)
+    auto critic_here = [&](const float* ob) __attribute__((always_inline)) -> float {
+        float oc[9], outv[8];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) oc[k] = k < OD ? ob[k] : 0.0f;
+        SplitIn f;
+        obs_to_frags_x<OD>(oc, f);
+        if constexpr (PREC == PREC_F32) mlp_eval_x<KA>(Wv, Wv_l, Bv, pa.n_hidden, f, pa.leak, outv);
+        else mlp_eval<KA>(Wv, Bv, pa.n_hidden, f.h0, f.h1, leak, outv);
+        return outv[0];
+    };
+    float v_cur = 0.0f;
+    bool pre_owed = false;                                                   // step t-1 left a pre-reset observation in pre_mb
     uint64_t w_mu = 0, w_v = 0, t_env = 0, t_noi = 0; const uint64_t t_start = __builtin_amdgcn_s_memtime(); (void)t_start; (void)w_mu; (void)w_v; (void)t_env; (void)t_noi;
     uint64_t t_pre = 0, t_post = 0, t_off = 0; (void)t_pre; (void)t_post; (void)t_off;
     bool boot_wanted = false, was_reset = false;                             // of the step whose boot row is still owed
@@ -304,8 +335,26 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
     constexpr bool PREDRAW = DPENV_WS_PREDRAW != 0;      // measured (round 3, same call): 1-2 % in every form, e.g. f16 7.28 -> 7.18 us at 65 536 envs
     ResetDraw rdraw;
     bool need_draw = PREDRAW && (a.auto_reset || pa.reset_at_end);
-    for (int t = 0; t < pa.T; ++t) {
+    for (int t = 0; t <= pa.T; ++t) {
         const bool q_boot_wanted = boot_wanted, q_was_reset = was_reset;     // flags of step t-1
+        if constexpr (ECRITIC) {
+            // V(o_t) - and V of the pre-reset observation where step t-1 cut an episode that was re-drawn - while the network wave
+            // evaluates mu_t.  One copy of the evaluation: first the row this wave left in pre_mb, then o_t.
+            float v_pre = 0.0f;
+            for (int pass = pre_owed ? 0 : 1; pass < 2; ++pass) {            // wave-uniform
+                const float* rm = pre_mb + ((t - 1) & 1) * (64 * 9);
+                float orow[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) orow[k] = k < OD ? (pass == 0 ? rm[lane * 9 + k] : o[k]) : 0.0f;
+                const float vv = critic_here(orow);
+                if (pass == 0) v_pre = vv; else v_cur = vv;
+            }
+            if (live) {
+                if (t < pa.T) (pa.val + (int64_t)t * n)[(unsigned)i] = v_cur;
+                if (t > 0) (pa.boot + (int64_t)(t - 1) * n)[(unsigned)i] = q_boot_wanted ? (q_was_reset ? v_pre : v_cur) : 0.0f;
+            }
+        }
+        if (t == pa.T) break;
         // the exploration noise of this step does not depend on the actor's answer: it is drawn while the network wave is
         // still evaluating mu_t (the env wave would otherwise only poll)
         float xi[A];
@@ -424,6 +473,7 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
             for (int k = 0; k < OD; ++k) pm[lane * 9 + k] = o[k];
         }
         if (lane == 0) flag[t & 1] = post_pre ? 1 : 0;
+        pre_owed = post_pre;
         if (__ballot(do_reset) != 0ull) {
             if (do_reset) {
                 if constexpr (PREDRAW) { reset_apply<MODE>(a, s, rdraw, o); need_draw = true; }
@@ -456,15 +506,19 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
             (pa.done + (int64_t)t * n)[(unsigned)i] = (uint8_t)out.d;
             (pa.logp + (int64_t)t * n)[(unsigned)i] = logp;
         }
-        WS_WAIT_T(w_v, &seq[2], t + 1);                                      // V(o_t), V(pre-reset o_t) posted
-        WS_TOC(t_off, tr_);
-        if (live) {
-            const float v_t = v_mb[(t & 1) * 64 + lane];
-            (pa.val + (int64_t)t * n)[(unsigned)i] = v_t;
-            if (t > 0) (pa.boot + (int64_t)(t - 1) * n)[(unsigned)i] = q_boot_wanted ? (q_was_reset ? vpre_mb[(t & 1) * 64 + lane] : v_t) : 0.0f;
+        if constexpr (ECRITIC) {
+            WS_TOC(t_off, tr_);
+        } else {
+            WS_WAIT_T(w_v, &seq[2], t + 1);                                  // V(o_t), V(pre-reset o_t) posted
+            WS_TOC(t_off, tr_);
+            if (live) {
+                const float v_t = v_mb[(t & 1) * 64 + lane];
+                (pa.val + (int64_t)t * n)[(unsigned)i] = v_t;
+                if (t > 0) (pa.boot + (int64_t)(t - 1) * n)[(unsigned)i] = q_boot_wanted ? (q_was_reset ? vpre_mb[(t & 1) * 64 + lane] : v_t) : 0.0f;
+            }
         }
     }
-    ws_wait(&seq[2], pa.T + 1);                                              // V(o_T) posted
+    if constexpr (!ECRITIC) ws_wait(&seq[2], pa.T + 1);                      // V(o_T) posted
 #ifdef DPENV_WS_PROFILE
     if (live && pa.T >= 12) {
         (pa.logp + (int64_t)0 * n)[(unsigned)i] = (float)w_mu; (pa.logp + (int64_t)1 * n)[(unsigned)i] = (float)w_v; (pa.logp + (int64_t)2 * n)[(unsigned)i] = (float)(__builtin_amdgcn_s_memtime() - t_start);
@@ -475,9 +529,12 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
 #endif
     put_rows_o(pa.last_obs, 0, o);
     if (live) {
-        const float v_T = v_mb[(pa.T & 1) * 64 + lane];
-        (pa.boot + (int64_t)(pa.T - 1) * n)[(unsigned)i] = boot_wanted ? (was_reset ? vpre_mb[(pa.T & 1) * 64 + lane] : v_T) : 0.0f;
-        pa.last_val[i] = v_T;
+        if constexpr (ECRITIC) pa.last_val[i] = v_cur;                       // V(o_T); boot[T-1] went out with it
+        else {
+            const float v_T = v_mb[(pa.T & 1) * 64 + lane];
+            (pa.boot + (int64_t)(pa.T - 1) * n)[(unsigned)i] = boot_wanted ? (was_reset ? vpre_mb[(pa.T & 1) * 64 + lane] : v_T) : 0.0f;
+            pa.last_val[i] = v_T;
+        }
         store_env(a, i, s, rf_dirty);
         if (EXT) a.S3[i] = make_float4(o[6], o[7], o[8], 0.0f);
         if (ep_dirty) a.episode[i] = (int)episode;

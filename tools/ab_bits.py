@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Digest of closed-loop rollouts in every arithmetic, to compare two builds of the library bit for bit (run once per DPENV_LIB):
+    DPENV_LIB=a.so python tools/ab_bits.py > a.txt; DPENV_LIB=b.so python tools/ab_bits.py > b.txt; diff a.txt b.txt"""
+import hashlib
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import ml4ca_amd
+from ml4ca_amd.policy import ActorCritic, policy_rollout
+
+for n in (4096 + 37, 65536):
+    for prec in ('f16', 'f32_actor', 'f32'):
+        env = ml4ca_amd.BatchedRevoltEnv(n, auto_reset=True, seed=3, max_ep_len=17)
+        ActorCritic(9, 7, (80, 80, 80), seed=2, device=env.device).upload(env, precision=prec)
+        env.reset()
+        out = policy_rollout(env, 40, sample=True)
+        torch.cuda.synchronize()
+        h = hashlib.sha256()
+        for k in sorted(out):
+            if torch.is_tensor(out[k]):
+                h.update(out[k].contiguous().cpu().numpy().tobytes())
+        print(n, prec, h.hexdigest()[:24], float(out['logp'].double().sum()))

@@ -24,7 +24,7 @@ env = ml4ca_amd.BatchedRevoltEnv(n, auto_reset=True)
 ActorCritic(9, 7, (80, 80, 80), device=env.device).upload(env, precision=prec, launch_form='two_wave')
 print('%d envs, %s' % (n, prec))
 env.reset()
-for _ in range(3):
+for _ in range(int(os.environ.get('WS_PROFILE_WARM', 30))):          # clocks ramp over the first ~20 launches
     out = policy_rollout(env, T, sample=True)
 lp = out['logp'].double()
 e_tot, m_tot = float(lp[2].mean()), float(lp[4].mean())

@@ -771,6 +771,21 @@ __device__ __forceinline__ void mlp_eval_x(const uint4* Wh, const uint4* Wl, con
     };
     const FragAddr<KS> fa(lane);
     int e0 = FragAddr<KS>::L0, bblk = 0;
+    // What a row-block needs before its first MFMA - its two bias tiles (the accumulators start from them) and its first weight
+    // fragments, twelve LDS reads - is fetched during the LAST k-step of the block before it (round 3).  Those slots carry no
+    // activation work, and the accumulators of the block before that one have just been used up, so the fetch costs no register
+    // the evaluation does not already own; issued at the block's own start it left the matrix pipe idle for the LDS latency ten
+    // times per evaluation.
+    float16v nb0, nb1;
+    half8 nw_h, nw_l;
+    auto fetch_blk0 = [&](int e, int blk, bool is_out) __attribute__((always_inline)) {
+        nb0 = ldbias(B, blk, lane); nb1 = ldbias(B2, blk, lane);
+        nw_h = fa.blk0(Wh, e, is_out, 0); nw_l = fa.blk0(Wl, e, is_out, 0);
+    };
+    auto fetch_hid = [&](int e, int blk, int mo) __attribute__((always_inline)) {
+        nb0 = ldbias(B, blk + mo, lane); nb1 = ldbias(B2, blk + mo, lane);
+        nw_h = fa.hid(Wh, e, mo, 0); nw_l = fa.hid(Wl, e, mo, 0);
+    };
     // ---- first layer (one k-step): blocks 0 and 1, then block 2 beside the split of block 0; the split of block 1 is exposed
     {
         Frag I0, I1;
@@ -789,6 +804,7 @@ __device__ __forceinline__ void mlp_eval_x(const uint4* Wh, const uint4* Wl, con
         q0 = zero; q1 = zero;
         slot(q0, w2h, w2l, I0, true, a0, 1, 0, X[1][0]);
         slot(q1, w2h, w2l, I1, true, a0, 1, 1, X[1][0]);
+        fetch_blk0(e0, bblk, n_hidden == 1);                 // the head of the next layer, under the exposed units below
         bare_unit(a1, 0, 0, X[0][1]); bare_unit(a1, 0, 1, X[0][1]);
         bare_unit(a1, 1, 0, X[1][1]); bare_unit(a1, 1, 1, X[1][1]);
 #pragma unroll
@@ -804,38 +820,44 @@ __device__ __forceinline__ void mlp_eval_x(const uint4* Wh, const uint4* Wl, con
     auto head = [&](Frag (&I)[KS][2], bool is_out) __attribute__((always_inline)) {
         // each accumulator starts from its OWN read of the bias tile (a 64-byte LDS broadcast per lane half): a shared copy would
         // be 16 more live registers for the whole block and 32 v_mov - this evaluation runs at the edge of the register file
-        p0 = ldbias(B, bblk, lane);
-        p1 = ldbias(B2, bblk, lane);
-        half8 wh = fa.blk0(Wh, e0, is_out, 0), wl = fa.blk0(Wl, e0, is_out, 0);
+        p0 = nb0;
+        p1 = nb1;
+        half8 wh = nw_h, wl = nw_l;
         constexpr int NU = 4 * (KS - 4);                                    // pending units: 4 (KS = 5) or 8 (KS = 6)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             half8 nwh = wh, nwl = wl;
             if (ks + 1 < KS) { nwh = fa.blk0(Wh, e0, is_out, ks + 1); nwl = fa.blk0(Wl, e0, is_out, ks + 1); }
+            // q0 / q1 have been read for the last time one k-step ago and the matrix pipe finished with them long before
+            if (ks == NU / 2) { keep_alive(q0); keep_alive(q1); }
+            if (ks == KS - 1 && !is_out) fetch_hid(e0, bblk, 1);
             const int u0 = 2 * ks, u1 = 2 * ks + 1;                          // unit u: tile u & 1, quarter (u >> 1) & 1, half u >> 2
             slot(p0, wh, wl, I[ks][0], ks < 4 && u0 < NU, (u0 & 1) ? q1 : q0, u0 >> 2, (u0 >> 1) & 1, I[4 + (u0 >> 2) < KS ? 4 + (u0 >> 2) : 4][u0 & 1]);
             slot(p1, wh, wl, I[ks][1], ks < 4 && u1 < NU, (u1 & 1) ? q1 : q0, u1 >> 2, (u1 >> 1) & 1, I[4 + (u1 >> 2) < KS ? 4 + (u1 >> 2) : 4][u1 & 1]);
             wh = nwh; wl = nwl;
         }
-        keep_alive(q0); keep_alive(q1);
     };
-    auto hidden = [&](Frag (&I)[KS][2], Frag (&O)[KS][2]) __attribute__((always_inline)) {
+    auto hidden = [&](Frag (&I)[KS][2], Frag (&O)[KS][2], bool next_is_out) __attribute__((always_inline)) {
         head(I, false);
 #pragma unroll
         for (int mo = 1; mo < 3; ++mo) {
-            float16v c0 = ldbias(B, bblk + mo, lane), c1 = ldbias(B2, bblk + mo, lane);
-            half8 wh = fa.hid(Wh, e0, mo, 0), wl = fa.hid(Wl, e0, mo, 0);
+            float16v c0 = nb0, c1 = nb1;
+            half8 wh = nw_h, wl = nw_l;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 half8 nwh = wh, nwl = wl;
                 if (ks + 1 < KS) { nwh = fa.hid(Wh, e0, mo, ks + 1); nwl = fa.hid(Wl, e0, mo, ks + 1); }
+                if (ks == 4) { keep_alive(p0); keep_alive(p1); }             // their eight units rode on k-steps 0..3
+                if (ks == KS - 1) {
+                    if (mo == 1) fetch_hid(e0, bblk, 2);
+                    else fetch_blk0(e0 + FragAddr<KS>::LH, bblk + 3, next_is_out);
+                }
                 // the eight units of block mo - 1 (p0 / p1) -> O[2 (mo - 1)], O[2 (mo - 1) + 1]
                 const int u0 = 2 * ks, u1 = 2 * ks + 1;
                 slot(c0, wh, wl, I[ks][0], u0 < 8, (u0 & 1) ? p1 : p0, (u0 >> 2) & 1, (u0 >> 1) & 1, O[2 * (mo - 1) + ((u0 >> 2) & 1)][u0 & 1]);
                 slot(c1, wh, wl, I[ks][1], u1 < 8, (u1 & 1) ? p1 : p0, (u1 >> 2) & 1, (u1 >> 1) & 1, O[2 * (mo - 1) + ((u1 >> 2) & 1)][u1 & 1]);
                 wh = nwh; wl = nwl;
             }
-            keep_alive(p0); keep_alive(p1);
             p0 = c0; p1 = c1;
         }
         q0 = p0; q1 = p1;
@@ -853,8 +875,8 @@ __device__ __forceinline__ void mlp_eval_x(const uint4* Wh, const uint4* Wl, con
         }
     };
     int l = 1;
-    for (; l + 1 < n_hidden; l += 2) { hidden(X, Y); hidden(Y, X); }
-    if (l < n_hidden) { hidden(X, Y); output(Y); }
+    for (; l + 1 < n_hidden; l += 2) { hidden(X, Y, false); hidden(Y, X, !(l + 2 < n_hidden)); }
+    if (l < n_hidden) { hidden(X, Y, true); output(Y); }
     else output(X);
 }
 

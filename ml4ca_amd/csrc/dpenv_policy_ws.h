@@ -137,7 +137,11 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
 #ifndef DPENV_WS_ECRITIC_MNOISE
 #define DPENV_WS_ECRITIC_MNOISE 1  // ... unless the env wave carries the critic: then the network wave (actor only) has the time
 #endif
-    constexpr bool M_NOISE = (ROLES == 2) && (!SPLIT || DPENV_WS_X_MNOISE || (ECRITIC && DPENV_WS_ECRITIC_MNOISE));
+#ifndef DPENV_WS_F16_G2_MNOISE
+#define DPENV_WS_F16_G2_MNOISE 0   // f16 with a SIMD per wave: the network wave (two evaluations per step) is the busy one there, the env wave draws
+#endif
+    constexpr bool M_NOISE = (ROLES == 2) && ((!SPLIT && (GROUPS == 4 || DPENV_WS_F16_G2_MNOISE)) || (SPLIT && DPENV_WS_X_MNOISE) ||
+                                              (ECRITIC && DPENV_WS_ECRITIC_MNOISE));
     float* xi_mb = obs_mb;
     const uint4* Wpi = lds_w;
     const uint4* Wv = lds_w + pa.nent;

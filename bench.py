@@ -114,8 +114,11 @@ def group_record(args, dist, world, dev=None):
         names = [None] * world
         me = {'rank': dist.get_rank(), 'pid': os.getpid(), 'device': str(dev) if dev is not None else 'cpu',
               'device_name': torch.cuda.get_device_name(dev) if dev is not None else None}
-        dist.all_gather_object(names, me)
-        rec['ranks'] = names
+        try:
+            dist.all_gather_object(names, me)
+            rec['ranks'] = names
+        except Exception as e:   # pragma: no cover - the record must never cost the bench line
+            rec['ranks'] = 'unavailable (%s: %s)' % (type(e).__name__, str(e)[:200])
     return rec
 
 

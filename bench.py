@@ -67,9 +67,39 @@ def parse():
     ap.add_argument('--config4-envs', type=int, default=32768)
     ap.add_argument('--classes', type=int, default=0, help='K > 0: also time dpenv_step with K vessel classes (LDS-staged [param][class] blocks) '
                                                            'against the single-class SGPR path, and the closed loop with classes on')
+    ap.add_argument('--init-timeout', type=float, default=180.0, help='seconds a rank waits for its peers in init_process_group / the first barrier '
+                                                                       'before it gives up with a message and a non-zero exit code')
     ap.add_argument('--rendezvous-only', action='store_true', help='diagnostic: the ranks join the process group, exchange one all-reduce and rank 0 '
                                                                     'prints what the group looks like; no GPU work (the CPU test of the self-launch path)')
     return ap.parse_args()
+
+
+def pool_environment():
+    """Environment every rank needs on this pool, whoever started it (the driver's `python -m torch.distributed.run ... bench.py`, or
+    self_launch below): the host driver only supports dmabuf IPC, and without HSA_ENABLE_IPC_MODE_LEGACY=0 RCCL between processes
+    fails with `hipIpcGetMemHandle: invalid argument`.  Must run before anything initialises HIP (i.e. before `import torch` touches a
+    device); setdefault, so an operator's explicit choice wins.  Returned for the `group` record of the JSON line."""
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    return {k: os.environ.get(k) for k in ('HSA_ENABLE_IPC_MODE_LEGACY', 'MASTER_ADDR', 'MASTER_PORT', 'NCCL_DEBUG', 'HIP_VISIBLE_DEVICES',
+                                           'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES')}
+
+
+def join_group(args, dist, backend, rank, world, dev=None):
+    """init_process_group + the first barrier with a timeout; a rank that cannot reach its peers says so in ONE line (rank, device,
+    error) and the process exits non-zero - no retry, no re-exec of a process that may have touched the GPU."""
+    from datetime import timedelta
+    try:
+        kw = {'timeout': timedelta(seconds=args.init_timeout)}
+        if backend == 'nccl' and dev is not None:
+            kw['device_id'] = dev
+        dist.init_process_group(backend, **kw)
+        dist.barrier()
+    except BaseException as e:      # noqa: BLE001 - whatever it is, report and leave
+        sys.stderr.write('bench.py: rank %d of %d (device %s, backend %s, pid %d) could not join the process group within %.0f s: %s: %s\n' % (
+            rank, world, dev if dev is not None else 'cpu', backend, os.getpid(), args.init_timeout, type(e).__name__, str(e).replace('\n', ' ')[:600]))
+        sys.stderr.flush()
+        os._exit(5)                 # not sys.exit: a half-initialised backend may hang in its destructors
 
 
 def self_launch(args):
@@ -91,9 +121,8 @@ def self_launch(args):
     sock.close()
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    pool_environment()                                      # the child ranks call it again themselves: same values either way
     env = dict(os.environ)
-    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL between processes needs it on this pool
-    env.setdefault('MASTER_ADDR', '127.0.0.1')
     sys.stderr.write('bench.py: no launcher (WORLD_SIZE unset): starting %d ranks as a child process: %s\n' % (args.gpus, ' '.join(cmd)))
     sys.stderr.flush()
     return subprocess.run(cmd, env=env).returncode
@@ -105,7 +134,8 @@ def group_record(args, dist, world, dev=None):
     rec = {'world_size': dist.get_world_size() if world > 1 else 1, 'backend': dist.get_backend() if world > 1 else None,
            'torch': torch.__version__, 'hip': getattr(torch.version, 'hip', None),
            'visible_devices': torch.cuda.device_count(),
-           'launcher': os.environ.get('TORCHELASTIC_RUN_ID') is not None and 'torch.distributed.run' or 'none'}
+           'launcher': os.environ.get('TORCHELASTIC_RUN_ID') is not None and 'torch.distributed.run' or 'none',
+           'environment': pool_environment(), 'init_timeout_s': args.init_timeout}
     try:
         rec['nccl_version'] = '.'.join(str(x) for x in torch.cuda.nccl.version())     # = RCCL's on ROCm
     except Exception as e:       # pragma: no cover - a CPU-only build
@@ -113,7 +143,8 @@ def group_record(args, dist, world, dev=None):
     if world > 1:
         names = [None] * world
         me = {'rank': dist.get_rank(), 'pid': os.getpid(), 'device': str(dev) if dev is not None else 'cpu',
-              'device_name': torch.cuda.get_device_name(dev) if dev is not None else None}
+              'device_name': torch.cuda.get_device_name(dev) if dev is not None else None,
+              'environment': {'HSA_ENABLE_IPC_MODE_LEGACY': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}}
         try:
             dist.all_gather_object(names, me)
             rec['ranks'] = names
@@ -492,6 +523,7 @@ def classes_record(args, dev, n):
 
 def main():
     args = parse()
+    pool_environment()                                  # the same on the torchrun-launched and on the self-launched path, before `import torch`
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(args))                     # before `import torch` initialises anything on the GPU
     import torch
@@ -503,9 +535,8 @@ def main():
         raise SystemExit('bench.py: --gpus %d but the launcher started %d rank(s)' % (args.gpus, world))
     if args.rendezvous_only:
         # the CPU rehearsal of the launch path: no device, gloo
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if world > 1:
-            dist.init_process_group('gloo')
+            join_group(args, dist, 'gloo', rank, world)
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         if world > 1:
             dist.all_reduce(t)
@@ -523,18 +554,22 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    # a fresh checkout (built artefacts are git-ignored): rank 0 alone decides and builds, BEFORE it joins the process group
-    # (the Makefile links to a temporary name and renames); every rank then passes the same barrier whatever it saw on disk
-    if rank == 0 and not os.path.exists(os.path.join(ROOT, 'ml4ca_amd', 'lib', 'libdpenv.so')):
-        import __graft_entry__
-        __graft_entry__.build()
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if args.backend == 'nccl':
-            dist.init_process_group('nccl', device_id=dev)
+    # a fresh checkout (built artefacts are git-ignored): rank 0 alone builds, BEFORE anybody joins the process group (the build takes
+    # minutes, the rendezvous has a timeout); the others wait for the file - the Makefile links to a temporary name and renames, so the
+    # library exists only when it is complete
+    libpath = os.path.join(ROOT, 'ml4ca_amd', 'lib', 'libdpenv.so')
+    if not os.path.exists(libpath):
+        if rank == 0:
+            import __graft_entry__
+            __graft_entry__.build()
         else:
-            dist.init_process_group(args.backend)
-        dist.barrier()
+            t_wait = time.time()
+            while not os.path.exists(libpath):
+                if time.time() - t_wait > 2400:
+                    raise SystemExit('bench.py: rank %d waited 40 min for rank 0 to build %s' % (rank, libpath))
+                time.sleep(2.0)
+    if world > 1:
+        join_group(args, dist, args.backend, rank, world, dev)
     group = group_record(args, dist, world, dev)
     side_legs = (args.side_legs == 1) or (args.side_legs < 0 and world == 1)
     if args.no_fused:

@@ -29,6 +29,14 @@
 
 namespace dpenv {
 
+#ifdef DPENV_STEP_TRACE
+// Diagnostic builds only (tools/build_kernels_variant.sh, tools/step_placement.py; never in the product library): where and when
+// every workgroup of step_kernel ran.  Ring of DPENV_STEP_TRACE_RING launches, slot = the env's own step counter, record per
+// workgroup = {HW_REG_XCC_ID, HW_REG_HW_ID, s_memrealtime at entry, s_memrealtime after the last store was issued}.
+__device__ uint32_t* g_step_trace = nullptr;
+constexpr int STEP_TRACE_RING = 8;
+#endif
+
 // =============================================================================================
 //  env.step: one launch = one step of every env
 // =============================================================================================
@@ -45,6 +53,9 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const StepArgs a)
     const int n = a.n;
     const bool live = i < n;
     const int il = live ? i : n - 1;   // dead lanes shadow the last env and never store
+#ifdef DPENV_STEP_TRACE
+    const uint64_t trace_t0 = wall_clock64();
+#endif
 
     // ---- issue all global loads up front ------------------------------------------------------
     float act[A];
@@ -125,6 +136,17 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const StepArgs a)
             a.parts[2 * (int64_t)n + i] = out.parts[2]; a.parts[3 * (int64_t)n + i] = out.parts[3];
         }
     }
+#ifdef DPENV_STEP_TRACE
+    if (tid == 0 && g_step_trace) {
+        const uint64_t t1 = wall_clock64();
+        const uint32_t slot = (uint32_t)(s.steps - 1) % STEP_TRACE_RING;      // envs of a launch without resets share their counter
+        uint32_t* rec = g_step_trace + ((size_t)slot * gridDim.x + blockIdx.x) * 4;
+        rec[0] = __builtin_amdgcn_s_getreg((31 << 11) | 20);                  // HW_REG_XCC_ID
+        rec[1] = __builtin_amdgcn_s_getreg((31 << 11) | 4);                   // HW_REG_HW_ID
+        rec[2] = (uint32_t)trace_t0;
+        rec[3] = (uint32_t)t1;
+    }
+#endif
 }
 
 // =============================================================================================
@@ -571,6 +593,13 @@ static hipError_t launch_step_mode(const StepArgs& a, bool ext, bool per_class, 
     }
     return hipGetLastError();
 }
+
+#ifdef DPENV_STEP_TRACE
+extern "C" int dpenv_debug_set_step_trace(void* p)      // device buffer of STEP_TRACE_RING x workgroups x 4 dwords (or NULL)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(dpenv::g_step_trace), &p, sizeof p);
+}
+#endif
 
 extern "C" hipError_t dpenv_dev_launch_step(const StepArgs* a, int mode, int ext, int per_class, hipStream_t s)
 {

@@ -352,6 +352,58 @@ def test_bench_starts_its_own_ranks_when_no_launcher_is_around():
     assert q.returncode != 0 and 'started 1 rank' in (q.stderr + q.stdout)
 
 
+def test_bench_under_the_drivers_launcher_has_the_same_environment():
+    """The driver's form for N > 1 (bench.py docstring): `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr
+    127.0.0.1 --master-port P bench.py --gpus 2 ...` - WORLD_SIZE is set, so self_launch is skipped.  The ranks must give themselves the
+    pool's environment (HSA_ENABLE_IPC_MODE_LEGACY=0: dmabuf IPC for RCCL) before torch initialises anything, exactly as the self-launched
+    ranks get it, and the JSON line records it.  The variable is removed from the launcher's environment first: the
+    driver's shell may not have it."""
+    import json
+    import socket
+    import subprocess
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'HSA_ENABLE_IPC_MODE_LEGACY', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    sock = socket.socket(); sock.bind(('127.0.0.1', 0)); port = sock.getsockname()[1]; sock.close()
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--rendezvous-only'],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout
+    r = json.loads(lines[0])
+    assert 'starting 2 ranks as a child process' not in p.stderr                      # the launcher's ranks, not bench.py's own
+    g = r['group']
+    assert g['world_size'] == 2 and g['launcher'] == 'torch.distributed.run' and len(g['ranks']) == 2
+    assert g['environment']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' and g['environment']['MASTER_ADDR'] == '127.0.0.1'
+    assert all(x['environment']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' for x in g['ranks'])    # every rank's own os.environ
+    assert g['init_timeout_s'] == 180.0
+    # an operator's explicit choice wins over the default
+    p2 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--rendezvous-only'],
+                        env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY='1'), capture_output=True, text=True, timeout=600)
+    assert p2.returncode == 0, p2.stderr[-2000:]
+    r2 = json.loads([l for l in p2.stdout.splitlines() if l.startswith('{')][0])
+    assert all(x['environment']['HSA_ENABLE_IPC_MODE_LEGACY'] == '1' for x in r2['group']['ranks'])
+
+
+def test_bench_rank_that_cannot_reach_its_peers_exits_nonzero_with_one_line():
+    """A rank whose peers never arrive must not hang until the driver's kill: init_process_group has a timeout, the failure is one
+    line naming rank, device and error, and the exit code is non-zero.  One rank of a pretended 2-rank job, nobody else, 3 s."""
+    import socket
+    import subprocess
+    import time as _t
+    sock = socket.socket(); sock.bind(('127.0.0.1', 0)); port = sock.getsockname()[1]; sock.close()
+    env = dict(os.environ, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    t0 = _t.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--rendezvous-only', '--init-timeout', '3'],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 5, (p.returncode, p.stderr[-1500:])
+    msg = [l for l in p.stderr.splitlines() if l.startswith('bench.py: rank 0 of 2')]
+    assert len(msg) == 1 and 'could not join the process group within 3 s' in msg[0], p.stderr[-1500:]
+    assert p.stdout.strip() == ''
+    assert _t.time() - t0 < 120
+
+
 def test_bench_refuses_more_ranks_than_devices():
     """fewer devices than --gpus: non-zero exit with a message, nothing measured, no rank started"""
     import subprocess

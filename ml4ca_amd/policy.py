@@ -81,6 +81,24 @@ class ActorCritic(object):
         from .tf_checkpoint import read_bundle
         return cls.from_tensors(read_bundle(prefix), leak=leak, device=device, activation=activation)
 
+    @classmethod
+    def from_saved_model(cls, model_dir, device='cpu'):
+        """Load a reference-trained model from its `tf1_save` directory (logx.py:161-228: `saved_model.pb` + `variables/`), taking the
+        hidden activation and its slope from the saved GRAPH (tf_graph.py) instead of from the caller: the thesis' models are
+        Maximum(0.2 x, x) (tf.nn.leaky_relu of TensorFlow 1.12), which is also how the kernels evaluate it."""
+        import os
+        from .tf_checkpoint import read_bundle
+        from . import tf_graph
+        g = tf_graph.read_saved_model(os.path.join(model_dir, 'saved_model.pb'))
+        desc = tf_graph.describe_actor_critic(g)
+        act, alpha = tf_graph.hidden_activation(desc)
+        for net in ('pi', 'v'):                            # the shape this library evaluates: dense stacks, no activation behind the last layer
+            assert all(len(l['ops']) == 3 for l in desc[net][:-1]) and desc[net][-1]['ops'] == ['MatMul', 'BiasAdd'], desc[net]
+        ac = cls.from_tensors(read_bundle(os.path.join(model_dir, 'variables', 'variables')), leak=float(np.float32(alpha)), device=device,
+                              activation=act)
+        ac.graph = desc
+        return ac
+
     def state_dict(self):
         """{reference variable name: numpy array} (inverse of from_tensors)."""
         out = {}

@@ -10,13 +10,19 @@ Parameters are taken in the reference's variable naming (pi/dense{,_1,..}/{kerne
 ml4ca_amd.policy.ActorCritic.state_dict() / tf_checkpoint.read_bundle() give, and evaluated in float64 with the fp32 VALUES of the
 parameters - the exact real-number function the reference's fp32 TensorFlow graph approximates.
 
-PARITY UNPINNED AGAINST TENSORFLOW: TensorFlow is not in this image, so no vector computed by the reference's own graph exists; the
-restatement is pinned only by its twenty lines being the cited formulae (and by tests/golden/final_policy.npz, an independent NumPy
-evaluation of the shipped checkpoint made by tools/gen_golden.py).  Only tests/ import this.
+PINNED TO THE REFERENCE'S OWN GRAPH FILE (round 4): tests/golden/final_graph.json holds the forward part of
+data/finalmodel/finconttothighbowder_s0/tf1_save/saved_model.pb (read without TensorFlow by ml4ca_amd/tf_graph.py,
+tests/golden/gen_final_graph.py) - node list, op order MatMul -> BiasAdd -> Maximum(alpha x, x), alpha, the likelihood's constants, the
+signature and the tensor test_policy.py:90 picks - and tests/test_policy_import_cpu.py executes THAT graph node by node on the
+checkpoint's variables and requires these functions to agree with it to 1e-12.  The constants below are the float32 values the graph
+holds.  NOT pinned: TensorFlow's own kernels (no TensorFlow in this image, so no vector it computed exists) - i.e. its fp32 summation
+order, which is inside the 1e-5 the arithmetic claim is stated at.  Only tests/ import this.
 """
 import numpy as np
 
-LEAKY_SLOPE = 0.2          # tf.nn.leaky_relu default alpha (train.py:24,31 'leaky')
+LEAKY_SLOPE = 0.20000000298023224      # pi/dense*/LeakyRelu/alpha: float32(0.2), tf.nn.leaky_relu's default (train.py:24,31 'leaky')
+LIKELIHOOD_EPS = 9.99999993922529e-09  # pi/add_1/y: float32(1e-8)  (core.py:44 EPS)
+LOG_2PI = 1.8378770351409912           # pi/add_3/y: float32(log(2 pi))  (core.py:45)
 
 
 def _layers(params, scope):
@@ -50,5 +56,5 @@ def actor_critic(params, obs, activation='leaky', leak=LEAKY_SLOPE):
 def gaussian_likelihood(x, mu, log_std):
     """core.py:42-46"""
     x, mu, log_std = np.asarray(x, np.float64), np.asarray(mu, np.float64), np.asarray(log_std, np.float64)
-    pre = -0.5 * (((x - mu) / (np.exp(log_std) + 1e-8)) ** 2 + 2 * log_std + np.log(2 * np.pi))
+    pre = -0.5 * (((x - mu) / (np.exp(log_std) + LIKELIHOOD_EPS)) ** 2 + 2 * log_std + LOG_2PI)
     return pre.sum(axis=1)

@@ -13,12 +13,46 @@ pytestmark = pytest.mark.gpu
 
 
 def ref64(ac, obs):
-    """float64 evaluation of core.py:29-33 with the fp32 parameters: the yardstick for the 1e-5 claims (oracle/policy_ref.py:
-    a restatement - TensorFlow is not in this image, so it is unpinned against the reference's own graph)."""
+    """float64 evaluation of core.py:29-33 with the fp32 parameters: the yardstick for the 1e-5 claims (oracle/policy_ref.py: a
+    restatement, pinned since round 4 to an execution of the reference's own saved GraphDef - tests/test_policy_import_cpu.py; the
+    slope is the float32 value the kernel is given)."""
     from oracle import policy_ref as PR
     torch = torch_()
-    mu, v = PR.actor_critic(ac.state_dict(), obs.detach().double().cpu().numpy(), activation=ac.activation, leak=ac.leak)
+    mu, v = PR.actor_critic(ac.state_dict(), obs.detach().double().cpu().numpy(), activation=ac.activation, leak=float(np.float32(ac.leak)))
     return torch.from_numpy(mu).to(obs.device), torch.from_numpy(v).to(obs.device)
+
+
+def test_in_kernel_networks_against_the_reference_graph_on_the_thesis_checkpoint():
+    """The thesis' trained actor-critic (tests/golden/final_policy.npz) through dpenv_policy_forward in DPENV_POLICY_F32 against what the
+    reference's OWN saved graph computes for the same observations (tests/golden/final_graph_vectors.npz: saved_model.pb executed node by
+    node in float64 by ml4ca_amd/tf_graph.py, tests/golden/gen_final_graph.py): mu and v within 1e-5 of the output scale; and the
+    log-likelihood the rollout kernel stores for a forced action (noise block = the fixture's xi) against the graph's pi/Sum_1."""
+    import os
+    from ml4ca_amd.policy import ActorCritic, policy_forward, policy_rollout
+    torch = torch_()
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    d = np.load(os.path.join(G, 'final_policy.npz'))
+    vec = np.load(os.path.join(G, 'final_graph_vectors.npz'))
+    env, _ = H.make_pair('final_cont', 64)
+    ac = ActorCritic.from_tensors({k.replace('.', '/'): d[k] for k in d.files if '.' in k}, device=env.device).upload(env, precision='f32')
+    obs = torch.from_numpy(vec['obs']).to(env.device)
+    mu, v = policy_forward(env, obs)
+    s_mu, s_v = np.abs(vec['mu_f64']).max() + 1.0, np.abs(vec['v_f64']).max() + 1.0
+    e_mu, e_v = np.abs(mu.double().cpu().numpy() - vec['mu_f64']).max(), np.abs(v.double().cpu().numpy() - vec['v_f64']).max()
+    assert e_mu < 1e-5 * s_mu and e_v < 1e-5 * s_v, (e_mu / s_mu, e_v / s_v)
+    # one closed-loop step from a reset: act = mu(o_0) + exp(log_std) xi and logp as the graph's pi/add and pi/Sum_1 give them for o_0
+    env.reset()
+    noise = torch.from_numpy(vec['xi'].astype(np.float32)).to(env.device).reshape(1, 64, 7)
+    out = policy_rollout(env, 1, noise=noise)
+    from ml4ca_amd import tf_graph as TG
+    from tests.test_policy_import_cpu import graph_fixture
+    _, nodes, _ = graph_fixture()
+    t = {k.replace('.', '/'): d[k] for k in d.files if '.' in k}
+    o0 = out['obs'][0].cpu().numpy()
+    xi32 = vec['xi'].astype(np.float32).astype(np.float64)
+    pi, lp = TG.evaluate(nodes, ['pi/add', 'pi/Sum_1'], {'Placeholder': o0}, t, rng_normal=lambda shape: xi32.reshape(shape))
+    assert np.abs(out['act'][0].double().cpu().numpy() - pi).max() < 1e-5 * (np.abs(pi).max() + 1.0)
+    assert np.abs(out['logp'][0].double().cpu().numpy() - lp).max() < 1e-5 * (np.abs(lp).max() + 1.0)
 
 
 @pytest.mark.parametrize('mode,ext,hidden,activation', [

@@ -203,9 +203,116 @@ def test_policy_yardstick_reproduces_the_checkpoint_fixture():
     rng = np.random.RandomState(0)
     x = mu + np.exp(params['pi/log_std']) * rng.standard_normal(mu.shape)
     lp = PR.gaussian_likelihood(x, mu, params['pi/log_std'])
-    z = (x - mu) / (np.exp(params['pi/log_std'].astype(np.float64)) + 1e-8)
-    want = (-0.5 * z * z - params['pi/log_std'] - 0.5 * np.log(2 * np.pi)).sum(1)
+    z = (x - mu) / (np.exp(params['pi/log_std'].astype(np.float64)) + PR.LIKELIHOOD_EPS)
+    want = (-0.5 * z * z - params['pi/log_std'] - 0.5 * PR.LOG_2PI).sum(1)
     assert np.abs(lp - want).max() < 1e-12
+    # the constants are the float32 values the reference's graph holds (test below); with the double-precision log(2 pi) the seven
+    # action dimensions would differ by 3.5 x 3.1e-8
+    want64 = (-0.5 * z * z - params['pi/log_std'] - 0.5 * np.log(2 * np.pi)).sum(1)
+    assert 0.9e-7 < np.abs(lp - want64).max() < 1.3e-7
     # relu = leaky with slope 0, tanh: the other --activation choices (train.py:24,31)
     assert np.all(PR.mlp(np.array([[-1.0]]), [np.eye(1), np.eye(1)], [np.zeros(1), np.zeros(1)], 'relu') == 0.0)
     assert abs(PR.mlp(np.array([[0.5]]), [np.eye(1), np.eye(1)], [np.zeros(1), np.zeros(1)], 'tanh')[0, 0] - np.tanh(0.5)) < 1e-15
+
+
+# ---- the network GRAPH pinned to the reference's own saved_model.pb (tests/golden/gen_final_graph.py) -----------------------------
+REF_MODEL = '/root/reference/src/rl/windows_workspace/data/finalmodel/finconttothighbowder_s0/tf1_save'
+
+
+def graph_fixture():
+    import json
+    rec = json.load(open(os.path.join(G, 'final_graph.json')))
+    nodes = {}
+    for n, nd in rec['forward_nodes'].items():
+        attr = {}
+        for k, v in nd['attr'].items():
+            attr[k] = np.array(v['data'], dtype=v['dtype']).reshape(v['shape']) if isinstance(v, dict) else v
+        nodes[n] = {'op': nd['op'], 'inputs': nd['inputs'], 'attr': attr}
+    return rec, nodes, np.load(os.path.join(G, 'final_graph_vectors.npz'))
+
+
+def test_the_saved_graph_is_what_the_library_and_the_yardstick_assume():
+    """Facts of the reference's GraphDef (not of config.json, not of prose): layer order, activation form and slope, likelihood
+    constants, signature, the tensor test_policy.py:90 feeds to the env."""
+    from oracle import policy_ref as PR
+    rec, nodes, _ = graph_fixture()
+    assert rec['nodes_in_file'] == 19898 and len(nodes) == 112
+    assert rec['signature'] == {'inputs': {'x': 'Placeholder:0'}, 'outputs': {'pi': 'pi/add:0', 'v': 'v/Squeeze:0'}}
+    assert rec['tensor_fed_to_the_env_by_test_policy_py_90'] == 'pi/dense_3/BiasAdd' and 'pi/dense_3/BiasAdd' in nodes
+    for net, out_units in (('pi', 7), ('v', 1)):
+        chain = rec['describe'][net]
+        assert [l['layer'] for l in chain] == [net + '/dense', net + '/dense_1', net + '/dense_2', net + '/dense_3']
+        assert all(l['ops'] == ['MatMul', 'BiasAdd', 'LeakyRelu'] and l['form'] == 'Maximum(Mul(alpha, x), x)' for l in chain[:-1])
+        assert chain[-1]['ops'] == ['MatMul', 'BiasAdd']                                   # no activation behind the output layer
+        assert not any(l['transpose_a'] or l['transpose_b'] for l in chain)                # x @ W, W stored [in][out] as the kernels take it
+        assert chain[0]['input'] == 'Placeholder'
+    # the slope: float32(0.2) - what ActorCritic's default, the kernel's `leak` argument (a float) and the yardstick use
+    assert rec['hidden_activation'] == ['leaky', float(np.float32(0.2))]
+    assert PR.LEAKY_SLOPE == float(np.float32(0.2))
+    c = rec['scalar_float_constants']
+    assert c['pi/add_1/y'] == PR.LIKELIHOOD_EPS == float(np.float32(1e-8))                 # core.py:44
+    assert c['pi/add_3/y'] == PR.LOG_2PI == float(np.float32(np.log(2 * np.pi)))           # core.py:45
+    assert c['pi/mul_2/x'] == -0.5 and c['pi/pow/y'] == 2.0 and c['pi/mul_1/x'] == 2.0
+    # the likelihood subgraph is the cited formula: Sum(-0.5 * (((a - mu) / (exp(log_std) + eps))^2 + 2 log_std + log 2 pi), axis 1)
+    assert nodes['pi/Sum']['op'] == 'Sum' and nodes['pi/Sum']['inputs'][0] == 'pi/mul_2'
+    assert nodes['pi/truediv']['op'] == 'RealDiv' and nodes['pi/truediv']['inputs'] == ['pi/sub', 'pi/add_1']
+    assert nodes['pi/sub']['inputs'] == ['Placeholder_1', 'pi/dense_3/BiasAdd'] and nodes['pi/add_1']['inputs'] == ['pi/Exp_1', 'pi/add_1/y']
+    # the sample: mu + N(0, 1) * exp(log_std)  (core.py:85)
+    assert nodes['pi/add']['inputs'] == ['pi/dense_3/BiasAdd', 'pi/mul'] and nodes['pi/mul']['inputs'] == ['pi/random_normal', 'pi/Exp']
+    # PPO clip ratio 0.2 (ppo.py:233: clip_ratio) sits in the loss as 1.2 / 0.8
+    assert abs(c['mul/x'] - 1.2) < 1e-6 and abs(c['mul_1/x'] - 0.8) < 1e-6
+
+
+def test_yardstick_and_torch_reference_against_an_execution_of_the_saved_graph():
+    """tf_graph.evaluate runs the reference's own forward graph (fixture nodes) on the checkpoint's variables (final_policy.npz).
+    oracle/policy_ref.py - the yardstick of every network-arithmetic claim - must BE that function (1e-12), and the fp32 torch
+    reference of ActorCritic must be within 1e-5 of the output scale."""
+    import torch
+    from ml4ca_amd import tf_graph as TG
+    from ml4ca_amd.policy import ActorCritic
+    from oracle import policy_ref as PR
+    rec, nodes, vec = graph_fixture()
+    t, _ = fixture_tensors()
+    obs, act, xi = vec['obs'], vec['act'], vec['xi']
+    mu, v = TG.evaluate(nodes, ['pi/dense_3/BiasAdd', 'v/Squeeze'], {'Placeholder': obs}, t)
+    logp, = TG.evaluate(nodes, ['pi/Sum'], {'Placeholder': obs, 'Placeholder_1': act}, t)
+    pi, logp_pi = TG.evaluate(nodes, ['pi/add', 'pi/Sum_1'], {'Placeholder': obs}, t, rng_normal=lambda shape: xi.reshape(shape))
+    # the stored vectors were made from the reference's files (bundle + graph) in the build container: same numbers from the fixtures
+    for a, k in ((mu, 'mu_f64'), (v, 'v_f64'), (logp, 'logp_f64'), (pi, 'pi_f64'), (logp_pi, 'logp_pi_f64')):
+        assert np.array_equal(a, vec[k]), k
+    # the yardstick IS the graph's function
+    pmu, pv = PR.actor_critic(t, obs)
+    assert np.abs(pmu - mu).max() < 1e-12 and np.abs(pv - v).max() < 1e-10 * max(1.0, np.abs(v).max())
+    assert np.abs(PR.gaussian_likelihood(act, pmu, t['pi/log_std']) - logp).max() < 1e-9 * np.abs(logp).max()
+    assert np.abs(PR.gaussian_likelihood(pi, pmu, t['pi/log_std']) - logp_pi).max() < 1e-9 * np.abs(logp_pi).max()
+    # the graph in its own arithmetic type (float32, NumPy's summation order) against its real-number function: the size of what
+    # "fp32" leaves open - and the torch fp32 reference, and ActorCritic's defaults, inside 1e-5 of the output scale
+    assert np.abs(vec['mu_f32'] - mu).max() < 1e-5 * max(1.0, np.abs(mu).max())
+    assert np.abs(vec['v_f32'] - v).max() < 1e-5 * np.abs(v).max()
+    ac = ActorCritic.from_tensors(t)
+    assert np.float32(ac.leak) == np.float32(rec['hidden_activation'][1]) and ac.activation == 'leaky'
+    tmu, tv = ac.forward_ref(torch.tensor(obs))
+    assert np.abs(tmu.numpy() - mu).max() < 1e-5 * max(1.0, np.abs(mu).max())
+    assert np.abs(tv.numpy() - v).max() < 1e-5 * np.abs(v).max()
+    tlp = ac.logp_ref(torch.tensor(act), tmu).numpy()
+    assert np.abs(tlp - logp).max() < 2e-5 * np.abs(logp).max()
+    # an op outside the forward pass is refused, not guessed
+    bad = dict(nodes, extra={'op': 'Conv2D', 'inputs': ['Placeholder'], 'attr': {}})
+    with pytest.raises(NotImplementedError):
+        TG.evaluate(bad, ['extra'], {'Placeholder': obs}, t)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_MODEL, 'saved_model.pb')), reason='reference tree only exists in the build container')
+def test_graph_reader_on_the_reference_file_matches_the_fixture():
+    from ml4ca_amd import tf_graph as TG
+    from ml4ca_amd.policy import ActorCritic
+    rec, nodes, _ = graph_fixture()
+    g = TG.read_saved_model(os.path.join(REF_MODEL, 'saved_model.pb'))
+    assert len(g.order) == rec['nodes_in_file'] and TG.ancestors(g, rec['fetches']) == rec['order']
+    for n in rec['order']:
+        assert g.nodes[n]['op'] == nodes[n]['op'] and g.nodes[n]['inputs'] == nodes[n]['inputs'], n
+    ac = ActorCritic.from_saved_model(REF_MODEL)
+    assert (ac.obs_dim, ac.act_dim, ac.hidden_sizes, ac.activation) == (9, 7, (80, 80, 80), 'leaky') and np.float32(ac.leak) == np.float32(0.2)
+    t, _ = fixture_tensors()
+    for k, v in ac.state_dict().items():
+        assert np.array_equal(v, t[k]), k

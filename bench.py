@@ -41,6 +41,44 @@ HBM_PEAK_GBPS = 8000.0                             # MI355X_MICROARCH.md: 8.0 TB
 ALGO_FLOPS_PER_ENV_STEP = 20 * 80 + 400            # ~80 flop per plant sub-step (semi-implicit Euler, 20 x 10 ms) + ~400 decode / trig / reward
 VALU_PEAK_TFLOPS = 157.3                           # MI355X_MICROARCH.md: peak fp32 vector
 MIN_TIMED_MS = 10.0
+# algorithmic bytes per env-step of the other measured kernels (each stated where it is used)
+ROLLOUT_BYTES_MOVED = 28 + 36 + 4 + 1              # dpenv_rollout: action row in; obs row, reward, done out (state stays in registers)
+POLICY_ROWS_BYTES_F32 = 36 + 28 + 4 + 4 + 4 + 4 + 1      # dpenv_policy_rollout: obs 36 | act 28 | rew | val | logp | boot | done written, nothing read
+CONFIG5_BYTES = 192                                # 175 B step with bf16 obs and current state + 17 B GAE pass
+GAE_BYTES = 21                                     # rew 4 + val 4 + done 1 + boot 4 read, adv 4 + ret 4 written (SURVEY's 17 + the boot row)
+ADV_APPLY_BYTES = 8                                # adv read + written
+
+
+def hbm_roofline(kernel, bytes_per_env_step, env_steps, seconds, what, launches=None, **extra):
+    """roofline sub-record of one measured kernel: algorithmic bytes / measured time against the 8 TB/s HBM peak"""
+    ach = bytes_per_env_step * env_steps / seconds / 1e9
+    rec = {'bound': 'hbm', 'kernel': kernel, 'algorithmic_bytes_per_env_step': bytes_per_env_step, 'algorithmic_bytes': bytes_per_env_step * env_steps,
+           'achieved': ach, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBPS, 'what': what}
+    if launches:
+        rec['avg_launch_us'] = seconds / launches * 1e6
+    rec.update(extra)
+    return rec
+
+
+def step_kernel_name(env):
+    """the instantiation dpenv_step launches for this env (dpenv_kernels.hip: step_kernel<MODE, EXT, PER_CLASS>; dpenv_dev.h MODE_*)"""
+    mode = {'full': 0, 'simple': 1, 'limited': 2, 'final': 4 if env.cont_ang else 3}[env.variant]
+    return 'dpenv::step_kernel<%d,%s,%s>' % (mode, 'true' if env.extended_state else 'false', 'true' if env.n_classes > 1 else 'false')
+
+
+def env_kernel_args(env):
+    mode = {'full': 0, 'simple': 1, 'limited': 2, 'final': 4 if env.cont_ang else 3}[env.variant]
+    return mode, ('true' if env.extended_state else 'false')
+
+
+def policy_kernel_name(env, prec):
+    """the closed-loop kernel DPENV_LAUNCH_AUTO resolved to (dpenv_policy_ws.h / dpenv_policy.hip / dpenv_policy_x.hip)"""
+    from ml4ca_amd.policy import policy_launch_form
+    form, epw = policy_launch_form(env)
+    mode, ext = env_kernel_args(env)
+    if form == 'two_wave':
+        return 'dpenv::policy_rollout_ws_kernel<%d,%s,KA=5,2,%s,GROUPS=%d>' % (mode, ext, {'f16': 'F16', 'f32': 'F32', 'f32_actor': 'F32_ACTOR'}[prec], epw // 64)
+    return 'dpenv::policy_rollout_%skernel<%d,%s,...>' % ('' if prec == 'f16' else 'x_', mode, ext)
 
 
 def parse():
@@ -54,6 +92,9 @@ def parse():
     ap.add_argument('--no-fused', action='store_true', help='skip the fused-rollout leg')
     ap.add_argument('--cpu-seconds', type=float, default=14.0, help='budget of the CPU baseline leg (half 1 thread, half all cores)')
     ap.add_argument('--policy-form', default='auto', choices=['auto', 'one_wave', 'two_wave'], help='launch form of the closed-loop legs')
+    ap.add_argument('--graph-steps', type=int, default=0, help='profiling form: capture ONE graph of this many env steps (from sequence position '
+                                                                 '--warmup) and replay it; the box sequence then does not advance between replays '
+                                                                 '(default 0: one graph of lcm(steps, 1250) steps, the whole sequence)')
     ap.add_argument('--repeats', type=int, default=0, help='repeats of the timed --steps region (0 = enough for %g ms)' % MIN_TIMED_MS)
     ap.add_argument('--gather', type=int, default=-1, help='time the config-4 trajectory all-gather (default: on if gpus > 1)')
     ap.add_argument('--hold-plant', action='store_true', help='diagnostic: skip the plant sub-steps (INVALID as a result)')
@@ -337,7 +378,11 @@ def config4_record(args, dev, rank, world, dist):
     hi, lo = _timed(gr.replay, 8, dev, dist, world)
     rec['step_only'] = {'what': 'T = %d launches of dpenv_step (rows written straight into the [T, n] block), one HIP graph per episode' % T,
                         'us_per_step': hi / T * 1e6, 'us_per_step_fastest_rank': lo / T * 1e6, 'env_steps_per_s': tot / hi,
-                        'GBps_at_177B': ALGO_BYTES_PER_ENV_STEP * nl * T / hi / 1e9}
+                        'GBps_at_177B': ALGO_BYTES_PER_ENV_STEP * nl * T / hi / 1e9,
+                        'workload_note': 'config-2 workload: terminate ON and auto-reset ON (the headline workload has both off) - the in-kernel '
+                                         're-draw of finished envs is what this leg pays over the headline kernel at the same size (DESIGN.md section 4)',
+                        'roofline': hbm_roofline(step_kernel_name(env), ALGO_BYTES_PER_ENV_STEP, nl * T, hi, '177 B per env-step; wall time of the slowest rank around '
+                                                 '8 graph replays of T launches', launches=T)}
     del gr
 
     # (b) fused open loop: CH steps per launch
@@ -367,7 +412,9 @@ def config4_record(args, dev, rank, world, dist):
         episode(bufA)
         hi, lo = _timed(lambda: episode(bufA), 3, dev, dist, world)
         rec['closed_loop']['policy_dtype_' + prec] = {'ms_per_episode': hi * 1e3, 'us_per_step': hi / T * 1e6, 'env_steps_per_s': tot / hi,
-                                                      'ms_per_episode_fastest_rank': lo * 1e3}
+                                                      'ms_per_episode_fastest_rank': lo * 1e3,
+                                                      'roofline': hbm_roofline(policy_kernel_name(env, prec) + ' + gae_kernel<2,8> + adv_apply_kernel', POLICY_ROWS_BYTES_F32 + GAE_BYTES + ADV_APPLY_BYTES,
+                                                                               nl * T, hi, 'PPO rows 81 B + GAE 21 B + normalisation 8 B per env-step, whole episode, slowest rank')}
     ac.upload(env, precision='f32_actor')            # the arithmetic a PPO update needs (exact log-likelihood), used below
     t_roll = rec['closed_loop']['policy_dtype_f32_actor']['ms_per_episode'] * 1e-3
 
@@ -625,6 +672,9 @@ def main():
         # an awkward --steps: the graph holds the smallest whole number of K-step regions that covers one box sequence, and the sequence
         # restarts with every replay (its last leg - back at the start pose - is up to K - 1 steps longer); said in config.launch
         G = K * (-(-SEQ // K))
+    if args.graph_steps > 0:
+        G = K * max(1, args.graph_steps // K)           # a whole number of --steps regions; --steps > --graph-steps: one region per graph
+        aligned = False
     use_graph = not args.no_graph
     pos = {'t': 0}
     for t in range(W):                                 # exactly W untimed warm-up steps, eager
@@ -737,7 +787,15 @@ def main():
         fused = {'what': 'dpenv_rollout: %d env steps per launch, state resident in registers; open-loop action block; '
                          'same workload; NOT the headline value' % CHUNK,
                  'steps': KL, 'env_steps_per_s': n * KL / fwall, 'us_per_step': fwall / KL * 1e6, 'launch_us_events': fms * 1e3 / (KL // CHUNK),
-                 'bytes_per_env_step_moved': 28 + 36 + 4 + 1,
+                 'bytes_per_env_step_moved': ROLLOUT_BYTES_MOVED,
+                 'roofline': hbm_roofline('dpenv::rollout_kernel<%d,%s,false>' % env_kernel_args(env), ROLLOUT_BYTES_MOVED, n * KL, fms * 1e-3,
+                                          'bytes this kernel has to move per env-step (action row in; obs row, reward, done out: the state '
+                                          'stays in registers for the %d steps of a launch); HIP events around %d launches' % (CHUNK, KL // CHUNK),
+                                          launches=KL // CHUNK, bound_in_practice='VALU issue of one wave per SIMD (DESIGN.md section 4)'),
+                 'roofline_at_177B_accounting': hbm_roofline('dpenv::rollout_kernel<%d,%s,false>' % env_kernel_args(env), ALGO_BYTES_PER_ENV_STEP, n * KL, fms * 1e-3,
+                                                             'the SAME time priced at SURVEY 8(d)\'s 177 B per env-step of the one-launch-per-step '
+                                                             'path (what the fusion saves is exactly the state traffic, so this is an '
+                                                             'equivalent-work rate, not bytes moved)'),
                  'GBps_at_177B_accounting': ALGO_BYTES_PER_ENV_STEP * n * KL / (fms * 1e-3) / 1e9,
                  'frac_of_8TBps_at_177B_accounting': ALGO_BYTES_PER_ENV_STEP * n * KL / (fms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                  'valu_TFLOPs_at_%d_flop_per_env_step' % ALGO_FLOPS_PER_ENV_STEP: ALGO_FLOPS_PER_ENV_STEP * n * KL / (fms * 1e-3) / 1e12}
@@ -762,18 +820,29 @@ def main():
 
             kc = KL if prec == 'f16' else max(CHUNK, KL // 2)
             run_closed(6 * WL)                       # the MFMA-heavy forms wobble for the first launches after a change of kernel (clock ramp)
+            ce0, ce1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize(dev)
             tc0 = time.perf_counter()
+            ce0.record()
             run_closed(kc)
+            ce1.record()
             torch.cuda.synchronize(dev)
             cwall = time.perf_counter() - tc0
+            cev = ce0.elapsed_time(ce1) * 1e-3
             assert bool(torch.isfinite(pout['obs']).all()) and bool(torch.isfinite(pout['logp']).all())
             closed['policy_dtype_' + prec] = {
                 'policy_dtype': {'f16': 'f16 weights/activations, f32 accumulate (fast mode, ~5e-4 of the output scale from fp32)',
                                  'f32': 'split-f16 hi+lo, three MFMAs per product (DPENV_POLICY_F32: within 1e-5 of an fp32 evaluation, the parity mode)',
                                  'f32_actor': 'actor as f32, critic as f16 (DPENV_POLICY_F32_ACTOR: mu / action / logp within 1e-5, values as in the fast mode)'}[prec],
                 'launch_form': '%s, %d envs per workgroup' % policy_launch_form(env),
-                'steps': kc, 'env_steps_per_s': n * kc / cwall, 'us_per_step': cwall / kc * 1e6, 'policy_TFLOPs': flops * kc / cwall / 1e12}
+                'steps': kc, 'env_steps_per_s': n * kc / cwall, 'us_per_step': cwall / kc * 1e6, 'policy_TFLOPs': flops * kc / cwall / 1e12,
+                'roofline': hbm_roofline(policy_kernel_name(env, prec), POLICY_ROWS_BYTES_F32, n * kc, cev,
+                                         'PPO rows written per env-step (obs 36 | act 28 | rew | val | logp | boot 16 | done 1; nothing is read); HIP events '
+                                         'around %d launches of %d steps' % (kc // CHUNK, CHUNK), launches=kc // CHUNK,
+                                         bound_in_practice='the serial chain actor -> env.step -> actor on MFMA + VALU issue, not memory (DESIGN.md section 4)'),
+                'roofline_mfma': {'bound': 'mfma', 'achieved': flops * kc / cev / 1e12, 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': flops * kc / cev / 1e12 / 2500.0,
+                                  'what': 'useful actor + critic flops (2 x MACs of 9-80-80-80-7 and 9-80-80-80-1; the split arithmetic issues 3 MFMAs per '
+                                          'product and padded tiles on top) against the dense f16 MFMA peak: a 64-row batch per wave cannot fill the pipe'}}
         closed['us_per_step'] = closed['policy_dtype_f16']['us_per_step']
         # reference point: the same policy as separate torch kernels (fp32) + one env.step launch per step
         noise1 = torch.randn((n, 7), generator=g, device=dev)
@@ -820,14 +889,17 @@ def main():
                 return buf5.get()
 
             epoch5()
-            ge0, ge1, ge2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            ge0, ge1, ge2, gw0, gw1 = (torch.cuda.Event(enable_timing=True) for _ in range(5))
             torch.cuda.synchronize(dev)
             t50 = time.perf_counter()
             reps5 = 3 if prec == 'f16' else 2
+            gw0.record()
             for _ in range(reps5):
                 o5, a5, adv5, ret5, lp5 = epoch5()
+            gw1.record()
             torch.cuda.synchronize(dev)
             w5 = (time.perf_counter() - t50) / reps5
+            w5ev = gw0.elapsed_time(gw1) * 1e-3 / reps5
             # GAE + normalisation alone, on the block just produced
             ge0.record()
             buf5.finish()
@@ -838,37 +910,32 @@ def main():
             assert bool(torch.isfinite(adv5).all()) and o5.dtype == torch.bfloat16
             cfg5['policy_dtype_' + prec] = {'env_steps_per_s': n * T5 / w5, 'ms_per_epoch': w5 * 1e3, 'us_per_step': w5 / T5 * 1e6,
                                             'gae_with_stats_ms': ge0.elapsed_time(ge1), 'normalise_ms': ge1.elapsed_time(ge2),
-                                            'gae_GBps_at_21B_per_env_step': 21 * n * T5 / (ge0.elapsed_time(ge1) * 1e-3) / 1e9}
+                                            'gae_GBps_at_21B_per_env_step': GAE_BYTES * n * T5 / (ge0.elapsed_time(ge1) * 1e-3) / 1e9,
+                                            'roofline': hbm_roofline('pack_policy_kernel + ' + policy_kernel_name(env5, prec) + ' + gae_kernel<2,8> + gae_finalize_kernel + adv_apply_kernel<true>',
+                                                                     CONFIG5_BYTES, n * T5, w5ev,
+                                                                     'SURVEY 8(d) config 5: 192 B per env-step (175 B step with bf16 obs and current state + 17 B GAE pass) '
+                                                                     'over the whole epoch (HIP events around %d epochs)' % reps5,
+                                                                     bound_in_practice='the closed-loop chain (above); the GAE + normalisation part alone is HBM-bound: roofline_gae / roofline_adv_apply'),
+                                            'roofline_gae': hbm_roofline('dpenv::gae_kernel<2,8> (+ gae_finalize_kernel)', GAE_BYTES, n * T5, ge0.elapsed_time(ge1) * 1e-3,
+                                                                         'rew 4 | val 4 | done 1 | boot 4 read, adv 4 | ret 4 written per env-step; statistics in the same pass'),
+                                            'roofline_adv_apply': hbm_roofline('dpenv::adv_apply_kernel<true>', ADV_APPLY_BYTES, n * T5, ge1.elapsed_time(ge2) * 1e-3,
+                                                                               'adv read and written once')}
         cfg5['us_per_step'] = cfg5['policy_dtype_f16']['us_per_step']
         del env5, buf5
-
-    # ---- config-4 record (BASELINE.json configs[3]): measured at ITS shard size, on every rank ------------------------------
-    # (the headline above is what the driver's scaling curve is computed from: a failure in a side record must not take the line down.
-    # The same deterministic error is raised on every rank at the same point, so no rank is left waiting in a collective.)
-    cfg4 = None
-    if (args.config4 == 1) or (args.config4 < 0 and world > 1) or args.gather == 1:
-        try:
-            cfg4 = config4_record(args, dev, rank, world, dist)
-        except Exception as e:       # pragma: no cover - reported, not hidden
-            import traceback
-            cfg4 = {'error': '%s: %s' % (type(e).__name__, e), 'traceback': traceback.format_exc()[-1500:]}
-            sys.stderr.write('bench.py: config-4 record failed on rank %d: %s\n' % (rank, cfg4['error']))
-    classes = None
-    if args.classes > 0 and rank == 0:
-        classes = classes_record(args, dev, n)
 
     if rank == 0:
         total_envs = n * world
         per_launch_bytes = ALGO_BYTES_PER_ENV_STEP * n
         kern_s = ev_ms * 1e-3 / KR                     # HIP events (on the launch stream) around the KR graph-replayed launches
         achieved = per_launch_bytes / kern_s / 1e9
-        traffic, traffic_source = None, None
+        traffic, traffic_source, kdur = None, None, None
         try:
             tj = json.load(open(args.traffic_json))
             if tj.get('n_envs') == n:
                 traffic = tj.get('hbm_bytes_per_launch')
                 traffic_source = '%s: rocprofv3 --pmc passes of this command run by the builder (%s), NOT measured in this run' % (
                     os.path.relpath(args.traffic_json, ROOT), tj.get('tag', 'see profiles/'))
+                kdur = tj.get('step_kernel_duration_ns')
         except Exception:
             pass
         valu_tflops = ALGO_FLOPS_PER_ENV_STEP * n / kern_s / 1e12
@@ -883,17 +950,18 @@ def main():
                                'fp32 state; error against the libm fp32 oracle: cpu_baseline.gpu_vs_cpu',
                        'launch': 'one launch per step from the host (no graph)' if graph is None else
                                  ('hipGraph replay: %d env steps per graph = lcm(steps, 1250) = %d repeats of the %d-step region, setpoint switches inside the graph' % (G, per_region, K)
-                                  if aligned else 'hipGraph replay: %d env steps per graph = %d repeats of the %d-step region covering one box sequence '
+                                  if aligned else 'PROFILING FORM (--graph-steps): hipGraph of %d env steps from sequence position %d, replayed (the sequence does not advance)' % (G, W)
+                                  if args.graph_steps > 0 else 'hipGraph replay: %d env steps per graph = %d repeats of the %d-step region covering one box sequence '
                                   '(lcm(steps, 1250) is too long: the sequence restarts with every replay), setpoint switches inside the graph' % (G, per_region, K)),
                        'timed_region': '%d steps x %d repeats back to back = %d graph replay(s) (%.1f ms)' % (K, R, RG, wall * 1e3),
                        'sharding': 'independent env shards, no data-path collective',
                        'backend': args.backend if world > 1 else None},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic, 'traffic_source': traffic_source,
-                         'kernel': 'dpenv::step_kernel<4,true,false>', 'algorithmic_bytes_per_launch': per_launch_bytes,
+                         'kernel': step_kernel_name(env), 'algorithmic_bytes_per_launch': per_launch_bytes,
                          'avg_launch_us': kern_s * 1e6,
-                         'note': 'avg_launch_us = HIP-event time over the timed region / launches (includes the ~1.5 us '
-                                 'kernel-boundary gap); 177 B/env-step x %d envs' % n},
+                         'note': 'avg_launch_us = HIP-event time over the timed region / launches = the SPACING of back-to-back dependent launches '
+                                 '(kernel duration + the ~1.5 us kernel boundary); frac uses it (the conservative reading); 177 B/env-step x %d envs' % n},
             'roofline_valu': {'bound': 'valu_fp32', 'achieved': valu_tflops, 'peak': VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                               'frac': valu_tflops / VALU_PEAK_TFLOPS, 'flops_per_env_step': ALGO_FLOPS_PER_ENV_STEP,
                               'note': 'SURVEY 8(d) secondary figure: algorithmic fp32 flops (20 semi-implicit Euler sub-steps x ~80 + ~400 decode/'
@@ -901,8 +969,40 @@ def main():
             'reference_context': {'published_derived_env_steps_per_s': 34.3,
                                   'source': 'BASELINE.md: 2.4M interactions / 69930 s, 1 env, laptop + Cybersea'},
         }
+        if kdur:
+            # the kernel's own duration cannot be taken with HIP events inside a dependent chain (an event pair brackets duration + boundary):
+            # it comes from the committed rocprofv3 kernel trace of the eager form of this command, where nothing stretches it
+            res['roofline']['kernel_duration_profile'] = {
+                'avg_us': kdur.get('avg', 0) / 1e3, 'median_us': kdur.get('median', 0) / 1e3, 'min_us': kdur.get('min', 0) / 1e3,
+                'frac_by_kernel_duration': per_launch_bytes / (kdur.get('avg', 1) * 1e-9) / 1e9 / HBM_PEAK_GBPS if kdur.get('avg') else None,
+                'source': '%s: %s; NOT measured in this run' % (os.path.relpath(args.traffic_json, ROOT), kdur.get('source', 'rocprofv3 --kernel-trace'))}
         res['group'] = group
         res['per_rank'] = {'wall_s': per_rank, 'hip_event_s': per_rank_ev, 'ms_per_step_min': min(per_rank) / KR * 1e3, 'ms_per_step_max': max(per_rank) / KR * 1e3}
+    else:
+        res = None
+    # ---- config-4 record (BASELINE.json configs[3]): measured at ITS shard size, on every rank ------------------------------
+    # (the headline above is what the driver's scaling curve is computed from: a failure in a side record must not take the line down.
+    # The same deterministic error is raised on every rank at the same point, so no rank is left waiting in a collective.)
+    cfg4 = None
+    want_cfg4 = (args.config4 == 1) or (args.config4 < 0 and world > 1) or args.gather == 1
+    if want_cfg4 and rank == 0:
+        # a side record that hangs in a collective (one rank failing alone) must not cost the measured headline - it goes to
+        # stderr first; stdout still carries exactly one JSON line, at the end
+        sys.stderr.write('bench.py: headline measured (the final stdout line repeats it with the side records): %s\n' % json.dumps(
+            {k: res[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'scaling', 'dtype', 'roofline')}))
+        sys.stderr.flush()
+    if want_cfg4:
+        try:
+            cfg4 = config4_record(args, dev, rank, world, dist)
+        except Exception as e:       # pragma: no cover - reported, not hidden
+            import traceback
+            cfg4 = {'error': '%s: %s' % (type(e).__name__, e), 'traceback': traceback.format_exc()[-1500:]}
+            sys.stderr.write('bench.py: config-4 record failed on rank %d: %s\n' % (rank, cfg4['error']))
+    classes = None
+    if args.classes > 0 and rank == 0:
+        classes = classes_record(args, dev, n)
+
+    if rank == 0:
         if cfg4:
             res['config4'] = cfg4
         if classes:

@@ -117,7 +117,9 @@ typedef struct dpenv_config {
     int32_t reset_acts;      /* 1: an episode starts with previous thrust clip(100 * N(0, 0.1)) instead of zero (the reference's
                                 reset_acts constructor flag, customEnv.py:30,179-188); drawn in the kernel by every kind of reset,
                                 Philox keyed (seed; global env id, episode) like the pose sample */
-    int32_t reserved;
+    int32_t step_one_wave;   /* 0 (default): with auto_reset on, dpenv_step launches a second wave per 64 envs that prepares the re-draw of
+                                finished envs beside the plant loop (same rows bit for bit).  1: keep the draw on
+                                the env wave - the A/B switch of tools/ and tests; was `reserved` (0) before round 4 */
 } dpenv_config;
 
 /* Optional outputs / inputs of one step beyond the Gym tuple.  All device pointers, any may be NULL. */
@@ -238,9 +240,14 @@ typedef struct dpenv_policy_desc {
  * packing if they are issued on `s` (or on a stream the caller orders behind `s`).  device_pointers = 1: stream-ordered, no host
  * synchronisation, graph-capturable.  device_pointers = 0 (host arrays): the call synchronises `s` before it returns, so the
  * arrays may be freed or changed at once.  Fails with DPENV_EINVAL if the requested launch form cannot hold the networks in the
- * 160 KiB LDS; after a failed DPENV_ENOMEM no policy is in force.  While `s` is being captured into a graph the event bookkeeping is
- * skipped (the graph's own edges order its nodes): a captured rollout keeps reading the image that was current at capture time, so do
- * not upload more than once between two replays of a graph that does not contain the upload itself. */
+ * 160 KiB LDS; after a failed DPENV_ENOMEM no policy is in force.
+ * Graphs: a dpenv_policy_rollout / dpenv_policy_forward RECORDED INTO A HIP GRAPH has the address of the image that was current at
+ * capture time baked into its kernel node.  From that capture on, every eager upload is written IN PLACE into that image (no more
+ * alternation), so a replay always runs the weights of the latest upload - the usual PPO pattern "upload each epoch, replay the rollout
+ * graph" works with any number of uploads between replays.  Ordering of an in-place upload: behind eager readers of the image by their
+ * event (any stream), behind graph replays by STREAM ORDER - replay and upload on one stream, or order the two streams yourself.  An
+ * upload recorded into the graph itself (device pointers) re-packs from the weight tensors at every replay.  Growing the network shape
+ * (a larger image) voids graphs captured before. */
 int dpenv_set_policy_desc(dpenv_handle h, const dpenv_policy_desc* d, dpenv_stream s);
 /* What DPENV_LAUNCH_AUTO resolved to for the policy in force: *two_wave_out = 1 for the two-wave form, *envs_per_workgroup_out = 256 or
  * 128 (host ints, either may be NULL). */
@@ -304,8 +311,10 @@ int dpenv_set_rng_counters(dpenv_handle h, const uint32_t* noise_ctr_in, const u
 /* The observation of step t carries the thrust command of step t-1 (customEnv.py:196-205 fills state_ext before :126 updates
  * prev_thrust); the state block holds the command of step t.  A closed-loop launch that CONTINUES an episode therefore starts from
  * the observation its predecessor ended with: the library keeps that observation's thrust columns (device float[n_envs][4]: o[6], o[7],
- * o[8], unused) and uses them while nothing else (reset, step, rollout, set_state) has touched the state in between - dpenv_step
- * callers hold the returned observation themselves.  get fails with DPENV_EINVAL when there is nothing to continue; set is for
+ * o[8], unused) and uses them while nothing else (step, rollout, set_state) has touched the state in between - dpenv_step
+ * callers hold the returned observation themselves.  dpenv_reset writes the columns of the envs it re-draws (the new episode's own
+ * previous thrust / 100): a full reset makes them valid everywhere, a masked reset leaves the other envs' columns and their validity
+ * alone.  get fails with DPENV_EINVAL when there is nothing to continue; set is for
  * restoring a mid-episode checkpoint (after dpenv_set_state).  Whether a launch continues or rebuilds is decided on the host when
  * dpenv_policy_rollout is CALLED: inside a captured graph the first closed-loop launch keeps the decision made at capture time on
  * every replay (capture a graph that starts with a continuing launch after one such launch has run). */

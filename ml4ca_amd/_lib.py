@@ -39,7 +39,7 @@ class Config(C.Structure):
                 ('obs_layout', C.c_int32), ('obs_dtype', C.c_int32), ('current_enabled', C.c_int32),
                 ('seed', C.c_uint64), ('env_id_base', C.c_int64), ('reset_fraction', C.c_float),
                 ('hold_plant', C.c_int32), ('current_drift', C.c_int32), ('current_tau', C.c_float),
-                ('current_sigma_v', C.c_float), ('current_sigma_beta', C.c_float), ('reset_acts', C.c_int32), ('reserved', C.c_int32)]
+                ('current_sigma_v', C.c_float), ('current_sigma_beta', C.c_float), ('reset_acts', C.c_int32), ('step_one_wave', C.c_int32)]
 
 
 class StepIO(C.Structure):

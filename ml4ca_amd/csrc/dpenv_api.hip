@@ -40,6 +40,9 @@ struct dpenv_s {
     int pol_slot;           // image the NEXT upload writes (0 / 1)
     hipEvent_t pol_read[2]; // recorded behind the last launch that read image k: the upload that reuses it waits for that
     bool pol_read_valid[2];
+    hipStream_t pol_read_stream[2];   // the stream that event was last recorded on (a reader on another stream chains behind it)
+    int pol_pinned;         // >= 0: a captured graph reads this image (PolicyArgs.frags is baked into the graph's kernel nodes by value):
+                            //   every later upload is written IN PLACE into it, so that a replay sees the latest weights
     int n_cus;
     float* pol_raw;         // device staging of raw fp32 weights for the host-pointer form of set_policy
     size_t pol_raw_bytes;
@@ -248,6 +251,8 @@ extern "C" int dpenv_create(const dpenv_config* cfg, const float* vessel_params,
     h->pol_slot = 0;
     h->pol_read[0] = h->pol_read[1] = nullptr;
     h->pol_read_valid[0] = h->pol_read_valid[1] = false;
+    h->pol_read_stream[0] = h->pol_read_stream[1] = nullptr;
+    h->pol_pinned = -1;
     {
         hipDeviceProp_t prop;
         h->n_cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
@@ -435,7 +440,9 @@ extern "C" int dpenv_reset(dpenv_handle h, const uint8_t* mask, const float* ini
     bind_optional(h, a);
     a.obs = obs_out;
     HIP_TRY(h, dpenv_dev_launch_reset(&a, h->mode, h->cfg.extended_state, mask, init, ref, (hipStream_t)s));
-    h->lag_valid = false;
+    // the reset kernel writes the lagged thrust columns (S3) of the envs it re-draws: a full reset makes them valid everywhere, a
+    // masked one leaves the validity of the other envs' columns as it was (it used to drop the lag of every env)
+    if (!mask) h->lag_valid = true;
     return DPENV_OK;
 }
 
@@ -457,7 +464,7 @@ extern "C" int dpenv_step_ex(dpenv_handle h, const dpenv_step_io* io, dpenv_stre
     a.done = io->done;
     a.parts = io->reward_parts;
     a.final_obs = io->final_obs;
-    HIP_TRY(h, dpenv_dev_launch_step(&a, h->mode, h->cfg.extended_state, h->n_classes > 1, (hipStream_t)s));
+    HIP_TRY(h, dpenv_dev_launch_step(&a, h->mode, h->cfg.extended_state, h->n_classes > 1, h->cfg.step_one_wave ? 0 : 1, (hipStream_t)s));
     h->lag_valid = false;
     return DPENV_OK;
 }
@@ -563,6 +570,7 @@ extern "C" int dpenv_set_policy_desc(dpenv_handle h, const dpenv_policy_desc* d,
         h->has_policy = false;
         std::memset(&h->pol, 0, sizeof h->pol);
         h->pol_read_valid[0] = h->pol_read_valid[1] = false;
+        h->pol_pinned = -1;                                   // graphs captured on the old images are void (dpenv.h)
     }
     if (!h->pol_buf) {
         if (hipMalloc(&h->pol_buf, 2 * need) != hipSuccess) {
@@ -576,7 +584,12 @@ extern "C" int dpenv_set_policy_desc(dpenv_handle h, const dpenv_policy_desc* d,
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing((hipStream_t)s, &cap);
     const bool capturing = cap != hipStreamCaptureStatusNone;      // inside a captured graph the graph's own edges order everything
-    const int slot = h->pol_slot;
+    // Which image this upload writes.  Eager launches read the image the last upload wrote (h->pol), so uploads alternate and a launch
+    // in flight keeps its weights.  A launch RECORDED INTO A GRAPH has the image's address baked into its kernel node: once that has
+    // happened (pol_pinned) an alternating upload would leave every second set of weights invisible to the replays - so from then on
+    // every eager upload goes in place into the pinned image, ordered behind the eager readers by their event and behind graph
+    // replays by stream order (the caller replays and uploads on one stream, or orders them itself: dpenv.h).
+    const int slot = (!capturing && h->pol_pinned >= 0) ? h->pol_pinned : h->pol_slot;
     if (!capturing && h->pol_read_valid[slot]) HIP_TRY(h, hipStreamWaitEvent((hipStream_t)s, h->pol_read[slot], 0));
     PackNet pn[2];
     const float* ls_dev = d->log_std;
@@ -642,7 +655,7 @@ extern "C" int dpenv_set_policy_desc(dpenv_handle h, const dpenv_policy_desc* d,
     pa.ws_groups = (d->activation == DPENV_ACT_LEAKY_RELU && (h->cfg.n_envs + 127) / 128 <= h->n_cus) ? 2 : 4;
     h->pol_form = d->launch_form;
     h->has_policy = true;
-    h->pol_slot = slot ^ 1;
+    h->pol_slot = slot ^ 1;                                  // "current" = the image just written (pinned or not)
     // host pointers: the caller's arrays (and the shared staging area) must be done with before this returns
     if (!d->device_pointers && !capturing) HIP_TRY(h, hipStreamSynchronize((hipStream_t)s));
     return DPENV_OK;
@@ -651,16 +664,24 @@ extern "C" int dpenv_set_policy_desc(dpenv_handle h, const dpenv_policy_desc* d,
 // behind every launch that reads the current image: the event an upload into that image waits for
 static int mark_policy_read(dpenv_handle h, dpenv_stream s)
 {
+    const int cur = h->pol_slot ^ 1;                        // the image the last upload wrote
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing((hipStream_t)s, &cap);
-    if (cap != hipStreamCaptureStatusNone) return DPENV_OK;
-    const int cur = h->pol_slot ^ 1;                        // the image the last upload wrote
+    if (cap != hipStreamCaptureStatusNone) {
+        h->pol_pinned = cur;                                // a graph now holds this image's address: uploads go in place from here on
+        return DPENV_OK;
+    }
     if (!h->pol_read[cur] && hipEventCreateWithFlags(&h->pol_read[cur], hipEventDisableTiming) != hipSuccess) {
         h->pol_read[cur] = nullptr;
         return fail(h, DPENV_EHIP, "hipEventCreate failed");
     }
+    // one event per image: a reader on ANOTHER stream than the last one first waits (on its stream) for the event as it stands, so
+    // that the re-recorded event completes only when both readers are done - the chain covers every reader on any stream
+    if (h->pol_read_valid[cur] && h->pol_read_stream[cur] != (hipStream_t)s)
+        HIP_TRY(h, hipStreamWaitEvent((hipStream_t)s, h->pol_read[cur], 0));
     HIP_TRY(h, hipEventRecord(h->pol_read[cur], (hipStream_t)s));
     h->pol_read_valid[cur] = true;
+    h->pol_read_stream[cur] = (hipStream_t)s;
     return DPENV_OK;
 }
 

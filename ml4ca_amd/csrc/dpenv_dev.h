@@ -170,7 +170,7 @@ hipError_t dpenv_dev_launch_policy_rollout(const dpenv::StepArgs* a, const dpenv
                                            hipStream_t s);
 hipError_t dpenv_dev_launch_rollout(const dpenv::StepArgs* a, const dpenv::RolloutArgs* ra, int mode, int ext,
                                     int per_class, hipStream_t s);
-hipError_t dpenv_dev_launch_step(const dpenv::StepArgs* a, int mode, int ext, int per_class, hipStream_t s);
+hipError_t dpenv_dev_launch_step(const dpenv::StepArgs* a, int mode, int ext, int per_class, int reset_wave, hipStream_t s);
 hipError_t dpenv_dev_launch_reset(const dpenv::StepArgs* a, int mode, int ext, const uint8_t* mask, const float* init,
                                   const float* ref, hipStream_t s);
 hipError_t dpenv_dev_launch_get_state(const dpenv::StepArgs* a, float* st, int32_t* ctr, hipStream_t s);

@@ -40,14 +40,65 @@ constexpr int STEP_TRACE_RING = 8;
 // =============================================================================================
 //  env.step: one launch = one step of every env
 // =============================================================================================
-template <int MODE, bool EXT, bool PER_CLASS>
-__global__ __launch_bounds__(BLOCK) void step_kernel(const StepArgs a)
+// RESETW (launched when config.auto_reset is on; 64-env workgroups only): the workgroup has a SECOND wave that does nothing but prepare
+// the re-draw of every env of the group - episode counter and setpoint loaded, the two Philox blocks, the sampler, the new episode's
+// first observation (reset_draw + reset_apply: ~250 VALU instructions, a pure function of (seed, global env id, episode, setpoint)) -
+// and leaves the result in LDS.  It runs beside the env wave's plant loop on another SIMD of the CU, so a finished env costs the env
+// wave a barrier and seventeen LDS reads instead of 0.6 us of lone-wave instruction issue (round 4: with termination on, some wave of
+// every launch holds a finished env, so every launch paid for the draw; tools/step_placement.py).  Same
+// functions on the same inputs: every row is bit-identical to the one-wave form.
+constexpr int RESETW_FIELDS = 17;       // N, E, psi | o[0..8] | pt[0..2] | sin psi, cos psi
+
+template <int MODE>
+__device__ __forceinline__ void reset_wave(const StepArgs& a, float* lds, int lane, int blk)
+{
+    const int n = a.n;
+    const int i = blk * 64 + lane;
+    const int il = i < n ? i : n - 1;
+    const uint32_t ep = (uint32_t)a.episode[il];
+    const float4 rf = a.RF[il];
+    Env s;
+    s.refN = rf.x; s.refE = rf.y; s.refPsi = rf.z;
+    if (a.new_ref) { s.refN = a.new_ref[il]; s.refE = a.new_ref[(int64_t)n + il]; s.refPsi = a.new_ref[2 * (int64_t)n + il]; }   // ENV:131 precedes the reset
+    ResetDraw d;
+    reset_draw<MODE>(a, a.env_id_base + i, ep, d);
+    float o[9];
+    reset_apply<MODE>(a, s, d, o);
+    lds[0 * 64 + lane] = s.N; lds[1 * 64 + lane] = s.E; lds[2 * 64 + lane] = s.psi;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) lds[(3 + k) * 64 + lane] = o[k];
+    lds[12 * 64 + lane] = s.pt[0]; lds[13 * 64 + lane] = s.pt[1]; lds[14 * 64 + lane] = s.pt[2];
+    lds[15 * 64 + lane] = s.sn; lds[16 * 64 + lane] = s.cs;
+}
+
+template <int MODE>
+__device__ __forceinline__ void reset_from_lds(const float* lds, int lane, Env& s, float o_new[9])
+{
+    s.N = lds[0 * 64 + lane]; s.E = lds[1 * 64 + lane]; s.psi = lds[2 * 64 + lane];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o_new[k] = lds[(3 + k) * 64 + lane];
+    s.u = o_new[3]; s.v = o_new[4]; s.r = o_new[5];
+    s.pt[0] = lds[12 * 64 + lane]; s.pt[1] = lds[13 * 64 + lane]; s.pt[2] = lds[14 * 64 + lane];
+    default_angles<MODE>(s.ang[0], s.ang[1], s.ang[2]);
+    s.steps = 0;
+    s.sn = lds[15 * 64 + lane]; s.cs = lds[16 * 64 + lane];
+}
+
+template <int MODE, bool EXT, bool PER_CLASS, bool RESETW = false>
+__global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(const StepArgs a)
 {
     constexpr int A = ModeTraits<MODE>::A;
     constexpr int OD = EXT ? 9 : 6;
+    static_assert(!RESETW || BLOCK == 64, "the reset wave pairs with ONE env wave");
     __shared__ float lds_io[BLOCK * 9];
     __shared__ float lds_cls[PER_CLASS ? VD_COUNT * MAX_CLASSES : 1];
+    __shared__ float lds_rst[RESETW ? RESETW_FIELDS * 64 : 1];
 
+    if (RESETW && threadIdx.x >= BLOCK) {
+        reset_wave<MODE>(a, lds_rst, threadIdx.x - BLOCK, blockIdx.x);
+        __syncthreads();
+        return;
+    }
     const int tid = threadIdx.x;
     const int i = blockIdx.x * BLOCK + tid;
     const int n = a.n;
@@ -110,6 +161,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const StepArgs a)
     for (int k = 0; k < 9; ++k) o_next[k] = out.o[k];
 
     // ---- auto-reset (divergent, rare): the batched form of ppo.py:305-322 -------------------------
+    if (RESETW) __syncthreads();        // the reset wave's results are in LDS (it finished long ago: ~250 instructions against ~1 000)
     if (a.auto_reset && out.d != 0u && live) {
         if (a.final_obs) {
             // scattered 36-byte rows, only from lanes that finished an episode
@@ -121,7 +173,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const StepArgs a)
         }
         const uint32_t ep = (uint32_t)a.episode[i];
         a.episode[i] = (int)(ep + 1u);
-        env_auto_reset<MODE>(a, s, a.env_id_base + i, ep, o_next);
+        if (RESETW) reset_from_lds<MODE>(lds_rst, tid, s, o_next);
+        else env_auto_reset<MODE>(a, s, a.env_id_base + i, ep, o_next);
         rf_dirty = true;
     }
 
@@ -313,6 +366,9 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(const StepArgs a, const ui
         rf.w = ab;
         if (ref) { rf.x = ref[i]; rf.y = ref[(int64_t)n + i]; rf.z = ref[2 * (int64_t)n + i]; }
         a.S0[i] = s0; a.S1[i] = s1; a.S2[i] = s2; a.RF[i] = rf;
+        // the lagged thrust columns a closed-loop launch starts from (PolicyArgs.use_lag): a new episode's observation carries the
+        // reset's own previous thrust (ENV:190,196-205) - written per env, so that a MASKED reset leaves the other envs' lag alone
+        a.S3[i] = make_float4(pt[0] * 0.01f, pt[1] * 0.01f, pt[2] * 0.01f, 0.0f);
     }
     if (a.obs) {
         const float pt[3] = {s2.x, s2.y, s2.z};
@@ -581,9 +637,21 @@ __device__ double g_sum_partials[2 * SUM_MAXGRID];
 using namespace dpenv;
 
 template <int MODE>
-static hipError_t launch_step_mode(const StepArgs& a, bool ext, bool per_class, hipStream_t s)
+static hipError_t launch_step_mode(const StepArgs& a, bool ext, bool per_class, bool reset_wave, hipStream_t s)
 {
     const dim3 grid((a.n + BLOCK - 1) / BLOCK), block(BLOCK);
+    if (a.auto_reset && BLOCK == 64 && reset_wave) {
+        // auto-reset on: a second wave per workgroup prepares the re-draws beside the plant loop (RESETW above)
+        const dim3 block2(2 * BLOCK);
+        if (ext) {
+            if (per_class) hipLaunchKernelGGL((step_kernel<MODE, true, true, BLOCK == 64>), grid, block2, 0, s, a);
+            else hipLaunchKernelGGL((step_kernel<MODE, true, false, BLOCK == 64>), grid, block2, 0, s, a);
+        } else {
+            if (per_class) hipLaunchKernelGGL((step_kernel<MODE, false, true, BLOCK == 64>), grid, block2, 0, s, a);
+            else hipLaunchKernelGGL((step_kernel<MODE, false, false, BLOCK == 64>), grid, block2, 0, s, a);
+        }
+        return hipGetLastError();
+    }
     if (ext) {
         if (per_class) hipLaunchKernelGGL((step_kernel<MODE, true, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((step_kernel<MODE, true, false>), grid, block, 0, s, a);
@@ -601,14 +669,14 @@ extern "C" int dpenv_debug_set_step_trace(void* p)      // device buffer of STEP
 }
 #endif
 
-extern "C" hipError_t dpenv_dev_launch_step(const StepArgs* a, int mode, int ext, int per_class, hipStream_t s)
+extern "C" hipError_t dpenv_dev_launch_step(const StepArgs* a, int mode, int ext, int per_class, int reset_wave, hipStream_t s)
 {
     switch (mode) {
-    case MODE_FULL: return launch_step_mode<MODE_FULL>(*a, ext, per_class, s);
-    case MODE_SIMPLE: return launch_step_mode<MODE_SIMPLE>(*a, ext, per_class, s);
-    case MODE_LIMITED: return launch_step_mode<MODE_LIMITED>(*a, ext, per_class, s);
-    case MODE_FINAL_WRAP: return launch_step_mode<MODE_FINAL_WRAP>(*a, ext, per_class, s);
-    case MODE_FINAL_CONT: return launch_step_mode<MODE_FINAL_CONT>(*a, ext, per_class, s);
+    case MODE_FULL: return launch_step_mode<MODE_FULL>(*a, ext, per_class, reset_wave != 0, s);
+    case MODE_SIMPLE: return launch_step_mode<MODE_SIMPLE>(*a, ext, per_class, reset_wave != 0, s);
+    case MODE_LIMITED: return launch_step_mode<MODE_LIMITED>(*a, ext, per_class, reset_wave != 0, s);
+    case MODE_FINAL_WRAP: return launch_step_mode<MODE_FINAL_WRAP>(*a, ext, per_class, reset_wave != 0, s);
+    case MODE_FINAL_CONT: return launch_step_mode<MODE_FINAL_CONT>(*a, ext, per_class, reset_wave != 0, s);
     }
     return hipErrorInvalidValue;
 }

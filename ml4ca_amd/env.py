@@ -87,7 +87,7 @@ class BatchedRevoltEnv(object):
                  wrap_mode='reference', seed=0, env_id_base=0, obs_dtype='float32', current=False,
                  vessel_params=None, layout='aos', reset_fraction=0.8, time_limit=True, hold_plant=False,
                  current_drift=False, current_tau=100.0, current_sigma_v=0.02, current_sigma_beta=5.0 * math.pi / 180.0,
-                 n_steps=None, reset_acts=False):
+                 n_steps=None, reset_acts=False, step_one_wave=False):
         torch = _torch()
         if not torch.cuda.is_available():
             raise RuntimeError('BatchedRevoltEnv needs a ROCm device: the env.step path is a HIP kernel and has no CPU fallback')
@@ -146,6 +146,7 @@ class BatchedRevoltEnv(object):
         cfg.current_sigma_v = float(current_sigma_v)
         cfg.current_sigma_beta = float(current_sigma_beta)
         cfg.reset_acts = int(self.reset_actions)                     # drawn inside the reset kernels, ENV:179-188
+        cfg.step_one_wave = int(bool(step_one_wave))                 # A/B switch: dpenv_step's re-draw on the env wave (dpenv.h)
         self.cfg = cfg
         self.layout = layout
         self.auto_reset = bool(auto_reset)
@@ -331,8 +332,9 @@ class BatchedRevoltEnv(object):
 
     def get_obs_thrust(self):
         """float32 [n, 4]: thrust columns of the observation the last closed-loop launch ended with (a mid-episode checkpoint needs
-        them: the observation lags the stored thrust command by one step, customEnv.py:196-205,126), or None if the next launch would
-        start from the state block alone (after reset / step / set_state)."""
+        them: the observation lags the stored thrust command by one step, customEnv.py:196-205,126); after a full reset the new
+        episodes' own previous thrust / 100; None if the next launch would start from the state block alone (after step / rollout /
+        set_state, or a masked reset of a handle whose columns were not valid)."""
         torch = _torch()
         t = torch.empty((self.n_envs, 4), dtype=torch.float32, device=self.device)
         rc = self.lib.dpenv_get_obs_thrust(self._h, self._ptr(t), self._stream())

@@ -593,6 +593,59 @@ def test_rollout_with_auto_reset_tracks_oracle():
     assert n_done > 3 * n      # every env went through >= 3 episodes (time limit 20)
 
 
+@pytest.mark.parametrize('mode,ext,n,extra', [
+    ('final_cont', True, 1000 + 13, {}),
+    ('final_cont', True, 64 * 40, {'reset_acts': True, 'current': True, 'current_drift': True}),
+    ('final_wrap', False, 333, {'reset_acts': True}),
+    ('limited', True, 129, {}),
+    ('simple', False, 64, {}),
+    ('full', True, 500, {'classes': 3}),
+])
+def test_step_reset_wave_is_bit_identical_to_the_one_wave_form(mode, ext, n, extra):
+    """dpenv_step with auto_reset on launches a second wave per 64 envs that prepares the re-draw of finished envs beside the plant
+    loop (round 4, step_kernel<.., RESETW>); config.step_one_wave keeps the draw on the env wave.  Same functions on the same
+    inputs: every observation, reward, done byte, final observation and the state block are bit-identical over 120 steps in which
+    every env is re-drawn several times (time limit 9), with late setpoints handed to the very steps that reset, reset_acts,
+    drifting current, vessel classes and a ragged last workgroup."""
+    import ml4ca_amd
+    torch = torch_()
+    variant, cont = H.MODES[mode]
+    extra = dict(extra)
+    k_classes = extra.pop('classes', 0)
+    vp = None
+    if k_classes:
+        base = np.array(ml4ca_amd.default_vessel(), np.float32)
+        vp = np.tile(base, (k_classes, 1))
+        vp[:, 0:4] *= (1.0 + 0.03 * np.arange(k_classes, dtype=np.float32))[:, None]
+    envs = []
+    for one_wave in (False, True):
+        e = ml4ca_amd.BatchedRevoltEnv(n, variant=variant, extended_state=ext, cont_ang=cont, device='cuda:0', auto_reset=True, terminate=True,
+                                       max_ep_len=9 * 20, seed=11, env_id_base=7000, vessel_params=vp, step_one_wave=one_wave, **extra)
+        if k_classes:
+            e.set_vessel_class((torch.arange(n, device=e.device) % k_classes).to(torch.int32))
+        if extra.get('current'):
+            e.set_current(torch.full((n,), 0.2, device=e.device), torch.full((n,), 2.3, device=e.device))
+        envs.append(e)
+    assert envs[0].max_ep_len == 9
+    g = torch.Generator(device='cuda:0').manual_seed(3)
+    o0 = [e.reset() for e in envs]
+    assert torch.equal(o0[0], o0[1])
+    fin = [torch.full((n, envs[0].num_states), -7.0, device='cuda:0') for _ in envs]
+    n_done = 0
+    for t in range(120):
+        act = torch.randn((n, envs[0].num_actions), generator=g, device='cuda:0') * 0.8
+        ref = torch.randn((3, n), generator=g, device='cuda:0') if t % 4 == 0 else None      # 9 and 4 are coprime: refs meet resets
+        outs = [e.step(act, new_ref=ref, final_obs=f) for e, f in zip(envs, fin)]
+        for a, b in zip(outs[0][:3], outs[1][:3]):
+            assert torch.equal(a, b), t
+        assert torch.equal(fin[0], fin[1])
+        n_done += int(outs[0][2].ne(0).sum())
+    assert n_done >= 12 * n
+    s0, c0 = envs[0].get_state()
+    s1, c1 = envs[1].get_state()
+    assert torch.equal(s0, s1) and torch.equal(c0, c1)
+
+
 # --------------------------------------------------------------------------------------------
 # properties at full size (BASELINE.json: 65 536 envs; 8 x 32 768 shards)
 # --------------------------------------------------------------------------------------------

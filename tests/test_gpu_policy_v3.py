@@ -293,7 +293,9 @@ def test_checkpoint_with_draw_counters_reproduces_sampled_rollouts():
         envB.set_current(vc, beta, present_only=True)             # the drifted values of the checkpoint
         ac.upload(envB, precision='f32_actor')
         envB.reset()
-        assert envB.get_obs_thrust() is None                      # nothing to continue after a reset
+        lag0 = envB.get_obs_thrust()                              # a FULL reset writes every env's columns: the new episode's own previous thrust / 100
+        stB, _ = envB.get_state()
+        assert lag0 is not None and torch.equal(lag0[:, 0:3], stB[9:12].T.contiguous() * 0.01)
         envB.set_state(st, ctr)
         envB.set_obs_thrust(lag)                                  # the observation lags the stored thrust command by one step
         if with_counters:
@@ -334,6 +336,78 @@ def test_upload_does_not_disturb_a_launch_in_flight_on_another_stream():
     acs[0].upload(env, precision='f16')
     mu1, _ = policy_forward(env, obs)
     assert torch.equal(mu1, ref['act'][0]) and not torch.equal(mu3, mu1)
+
+
+def test_captured_rollout_sees_every_eager_upload():
+    """a rollout recorded into a HIP graph has the weight image's address baked in.  With two alternating images only
+    every second eager upload reached the replays (the others ran stale weights, silently).  From the capture on, uploads go in place
+    into the image the graph reads: the PPO pattern - upload each epoch, replay the rollout graph - for three consecutive uploads."""
+    from ml4ca_amd.policy import policy_rollout
+    torch = torch_()
+    n, T = 4096, 12
+    env, _ = H.make_pair('final_cont', n, auto_reset=True, seed=9)
+    env2, _ = H.make_pair('final_cont', n, auto_reset=True, seed=9)
+    acs = [make_ac(9, 7, (80, 80, 80), seed=s_, device=env.device) for s_ in (1, 2, 3, 4)]
+    acs[0].upload(env, precision='f32_actor')
+    env.reset(); env2.reset()
+    st, ctr = env.get_state()
+    out = policy_rollout(env, T, sample=False)                 # allocates the rows; also warms the launch path before capture
+    env.set_state(st, ctr)
+    side = torch.cuda.Stream(device=env.device)
+    side.wait_stream(torch.cuda.current_stream(env.device))
+    with torch.cuda.stream(side):
+        policy_rollout(env, T, sample=False, out=out)
+    torch.cuda.current_stream(env.device).wait_stream(side)
+    torch.cuda.synchronize()
+    env.set_state(st, ctr)                                     # as before every replay: the launch form (start from the state block) is baked in too
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        policy_rollout(env, T, sample=False, out=out)
+    for k, ac in enumerate(acs[1:] + acs[:1]):                 # four uploads in a row, each followed by one replay
+        ac.upload(env, precision='f32_actor')                   # eager, on the current stream: the stream the graph is replayed on
+        env.set_state(st, ctr)
+        g.replay()
+        torch.cuda.synchronize()
+        ac.upload(env2, precision='f32_actor')
+        env2.set_state(st, ctr)
+        want = policy_rollout(env2, T, sample=False)
+        for key in ('obs', 'act', 'val', 'rew', 'logp'):
+            assert torch.equal(out[key], want[key]), (k, key)
+    # eager launches after the capture read the same (pinned) image and see the latest upload too
+    env.set_state(st, ctr)
+    eager = policy_rollout(env, T, sample=False)
+    assert torch.equal(eager['act'], want['act'])
+
+
+def test_upload_waits_for_readers_on_two_streams():
+    """one event per image, re-recorded by whoever read last - a long rollout on stream A followed by a short
+    forward on stream B left the event covering B alone, and the second-next upload repacked the image under A's kernel.  The reader on
+    B now chains behind the event as it stands.  A 60-step launch on A, a forward on B, then two uploads: A's rows are those of the
+    weights it was given."""
+    from ml4ca_amd.policy import policy_forward, policy_rollout
+    torch = torch_()
+    n, T = 65536, 60
+    env, _ = H.make_pair('final_cont', n, auto_reset=True, seed=5)
+    acs = [make_ac(9, 7, (80, 80, 80), seed=s_, device=env.device) for s_ in (1, 2, 3)]
+    acs[0].upload(env, precision='f16')
+    env.reset()
+    st, ctr = env.get_state()
+    ref = policy_rollout(env, T, sample=False)
+    obs = ref['obs'][0].float().contiguous()
+    torch.cuda.synchronize()
+    env.set_state(st, ctr)
+    sa, sb = torch.cuda.Stream(device=env.device), torch.cuda.Stream(device=env.device)
+    sa.wait_stream(torch.cuda.current_stream(env.device)); sb.wait_stream(torch.cuda.current_stream(env.device))
+    with torch.cuda.stream(sa):
+        out = policy_rollout(env, T, sample=False)             # long reader on A
+    with torch.cuda.stream(sb):
+        mu_b, _ = policy_forward(env, obs[:256].contiguous())    # short reader on B: re-records the image's event
+    acs[1].upload(env, precision='f16')                         # other image
+    acs[2].upload(env, precision='f16')                         # reuses the image A is still reading: must wait for A AND B
+    torch.cuda.synchronize()
+    for k in ('obs', 'act', 'val', 'rew'):
+        assert torch.equal(out[k], ref[k]), k
+    assert torch.equal(mu_b, ref['act'][0][:256])
 
 
 @pytest.mark.parametrize('changes', [False, True])

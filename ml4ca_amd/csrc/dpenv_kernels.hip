@@ -47,7 +47,7 @@ constexpr int STEP_TRACE_RING = 8;
 // wave a barrier and seventeen LDS reads instead of 0.6 us of lone-wave instruction issue (round 4: with termination on, some wave of
 // every launch holds a finished env, so every launch paid for the draw; tools/step_placement.py).  Same
 // functions on the same inputs: every row is bit-identical to the one-wave form.
-constexpr int RESETW_FIELDS = 17;       // N, E, psi | o[0..8] | pt[0..2] | sin psi, cos psi
+constexpr int RESETW_FIELDS = 18;       // N, E, psi | o[0..8] | pt[0..2] | sin psi, cos psi | episode counter (bits)
 
 template <int MODE>
 __device__ __forceinline__ void reset_wave(const StepArgs& a, float* lds, int lane, int blk)
@@ -69,6 +69,7 @@ __device__ __forceinline__ void reset_wave(const StepArgs& a, float* lds, int la
     for (int k = 0; k < 9; ++k) lds[(3 + k) * 64 + lane] = o[k];
     lds[12 * 64 + lane] = s.pt[0]; lds[13 * 64 + lane] = s.pt[1]; lds[14 * 64 + lane] = s.pt[2];
     lds[15 * 64 + lane] = s.sn; lds[16 * 64 + lane] = s.cs;
+    lds[17 * 64 + lane] = __uint_as_float(ep);      // the env wave only has to store ep + 1: no load on its tail
 }
 
 template <int MODE>
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(const 
                 else ((float*)a.final_obs)[idx] = out.o[k];
             }
         }
-        const uint32_t ep = (uint32_t)a.episode[i];
+        const uint32_t ep = RESETW ? __float_as_uint(lds_rst[17 * 64 + tid]) : (uint32_t)a.episode[i];
         a.episode[i] = (int)(ep + 1u);
         if (RESETW) reset_from_lds<MODE>(lds_rst, tid, s, o_next);
         else env_auto_reset<MODE>(a, s, a.env_id_base + i, ep, o_next);

@@ -620,7 +620,7 @@ def test_step_reset_wave_is_bit_identical_to_the_one_wave_form(mode, ext, n, ext
     envs = []
     for one_wave in (False, True):
         e = ml4ca_amd.BatchedRevoltEnv(n, variant=variant, extended_state=ext, cont_ang=cont, device='cuda:0', auto_reset=True, terminate=True,
-                                       max_ep_len=9 * 20, seed=11, env_id_base=7000, vessel_params=vp, step_one_wave=one_wave, **extra)
+                                       max_ep_len=18, seed=11, env_id_base=7000, vessel_params=vp, step_one_wave=one_wave, **extra)
         if k_classes:
             e.set_vessel_class((torch.arange(n, device=e.device) % k_classes).to(torch.int32))
         if extra.get('current'):

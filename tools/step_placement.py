@@ -93,12 +93,13 @@ def main():
     block = int(os.environ.get('DPENV_TRACE_BLOCK', '64'))
     out = {'lib': os.environ.get('DPENV_LIB', 'product'), 'trace': trace, 'rows': []}
     print('library: %s   trace records: %s' % (out['lib'], trace))
-    for wl in (['headline', 'config2'] if args.workload == 'both' else [args.workload]):
+    for wl in (['headline', 'config2', 'config2_one_wave'] if args.workload == 'both' else args.workload.split(',')):
         for n in [int(x) for x in args.sizes.split(',')]:
             if wl == 'headline':
                 env = ml4ca_amd.BatchedRevoltEnv(n, device=dev, terminate=False, time_limit=False, seed=1)
             else:
-                env = ml4ca_amd.BatchedRevoltEnv(n, device=dev, terminate=True, auto_reset=True, seed=4)
+                # config 2 / 4 workload: termination and auto-reset on; `_one_wave`: the re-draw on the env wave (config.step_one_wave)
+                env = ml4ca_amd.BatchedRevoltEnv(n, device=dev, terminate=True, auto_reset=True, seed=4, step_one_wave=wl.endswith('one_wave'))
             g = torch.Generator(device=dev)
             g.manual_seed(7)
             actions = torch.randn((50, n, 7), generator=g, device=dev) * 0.6065
@@ -128,7 +129,7 @@ def main():
                 torch.cuda.synchronize(dev)
                 ts.append(e0.elapsed_time(e1) * 1e3 / args.steps)
             row = {'workload': wl, 'envs': n, 'us_per_step_median': float(np.median(ts)), 'us_per_step_min': float(min(ts))}
-            line = '%-8s envs %6d  step %6.3f us (min %6.3f)' % (wl, n, row['us_per_step_median'], row['us_per_step_min'])
+            line = '%-16s envs %6d  step %6.3f us (min %6.3f)' % (wl, n, row['us_per_step_median'], row['us_per_step_min'])
             if trace and wl == 'headline':
                 nwg = (n + block - 1) // block
                 buf = torch.zeros((RING, nwg, 4), dtype=torch.int32, device=dev)

@@ -77,7 +77,8 @@ def policy_kernel_name(env, prec):
     form, epw = policy_launch_form(env)
     mode, ext = env_kernel_args(env)
     if form == 'two_wave':
-        return 'dpenv::policy_rollout_ws_kernel<%d,%s,KA=5,2,%s,GROUPS=%d>' % (mode, ext, {'f16': 'F16', 'f32': 'F32', 'f32_actor': 'F32_ACTOR'}[prec], epw // 64)
+        roles = 3 if (epw == 128 and prec != 'f16') else 2       # dpenv_policy_ws.h: a critic wave of its own for the split arithmetics in the 128-env geometry
+        return 'dpenv::policy_rollout_ws_kernel<%d,%s,KA=5,ROLES=%d,%s,GROUPS=%d>' % (mode, ext, roles, {'f16': 'F16', 'f32': 'F32', 'f32_actor': 'F32_ACTOR'}[prec], epw // 64)
     return 'dpenv::policy_rollout_%skernel<%d,%s,...>' % ('' if prec == 'f16' else 'x_', mode, ext)
 
 

@@ -133,6 +133,8 @@ def main():
             v_opt.step()
         with torch.no_grad():
             ac.log_std.clamp_(-4.0, 1.0)
+        if gather:
+            D.assert_params_in_step(ac.parameters())                            # replicated updates: no collective keeps them equal, so check
         ac.upload(env, precision=args.precision)
         torch.cuda.synchronize()
         t_upd = time.perf_counter() - t1

@@ -3,6 +3,7 @@
 // (PREC_F32, PREC_F32_ACTOR: one translation unit each, they take minutes to compile).
 #ifndef DPENV_POLICY_WS_H
 #define DPENV_POLICY_WS_H
+#include <type_traits>
 #include "dpenv_policy_dev.h"
 
 namespace dpenv {
@@ -98,8 +99,15 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
 #ifndef DPENV_WS_ECRITIC
 #define DPENV_WS_ECRITIC 1
 #endif
-    constexpr bool ECRITIC = PREC == PREC_F32 && GROUPS == 2 && (DPENV_WS_ECRITIC != 0);
-    static_assert(ROLES == 2, "an env wave and a network wave per 64 envs (the three-wave forms of round 2 were measured, rejected and removed: DESIGN.md section 4)");
+    constexpr bool ECRITIC = PREC == PREC_F32 && GROUPS == 2 && ROLES == 2 && (DPENV_WS_ECRITIC != 0);
+    // ROLES = 3 (round 4, 128-env workgroups only): a CRITIC WAVE of its own per 64 envs - six waves on the four SIMDs of a CU, in the
+    // order E0 E1 A0 A1 C0 C1, so that the actor waves keep a SIMD each and a critic wave shares one with its env wave (matrix work beside
+    // vector work, the pairing that nets; MI355X_MICROARCH.md "Two waves per SIMD").  V(o_t) is then evaluated while the actor wave
+    // evaluates mu_t, by a wave whose registers hold nothing but the evaluation (the env wave's own copy - ECRITIC above - is compiled
+    // around ~100 registers of env state).  The observation mailbox gets a second slot (by step parity): the critic may still be reading
+    // o_t when the env wave posts o_t+1.  (Round 2's three-wave forms were 256-env workgroups with THREE waves on every SIMD: 168
+    // registers per wave, spills, three streams per issue port - measured slower and removed.  Here no SIMD holds more than two.)
+    static_assert(ROLES == 2 || (ROLES == 3 && GROUPS == 2), "an env wave and a network wave per 64 envs; a critic wave of its own only with a SIMD per wave to spare");
     static_assert(GROUPS == 4 || GROUPS == 2, "workgroups of 256 or 128 envs");
     extern __shared__ uint4 lds_dyn[];
     uint4* lds_w = lds_dyn;
@@ -117,8 +125,8 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
     const int role = wave / GROUPS;                 // 0 = env wave, 1 = network wave
 #endif
     const int g = wave % GROUPS;
-    constexpr int OBS_SLOTS = 1;
-    float* grp = (float*)lds_dyn + img_floats + g * (STAGE ? WS_GROUP_FLOATS : WS_GROUP_FLOATS_X);
+    constexpr int OBS_SLOTS = ROLES == 3 ? 2 : 1;
+    float* grp = (float*)lds_dyn + img_floats + g * ((STAGE ? WS_GROUP_FLOATS : WS_GROUP_FLOATS_X) + (OBS_SLOTS - 1) * 64 * 9);
     float* lds_io = grp;                         // E-wave row staging (STAGE only)
     float* obs_mb = grp + (STAGE ? 64 * 9 : 0);  // [OBS_SLOTS][64][9] o_t (by step parity): one row of 9 per lane (stride 9 is conflict-free)
     float* pre_mb = obs_mb + 64 * 9 * OBS_SLOTS;   // [2][64][9] pre-reset observation of a cut episode, by step parity
@@ -166,10 +174,17 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
 #ifndef DPENV_WS_M_PRIO
 #define DPENV_WS_M_PRIO 3
 #endif
+#ifndef DPENV_WS_C_PRIO
+#define DPENV_WS_C_PRIO 1        // the critic wave of the three-role form shares its SIMD with the env wave; same-call A/B at 32 768 envs, all
+#endif                           // exact: priority 0 8.4 us per step, 1 8.05, 2 7.85-8.1, 3 8.1 (profiles/r04_critic_wave.txt)
 #ifndef DPENV_WS_NO_SETPRIO
-        __builtin_amdgcn_s_setprio(DPENV_WS_M_PRIO);
+        if (ROLES == 3 && role == 2) __builtin_amdgcn_s_setprio(DPENV_WS_C_PRIO);
+        else __builtin_amdgcn_s_setprio(DPENV_WS_M_PRIO);
 #endif
-        constexpr bool do_actor = true, do_critic = !ECRITIC;
+        // one copy of the loop per role, so that a wave's registers hold only what ITS evaluation needs (with the roles as run-time flags
+        // the three-role kernel kept the union of both and spilled)
+        auto net_wave = [&](auto ACT_, auto CRI_) __attribute__((always_inline)) {
+        constexpr bool do_actor = decltype(ACT_)::value, do_critic = decltype(CRI_)::value;
         half8 in0, in1;                                                      // PREC_F16: first-layer fragments of o_t
         SplitIn inx;                                                         // SPLIT: their high and low parts
         float o[9], outv[8];
@@ -257,6 +272,13 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
             (pa.logp + (int64_t)5 * n)[(unsigned)i] = (float)t_act; (pa.logp + (int64_t)6 * n)[(unsigned)i] = (float)t_cri;
         }
 #endif
+        };
+        if constexpr (ROLES == 3) {
+            if (role == 1) net_wave(std::true_type{}, std::false_type{});
+            else net_wave(std::false_type{}, std::true_type{});
+        } else {
+            net_wave(std::true_type{}, std::integral_constant<bool, !ECRITIC>{});
+        }
         return;
     }
 
@@ -560,13 +582,21 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
 namespace dpenv_ws_launch {
 using namespace dpenv;
 
+// which arithmetics get the critic wave (ROLES = 3) in the 128-env geometry: bit 0 f16, bit 1 all exact, bit 2 exact actor.  Measured
+// (same call, bit-identical rows, profiles/r04_critic_wave.txt; 32 768 / 8 192 envs): all exact 9.43 -> 7.85 / 9.24 -> 7.30 us per step, exact
+// actor 7.4-7.7 -> 7.3-7.45 / 7.23 -> 7.01; f16 5.20 -> 5.50 / 4.76 -> 5.03 (its env wave needs more than the 256 registers two waves on a
+// SIMD leave: 116 B of scratch) - so the two split arithmetics get it, f16 keeps two roles.
+#ifndef DPENV_WS_CRITIC_WAVE
+#define DPENV_WS_CRITIC_WAVE 6
+#endif
 template <int MODE, bool EXT, int KA, int PREC, int GROUPS>
 static hipError_t go(const StepArgs& a, const PolicyArgs& pa, hipStream_t s)
 {
-    constexpr int ROLES = 2;
+    constexpr int ROLES = (GROUPS == 2 && ((DPENV_WS_CRITIC_WAVE >> PREC) & 1)) ? 3 : 2;
     const dim3 grid((a.n + 64 * GROUPS - 1) / (64 * GROUPS));
     const size_t lds = (size_t)ws_images(PREC) * pa.nent * 16 + (size_t)2 * pa.nblk * 32 * 4 +
-                       (size_t)GROUPS * ((PREC == PREC_F16 || (PREC == PREC_F32_ACTOR && DPENV_WS_STAGE_ACTOR)) ? WS_GROUP_FLOATS : WS_GROUP_FLOATS_X) * 4;
+                       (size_t)GROUPS * (((PREC == PREC_F16 || (PREC == PREC_F32_ACTOR && DPENV_WS_STAGE_ACTOR)) ? WS_GROUP_FLOATS : WS_GROUP_FLOATS_X) +
+                                         (ROLES == 3 ? 64 * 9 : 0)) * 4;
     hipError_t e = hipFuncSetAttribute((const void*)policy_rollout_ws_kernel<MODE, EXT, KA, ROLES, PREC, GROUPS>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

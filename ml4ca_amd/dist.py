@@ -90,6 +90,27 @@ def average_gradients(params, group=None):
         off += n
 
 
+def assert_params_in_step(params, group=None, what='parameters'):
+    """Replicated updates (examples/train_ppo.py --exchange rollout: every rank computes the SAME update from the gathered batch, no
+    gradient or parameter collective) stay replicated only while every rank's arithmetic is bit-identical.  One 16-byte all-reduce
+    per epoch: the min and the max over ranks of a checksum of the parameter bits must agree; raises on the first epoch they do not
+    (a GEMM algorithm choice or a kl a few ulps apart flipping the early stop on one rank would otherwise go unnoticed for the rest of
+    the run)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    flat = torch.cat([p.detach().reshape(-1) for p in params]).contiguous()
+    bits = flat.view(torch.int32).to(torch.int64)
+    w = torch.arange(1, bits.numel() + 1, device=bits.device, dtype=torch.int64)
+    cs = ((bits * w).sum() % 2147483629).to(torch.float64)          # exact in float64; position-weighted so that swaps show
+    t = torch.stack([cs, -cs])
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)            # max(cs), max(-cs) = -min(cs)
+    if float(t[0]) != -float(t[1]):
+        raise RuntimeError('%s differ between ranks (checksums %.0f .. %.0f): the replicated update has diverged; use --exchange gradients '
+                           'or re-broadcast with dist.sync_params' % (what, -float(t[1]), float(t[0])))
+
+
 def sync_params(params, root=0, group=None):
     """sync_all_params / sync_params (mpi_tf.py:16-26): broadcast the root's parameters, as one flat buffer."""
     import torch

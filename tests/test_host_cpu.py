@@ -201,6 +201,58 @@ def test_two_rank_gloo_gather_matches_single_process_run():
     assert dp[0][0] == dp[1][0] and dp[0][1] == dp[1][1] == 1.5 and abs(dp[0][2] - 0.015) < 1e-9 and abs(dp[1][2] - 0.015) < 1e-9
 
 
+def _params_in_step_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from ml4ca_amd import dist as D
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(4)
+    params = [torch.randn((9, 80), generator=g), torch.randn(80, generator=g), torch.full((7,), -0.5)]
+    res = []
+    D.assert_params_in_step(params)                                   # equal on both ranks: passes
+    res.append('equal ok')
+    params[0][3, 5] += (1e-7 if rank == 1 else 0.0)                   # one ulp-sized difference on ONE rank
+    try:
+        D.assert_params_in_step(params)
+        res.append('missed')
+    except RuntimeError as e:
+        res.append('raised: ' + str(e)[:60])
+    a, b = params[1][2].clone(), params[1][7].clone()                 # a swap of two unequal entries keeps the plain sum: the weights catch it
+    if rank == 1:
+        params[0][3, 5] -= 1e-7
+        params[1][2], params[1][7] = b, a
+    else:
+        params[0][3, 5] += 0.0
+    try:
+        D.assert_params_in_step(params)
+        res.append('missed swap')
+    except RuntimeError:
+        res.append('raised swap')
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replicated_update_divergence_is_detected():
+    """ADVICE r03: examples/train_ppo.py --exchange rollout keeps the ranks' policies equal by computing the same update everywhere;
+    dist.assert_params_in_step is the per-epoch check that they still are (raises on EVERY rank, so nobody is left in a collective)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_params_in_step_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        assert got[r][0] == 'equal ok' and got[r][1].startswith('raised: parameters differ between ranks') and got[r][2] == 'raised swap', got
+
+
 def test_current_drift_is_a_stationary_gauss_markov_process():
     """Config 5's slowly varying current (build-defined): mean reversion to the set value, stationary std sigma,
     correlation time tau - checked on the oracle (the GPU kernel is checked against the oracle in -m gpu)."""

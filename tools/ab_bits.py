@@ -10,7 +10,7 @@ import torch
 import ml4ca_amd
 from ml4ca_amd.policy import ActorCritic, policy_rollout
 
-for n in (4096 + 37, 65536):
+for n in (4096 + 37, 32768, 65536):
     for prec in ('f16', 'f32_actor', 'f32'):
         env = ml4ca_amd.BatchedRevoltEnv(n, auto_reset=True, seed=3, max_ep_len=17)
         ActorCritic(9, 7, (80, 80, 80), seed=2, device=env.device).upload(env, precision=prec)

@@ -17,7 +17,30 @@ import subprocess
 import sys
 import tempfile
 
-OBJDUMP = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+
+
+def find_objdump():
+    """llvm-objdump of the ROCm install in use: $ROCM_PATH, the prefix `hipconfig --rocmpath` reports, /opt/rocm, then PATH"""
+    cands = []
+    if os.environ.get('ROCM_PATH'):
+        cands.append(os.path.join(os.environ['ROCM_PATH'], 'lib', 'llvm', 'bin', 'llvm-objdump'))
+    try:
+        root = subprocess.run(['hipconfig', '--rocmpath'], capture_output=True, text=True, timeout=20).stdout.strip()
+        if root:
+            cands.append(os.path.join(root, 'lib', 'llvm', 'bin', 'llvm-objdump'))
+    except Exception:
+        pass
+    cands.append('/opt/rocm/lib/llvm/bin/llvm-objdump')
+    for c in cands:
+        if os.path.exists(c):
+            return c
+    w = shutil.which('llvm-objdump')
+    if w:
+        return w
+    raise SystemExit('check_isa: no llvm-objdump found (ROCM_PATH, hipconfig --rocmpath, /opt/rocm, PATH)')
+
+
+OBJDUMP = find_objdump()
 
 
 def device_disassembly(lib):

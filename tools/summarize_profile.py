@@ -92,9 +92,14 @@ except Exception as e:
     out['bench_line'] = str(e)
 # the headline kernel's duration by launch form (round 4): what the tracer does to a dependent chain depends on how it is launched
 hd = {'what': 'step_kernel duration (End - Start timestamp of rocprofv3 --kernel-trace) by launch form, beside the HIP-event SPACING of back-to-back '
-              'launches that bench.py reports (spacing = duration + kernel boundary).  Eager launches are spaced by the host, so each dispatch\'s '
-              'timestamps are its own: that duration is the one to price the kernel with; the one-long-graph pass instruments every node of a '
-              '2 500-node graph and stretches kernel and spacing alike (its own bench line says so).'}
+              'dependent launches that bench.py reports, traced and untraced.  Three different clocks (profiles/LAB_NOTES.md, round 4): (1) the waves\' '
+              'own span, first wave in to last store issued, read with s_memrealtime inside a -DDPENV_STEP_TRACE build: 3.67 us at 65 536 envs '
+              '(profiles/r04_step_placement.txt); (2) the command processor\'s dispatch-to-completion interval that rocprofv3 reports: it adds the launch '
+              'ramp and the end-of-kernel cache write-back / completion signal, 5.3-6.1 us in EVERY launch form, eager included, and the tracer\'s own '
+              'per-dispatch signals space the launches out (bench spacing in the traced runs: 6.0-15 us); (3) the untraced spacing of back-to-back '
+              'launches, 5.05 us: shorter than (2) because, untraced, the processing of dispatch k + 1 overlaps the tail of kernel k.  roofline.frac of '
+              'the bench line uses (3), the only one of the three that is throughput; pricing the kernel by (2) (median of the 50-step-graph pass) '
+              'gives a fraction 5-6 % lower, by (1) 38 % higher.'}
 for form, sub, cmd in (('eager', 'kt_eager', 'bench.py --no-graph --steps 250 --warmup 50 --no-cpu-baseline --no-fused'),
                        ('graph_50_steps', 'kt_g50', 'bench.py --graph-steps 50 --steps 50 --warmup 50 --no-cpu-baseline --no-fused'),
                        ('one_long_graph', 'kt', 'bench.py --no-cpu-baseline')):
@@ -116,9 +121,10 @@ try:
     hd['untraced_spacing_us'] = out['bench_line']['roofline']['avg_launch_us']
     if 'eager' in hd:
         e = hd['eager']['avg_ns'] * 1e-3
-        hd['frac_by_eager_kernel_duration'] = 177 * 65536 / (e * 1e-6) / 8e12
         hd['frac_by_untraced_spacing'] = out['bench_line']['roofline']['frac']
-        hd['boundary_us'] = hd['untraced_spacing_us'] - e
+        for form in ('eager', 'graph_50_steps', 'one_long_graph'):
+            if form in hd:
+                hd['frac_by_rocprof_duration_' + form] = {'avg': 177 * 65536 / (hd[form]['avg_ns'] * 1e-9) / 8e12, 'median': 177 * 65536 / (hd[form]['median_ns'] * 1e-9) / 8e12}
 except Exception:
     pass
 out['headline_kernel_duration'] = hd
@@ -126,8 +132,10 @@ json.dump(out, open('%s/%s_summary.json' % (dst, tag), 'w'), indent=1)
 if 'step_kernel' in out['kernels'] and 'hbm_bytes_per_launch' in out['kernels']['step_kernel']:
     tl = {'n_envs': 65536, 'hbm_bytes_per_launch': out['kernels']['step_kernel']['hbm_bytes_per_launch'],
           'source': 'profiles/%s_summary.json' % tag, 'tag': tag}
-    if 'eager' in hd:
-        tl['step_kernel_duration_ns'] = {'avg': hd['eager']['avg_ns'], 'median': hd['eager']['median_ns'], 'min': hd['eager']['min_ns'],
-                                         'source': 'profiles/%s_summary.json headline_kernel_duration.eager (rocprofv3 --kernel-trace of the eager form, %d dispatches)' % (tag, hd['eager']['dispatches'])}
+    if 'graph_50_steps' in hd:
+        f_ = hd['graph_50_steps']
+        tl['step_kernel_duration_ns'] = {'avg': f_['avg_ns'], 'median': f_['median_ns'], 'min': f_['min_ns'],
+                                         'source': 'profiles/%s_summary.json headline_kernel_duration.graph_50_steps (rocprofv3 --kernel-trace, dispatch-to-completion '
+                                                   'interval of %d dispatches in 50-step graphs: launch ramp + waves + end-of-kernel write-back)' % (tag, f_['dispatches'])}
     json.dump(tl, open('%s/traffic_latest.json' % dst, 'w'))
 print(json.dumps({k: v for k, v in out['kernels'].items() if 'policy' in k or 'gae' in k}, indent=1)[:6000])

@@ -93,6 +93,15 @@ def _tensor(raw):
 
 def _attr(raw):
     a = _parse_proto(raw)
+    if 1 in a:                                   # AttrValue.ListValue {3: i (packed or repeated varints), 4: f, 2: s}
+        lv = _parse_proto(a[1][0])
+        if 3 in lv:
+            return _packed_varints(lv[3])
+        if 4 in lv:
+            return _packed_floats(lv[4], '<f', 4)
+        if 2 in lv:
+            return [_s(x) for x in lv[2]]
+        return []
     if 8 in a:
         return _tensor(a[8][0])
     if 4 in a:
@@ -272,8 +281,8 @@ def evaluate(nodes, fetches, feeds, variables, dtype=np.float64, rng_normal=None
         elif op == 'Sum':
             r = val(ins[0]).sum(axis=tuple(np.atleast_1d(val(ins[1])).tolist()), keepdims=bool(nd['attr'].get('keep_dims', False)))
         elif op == 'Squeeze':
-            dims = nd['attr'].get('squeeze_dims')
-            r = np.squeeze(val(ins[0]), axis=tuple(dims) if dims else (1 if val(ins[0]).ndim == 2 and val(ins[0]).shape[1] == 1 else None))
+            dims = nd['attr'].get('squeeze_dims')                 # list(int); empty = every dimension of size one
+            r = np.squeeze(val(ins[0]), axis=tuple(int(k) for k in dims) if dims else None)
         elif op == 'Shape':
             r = np.array(val(ins[0]).shape, np.int64)
         elif op == 'RandomStandardNormal':

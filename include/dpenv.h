@@ -117,9 +117,10 @@ typedef struct dpenv_config {
     int32_t reset_acts;      /* 1: an episode starts with previous thrust clip(100 * N(0, 0.1)) instead of zero (the reference's
                                 reset_acts constructor flag, customEnv.py:30,179-188); drawn in the kernel by every kind of reset,
                                 Philox keyed (seed; global env id, episode) like the pose sample */
-    int32_t step_one_wave;   /* 0 (default): with auto_reset on, dpenv_step launches a second wave per 64 envs that prepares the re-draw of
-                                finished envs beside the plant loop (same rows bit for bit).  1: keep the draw on
-                                the env wave - the A/B switch of tools/ and tests; was `reserved` (0) before round 4 */
+    int32_t step_one_wave;   /* 0 (default): dpenv_step with auto_reset on launches a second wave per 64 envs that prepares the re-draw of
+                                finished envs beside the plant loop, and dpenv_rollout runs an env wave and a row wave per 64 envs (same
+                                rows bit for bit).  1: the one-wave kernels - the A/B switch of tools/ and tests;
+                                was `reserved` (0) before round 4 */
 } dpenv_config;
 
 /* Optional outputs / inputs of one step beyond the Gym tuple.  All device pointers, any may be NULL. */

@@ -500,7 +500,7 @@ extern "C" int dpenv_rollout(dpenv_handle h, const dpenv_rollout_io* io, dpenv_s
     ra.T = io->T; ra.actions = io->actions; ra.obs = io->obs; ra.rew = io->reward; ra.done = io->done;
     ra.n_switch = io->n_switch; ra.refs = io->refs;
     for (int k = 0; k < io->n_switch; ++k) ra.switch_step[k] = io->switch_step[k];
-    HIP_TRY(h, dpenv_dev_launch_rollout(&a, &ra, h->mode, h->cfg.extended_state, h->n_classes > 1, (hipStream_t)s));
+    HIP_TRY(h, dpenv_dev_launch_rollout(&a, &ra, h->mode, h->cfg.extended_state, h->n_classes > 1, h->cfg.step_one_wave ? 0 : 1, (hipStream_t)s));
     h->lag_valid = false;
     return DPENV_OK;
 }

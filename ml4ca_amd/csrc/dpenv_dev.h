@@ -168,8 +168,8 @@ hipError_t dpenv_dev_launch_policy_forward(const dpenv::PolicyArgs* pa, int od, 
                                            float* v, int n, hipStream_t s);
 hipError_t dpenv_dev_launch_policy_rollout(const dpenv::StepArgs* a, const dpenv::PolicyArgs* pa, int mode, int ext,
                                            hipStream_t s);
-hipError_t dpenv_dev_launch_rollout(const dpenv::StepArgs* a, const dpenv::RolloutArgs* ra, int mode, int ext,
-                                    int per_class, hipStream_t s);
+hipError_t dpenv_dev_launch_rollout(const dpenv::StepArgs* a, const dpenv::RolloutArgs* ra, int mode, int ext, int per_class, int two_wave,
+                                    hipStream_t s);
 hipError_t dpenv_dev_launch_step(const dpenv::StepArgs* a, int mode, int ext, int per_class, int reset_wave, hipStream_t s);
 hipError_t dpenv_dev_launch_reset(const dpenv::StepArgs* a, int mode, int ext, const uint8_t* mask, const float* init,
                                   const float* ref, hipStream_t s);

@@ -459,11 +459,14 @@ struct Wrench {
 // heads directly, the angles themselves are only bookkeeping (next step's ang_prev) and reward (azimuth-rate penalty) - so a kernel
 // whose next observation is on a critical path takes them later with stern_angles() (env_step_finish); ang[1], ang[2] are left alone.
 template <int MODE, bool DEFER_ANG = false>
-__device__ __forceinline__ void env_decode(const Vessel& ve, float ang[3], const float* act, Wrench& w)
+__device__ __forceinline__ void env_decode_cmd(float ang[3], const float* act, float thr[3])
 {
-    w.thr[0] = clipf(act[0] * 100.0f, 100.0f);
-    w.thr[1] = clipf(act[1] * 100.0f, 100.0f);
-    w.thr[2] = clipf(act[2] * 100.0f, 100.0f);
+    // the COMMANDS of a step (thrust percent, azimuths): all the reward's penalties and the azimuth bookkeeping need; the force map
+    // (below) needs more.  Split out so that a wave that only keeps the books (rollout_ws_kernel's row wave) evaluates exactly these
+    // expressions and nothing else.
+    thr[0] = clipf(act[0] * 100.0f, 100.0f);
+    thr[1] = clipf(act[1] * 100.0f, 100.0f);
+    thr[2] = clipf(act[2] * 100.0f, 100.0f);
     if (MODE == MODE_FULL) {
         ang[0] = clipf(act[3] * kPi, kPi); ang[1] = clipf(act[4] * kPi, kPi); ang[2] = clipf(act[5] * kPi, kPi);
     } else if (MODE == MODE_LIMITED) {
@@ -477,6 +480,12 @@ __device__ __forceinline__ void env_decode(const Vessel& ve, float ang[3], const
         // ENV:227-235: atan2(sin_head, cos_head)/pi, then *pi and clip
         if (!DEFER_ANG) { ang[1] = clipf(atan2_lean(act[3], act[4]), kPi); ang[2] = clipf(atan2_lean(act[5], act[6]), kPi); }
     }
+}
+
+template <int MODE, bool DEFER_ANG = false>
+__device__ __forceinline__ void env_decode(const Vessel& ve, float ang[3], const float* act, Wrench& w)
+{
+    env_decode_cmd<MODE, DEFER_ANG>(ang, act, w.thr);
     if (MODE == MODE_FINAL_CONT) {
         // the azimuth is atan2 of the two heads, so its sine and cosine are the normalised heads themselves:
         // no sincos of the angle just computed ((0, 0) -> angle 0 -> (0, 1))

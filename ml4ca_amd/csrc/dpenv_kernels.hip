@@ -331,6 +331,257 @@ __global__ __launch_bounds__(RBLOCK) void rollout_kernel(const StepArgs a, const
 }
 
 // =============================================================================================
+//  fused rollout, two waves per 64 envs (round 4): an ENV wave and a ROW wave.
+//
+//  rollout_kernel above is bound by the instruction issue of ONE wave per SIMD: 910 VALU + the LDS transposes and row stores of every
+//  step in one stream (2.65 us per step at 65 536 envs).  About a sixth of that stream needs nothing the plant loop produces until
+//  the step is over, or nothing at all: the action row fetch and its transposition, the azimuth bookkeeping (two atan2), the reward,
+//  the observation / reward / done row stores, the re-draw of finished envs.  Here a 128-thread workgroup owns 64 envs with two waves:
+//      row wave (H)                                           env wave (E)
+//      act_t+2 row: global -> LDS mailbox, post               wait act_t; a_t from the mailbox
+//      wait post(t): o_t+1 (pre-reset), done bits              env_step_chain (decode, force map, plant, observation, termination)
+//      commands / azimuths of a_t, reward, rows of step t      re-draw of finished envs from the prepared record
+//      prepared re-draw record for the next episode            post o_t+1, done bits                       -> step t+1 at once
+//  E never waits for H on its way (H runs one step behind on the rows and two ahead on the actions); the hand-over is LDS mailboxes with
+//  sequence words (release / acquire at workgroup scope, no barrier in the loop).  Same device functions on the same values
+//  (env_decode_cmd, env_reward, reset_draw / reset_apply, env_step_chain): every row and the final state are bit-identical to
+//  rollout_kernel and to T single steps (tests).  config.step_one_wave keeps the one-wave kernel (A/B, tests).
+// =============================================================================================
+__device__ __forceinline__ void mb_post(int* p, int v, int lane)
+{
+    if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void mb_wait(int* p, int v)
+{
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < v)
+        __builtin_amdgcn_s_sleep(1);
+}
+
+constexpr int RW_REC = 18;              // re-draw record: N, E, psi | o[0..8] | pt[0..2] | sin psi, cos psi | (unused)
+template <int MODE, bool EXT, bool PER_CLASS>
+__global__ __launch_bounds__(128) void rollout_ws_kernel(const StepArgs a, const RolloutArgs ra)
+{
+    constexpr int A = ModeTraits<MODE>::A;
+    constexpr int OD = EXT ? 9 : 6;
+    __shared__ float act_mb[2][64 * 7];          // a_t rows by step parity, [lane * A + k]
+    __shared__ float post_mb[2][64 * 9];         // o_t+1 rows (pre-reset) by step parity, [lane * OD + k]: also the staged image of the row store
+    __shared__ uint32_t done_mb[2][64];
+    __shared__ float rec_mb[RW_REC * 64];        // the prepared re-draw, [field][lane]
+    __shared__ float ang_mb[2 * 64];             // stern azimuths in force after the last step (MODE_FINAL_CONT: the row wave keeps them)
+    __shared__ int seq[8];                       // [0] actions posted, [1] steps posted, [2] re-draw record version, [3] final
+    __shared__ float lds_cls[PER_CLASS ? VD_COUNT * MAX_CLASSES : 1];
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 64 + lane;
+    const int n = a.n;
+    const bool live = i < n;
+    const int il = live ? i : n - 1;
+    if (threadIdx.x < 8) seq[threadIdx.x] = 0;
+    int cls = 0;
+    if (PER_CLASS) {
+        cls = a.class_id[il];
+        for (int k = threadIdx.x; k < VD_COUNT * a.n_classes; k += 128) {
+            const int c = k / VD_COUNT, p = k - c * VD_COUNT;
+            lds_cls[p * a.n_classes + c] = a.class_tab[k];
+        }
+    }
+    __syncthreads();
+    const int64_t step_stride_act = (int64_t)n * A;
+    const int64_t step_stride_obs = (int64_t)n * OD;
+    const int64_t blk_act = (int64_t)blockIdx.x * (64 * A);
+    const int64_t blk_obs = (int64_t)blockIdx.x * (64 * OD);
+    const bool resets = a.auto_reset != 0;
+
+    if (wave == 1) {
+        // ------------------------------------------------------------------------------------------------ row wave
+        float pt[3], ang[3], refN, refE, refPsi;
+        {
+            const float4 s1 = a.S1[il], s2 = a.S2[il], rf = a.RF[il];
+            pt[0] = s2.x; pt[1] = s2.y; pt[2] = s2.z;
+            ang[0] = rf.w; ang[1] = s1.z; ang[2] = s1.w;
+            refN = rf.x; refE = rf.y; refPsi = rf.z;
+        }
+        uint32_t episode = resets ? (uint32_t)a.episode[il] : 0u;
+        bool ep_dirty = false;
+        int next_switch = 0, version = 0;
+        float rec_o[9], rec_pt[3];
+        // the re-draw an env would get if it finished NOW: (seed, global env id, episode) and the setpoint in force
+        auto prepare = [&]() __attribute__((always_inline)) {
+            Env s;
+            s.refN = refN; s.refE = refE; s.refPsi = refPsi;
+            ResetDraw d;
+            reset_draw<MODE>(a, a.env_id_base + i, episode, d);
+            reset_apply<MODE>(a, s, d, rec_o);
+            rec_mb[0 * 64 + lane] = s.N; rec_mb[1 * 64 + lane] = s.E; rec_mb[2 * 64 + lane] = s.psi;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) rec_mb[(3 + k) * 64 + lane] = rec_o[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { rec_pt[k] = s.pt[k]; rec_mb[(12 + k) * 64 + lane] = s.pt[k]; }
+            rec_mb[15 * 64 + lane] = s.sn; rec_mb[16 * 64 + lane] = s.cs;
+            ++version;
+            mb_post(&seq[2], version, lane);
+        };
+        // a setpoint handed over at step t is in force BEFORE that step's re-draw (ENV:131 precedes the reset): the record is
+        // re-made with it while the env wave is still in the plant loop of step t
+        auto look_ahead = [&](int t) __attribute__((always_inline)) {
+            if (next_switch < ra.n_switch && ra.switch_step[next_switch] == t) {   // wave-uniform
+                const float* rp = ra.refs + (int64_t)next_switch * 3 * n;
+                refN = rp[il]; refE = rp[(int64_t)n + il]; refPsi = rp[2 * (int64_t)n + il];
+                ++next_switch;
+                if (resets) prepare();
+            }
+        };
+        float pre[A];
+        auto fetch = [&](int t) __attribute__((always_inline)) {
+            const float* src = ra.actions + (int64_t)t * step_stride_act;   // uniform
+            if (a.action_layout == LAYOUT_AOS) {
+                load_rows<A, 64>(src + blk_act, step_stride_act - blk_act, lane, pre);
+            } else {
+#pragma unroll
+                for (int k = 0; k < A; ++k) pre[k] = src[(int64_t)k * n + il];
+            }
+        };
+        auto post_actions = [&](int t) __attribute__((always_inline)) {     // pre holds row t
+            float* mb = act_mb[t & 1];
+            if (a.action_layout == LAYOUT_AOS) {
+#pragma unroll
+                for (int j = 0; j < A; ++j) mb[j * 64 + lane] = pre[j];      // element j * 64 + lane of the 64 x A block IS its row-major place
+            } else {
+#pragma unroll
+                for (int k = 0; k < A; ++k) mb[lane * A + k] = pre[k];
+            }
+            mb_post(&seq[0], t + 1, lane);
+        };
+        if (resets) prepare();                                               // version 1: the first episode's successor
+        look_ahead(0);
+        fetch(0); post_actions(0);
+        if (ra.T > 1) { fetch(1); post_actions(1); }
+        if (ra.T > 2) fetch(2);
+        for (int t = 0; t < ra.T; ++t) {
+            mb_wait(&seq[1], t + 1);                                         // step t posted
+            const float* pm = post_mb[t & 1];
+            float o[9], act[A];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) o[k] = k < OD ? pm[lane * OD + k] : 0.0f;
+            const uint32_t d = done_mb[t & 1][lane];
+#pragma unroll
+            for (int k = 0; k < A; ++k) act[k] = act_mb[t & 1][lane * A + k];
+            // ENV:102-126 for the books: commands in force before, commands of this step
+            float thr[3], pt_old[3], ang_prev[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { ang_prev[k] = ang[k]; pt_old[k] = pt[k]; }
+            env_decode_cmd<MODE, false>(ang, act, thr);
+            StepOut out;
+            env_reward<MODE, EXT>(a, o, thr, pt_old, ang, ang_prev, out);
+            if (live) {
+                (ra.rew + (int64_t)t * n)[(unsigned)i] = out.reward;
+                (ra.done + (int64_t)t * n)[(unsigned)i] = (uint8_t)d;
+            }
+            const bool do_reset = resets && d != 0u && live;
+            const bool any_reset = __ballot(do_reset) != 0ull;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pt[k] = do_reset ? rec_pt[k] : thr[k];                   // ENV:126 / ENV:190
+            if (do_reset) default_angles<MODE>(ang[0], ang[1], ang[2]);
+            // observation row of step t: the new episode's first observation where the env was re-drawn
+            if (a.obs_layout == LAYOUT_SOA) {
+                if (live) {
+#pragma unroll
+                    for (int k = 0; k < OD; ++k) {
+                        const float v = do_reset ? rec_o[k] : o[k];
+                        const int64_t idx = (int64_t)t * step_stride_obs + (int64_t)k * n + i;
+                        if (a.obs_bf16) ((uint16_t*)ra.obs)[idx] = f2bf(v);
+                        else ((float*)ra.obs)[idx] = v;
+                    }
+                }
+            } else {
+                if (any_reset) {
+                    if (do_reset) {
+#pragma unroll
+                        for (int k = 0; k < OD; ++k) post_mb[t & 1][lane * OD + k] = rec_o[k];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                store_rows<OD, 64>(ra.obs, (int64_t)t * step_stride_obs + blk_obs, step_stride_obs - blk_obs, a.obs_bf16, pm, lane);
+            }
+            if (any_reset) {
+                if (do_reset) { ++episode; ep_dirty = true; }
+                prepare();                                                   // lanes whose episode did not move re-make the same record
+            }
+            look_ahead(t + 1);
+            // a_t+2 takes the place of a_t (read by the env wave before it posted step t, and by this wave above)
+            if (t + 2 < ra.T) {
+                post_actions(t + 2);
+                if (t + 3 < ra.T) fetch(t + 3);
+            }
+        }
+        if (MODE == MODE_FINAL_CONT) { ang_mb[lane] = ang[1]; ang_mb[64 + lane] = ang[2]; }
+        mb_post(&seq[3], 1, lane);
+        if (live && ep_dirty) a.episode[i] = (int)episode;
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------------------------- env wave
+    Env s;
+    load_env(a, il, s);
+    sincos_lean(s.psi, s.sn, s.cs);
+    Current cur = {0.0f, 0.0f, 0.0f, 0.0f, 0u};
+    float vc0 = 0.0f, beta0 = 0.0f;
+    if (a.cur_vc) {
+        cur.vc = a.cur_vc[il]; cur.beta = a.cur_beta[il];
+        if (a.current_drift) { vc0 = a.cur_vc0[il]; beta0 = a.cur_beta0[il]; cur.ctr = a.drift_ctr[il]; }
+        current_components(cur);
+    }
+    Vessel ve = PER_CLASS ? vessel_from_lds(lds_cls, a.n_classes, cls) : vessel_from_args(a.v0);
+    if (!PER_CLASS) pin_vessel_in_vgprs(ve);
+    bool rf_dirty = (MODE == MODE_FULL);
+    int next_switch = 0, need = 1;               // re-draw record version this wave may read: 1 + setpoint switches so far + re-draw events so far
+    for (int t = 0; t < ra.T; ++t) {
+        mb_wait(&seq[0], t + 1);                                             // a_t posted (long ago: the row wave runs two steps ahead)
+        float act[A];
+#pragma unroll
+        for (int k = 0; k < A; ++k) act[k] = act_mb[t & 1][lane * A + k];
+        bool has_ref = false;
+        float nrN = 0.0f, nrE = 0.0f, nrP = 0.0f;
+        if (next_switch < ra.n_switch && ra.switch_step[next_switch] == t) {   // wave-uniform
+            const float* rp = ra.refs + (int64_t)next_switch * 3 * n;
+            nrN = rp[il]; nrE = rp[(int64_t)n + il]; nrP = rp[2 * (int64_t)n + il];
+            has_ref = true; rf_dirty = true;
+            ++next_switch;
+            if (resets) ++need;
+        }
+        StepOut out;
+        StepRest rest;
+        env_step_chain<MODE, EXT, true>(a, ve, s, act, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out, rest);
+        if (a.current_drift) current_drift_step(a, cur, vc0, beta0, a.env_id_base + i);
+        const bool do_reset = resets && out.d != 0u && live;
+        float* pm = post_mb[t & 1];
+#pragma unroll
+        for (int k = 0; k < OD; ++k) pm[lane * OD + k] = out.o[k];           // the row wave's reward is that of the TERMINAL observation
+        done_mb[t & 1][lane] = out.d;
+        if (__ballot(do_reset) != 0ull) {                                    // wave-uniform
+            mb_wait(&seq[2], need);                                          // the record for (episode, setpoint) as they are now
+            if (do_reset) {
+                float o_new[9];
+                reset_from_lds<MODE>(rec_mb, lane, s, o_new);
+                rf_dirty = true;
+            }
+            ++need;
+        }
+        mb_post(&seq[1], t + 1, lane);                                       // o_t+1, done bits posted; the record (if read) is free again
+    }
+    mb_wait(&seq[3], 1);
+    if (MODE == MODE_FINAL_CONT) {
+        // the azimuth bookkeeping of the continuous-angle variant lives in the row wave (two atan2 per step that nothing on this
+        // wave's way needs); a re-drawn env's defaults are the same on both sides
+        s.ang[1] = ang_mb[lane]; s.ang[2] = ang_mb[64 + lane];
+    }
+    if (live) {
+        store_env(a, i, s, rf_dirty);
+        if (a.current_drift) { a.cur_vc[i] = cur.vc; a.cur_beta[i] = cur.beta; a.drift_ctr[i] = cur.ctr; }
+    }
+}
+
+// =============================================================================================
 //  env.reset  (ENV:135-194)
 // =============================================================================================
 template <int MODE, bool EXT>
@@ -683,9 +934,20 @@ extern "C" hipError_t dpenv_dev_launch_step(const StepArgs* a, int mode, int ext
 }
 
 template <int MODE>
-static hipError_t launch_rollout_mode(const StepArgs& a, const RolloutArgs& ra, bool ext, bool per_class, hipStream_t s)
+static hipError_t launch_rollout_mode(const StepArgs& a, const RolloutArgs& ra, bool ext, bool per_class, bool two_wave, hipStream_t s)
 {
     const dim3 grid((a.n + RBLOCK - 1) / RBLOCK), block(RBLOCK);
+    if (two_wave) {
+        const dim3 block2(128);
+        if (ext) {
+            if (per_class) hipLaunchKernelGGL((rollout_ws_kernel<MODE, true, true>), grid, block2, 0, s, a, ra);
+            else hipLaunchKernelGGL((rollout_ws_kernel<MODE, true, false>), grid, block2, 0, s, a, ra);
+        } else {
+            if (per_class) hipLaunchKernelGGL((rollout_ws_kernel<MODE, false, true>), grid, block2, 0, s, a, ra);
+            else hipLaunchKernelGGL((rollout_ws_kernel<MODE, false, false>), grid, block2, 0, s, a, ra);
+        }
+        return hipGetLastError();
+    }
     if (ext) {
         if (per_class) hipLaunchKernelGGL((rollout_kernel<MODE, true, true>), grid, block, 0, s, a, ra);
         else hipLaunchKernelGGL((rollout_kernel<MODE, true, false>), grid, block, 0, s, a, ra);
@@ -696,15 +958,15 @@ static hipError_t launch_rollout_mode(const StepArgs& a, const RolloutArgs& ra, 
     return hipGetLastError();
 }
 
-extern "C" hipError_t dpenv_dev_launch_rollout(const StepArgs* a, const RolloutArgs* ra, int mode, int ext, int per_class,
+extern "C" hipError_t dpenv_dev_launch_rollout(const StepArgs* a, const RolloutArgs* ra, int mode, int ext, int per_class, int two_wave,
                                                hipStream_t s)
 {
     switch (mode) {
-    case MODE_FULL: return launch_rollout_mode<MODE_FULL>(*a, *ra, ext, per_class, s);
-    case MODE_SIMPLE: return launch_rollout_mode<MODE_SIMPLE>(*a, *ra, ext, per_class, s);
-    case MODE_LIMITED: return launch_rollout_mode<MODE_LIMITED>(*a, *ra, ext, per_class, s);
-    case MODE_FINAL_WRAP: return launch_rollout_mode<MODE_FINAL_WRAP>(*a, *ra, ext, per_class, s);
-    case MODE_FINAL_CONT: return launch_rollout_mode<MODE_FINAL_CONT>(*a, *ra, ext, per_class, s);
+    case MODE_FULL: return launch_rollout_mode<MODE_FULL>(*a, *ra, ext, per_class, two_wave != 0, s);
+    case MODE_SIMPLE: return launch_rollout_mode<MODE_SIMPLE>(*a, *ra, ext, per_class, two_wave != 0, s);
+    case MODE_LIMITED: return launch_rollout_mode<MODE_LIMITED>(*a, *ra, ext, per_class, two_wave != 0, s);
+    case MODE_FINAL_WRAP: return launch_rollout_mode<MODE_FINAL_WRAP>(*a, *ra, ext, per_class, two_wave != 0, s);
+    case MODE_FINAL_CONT: return launch_rollout_mode<MODE_FINAL_CONT>(*a, *ra, ext, per_class, two_wave != 0, s);
     }
     return hipErrorInvalidValue;
 }

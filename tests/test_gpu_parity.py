@@ -802,6 +802,70 @@ def test_fused_rollout_equals_single_steps_random_configurations(case):
         assert torch.equal(a1, a2) and torch.equal(b1, b2)
 
 
+@pytest.mark.parametrize('mode,ext,layout,n,T,extra', [
+    ('final_cont', True, 'aos', 1000 + 13, 120, {'reset_acts': True}),
+    ('final_cont', True, 'soa', 64 * 9, 61, {'current': True, 'current_drift': True}),
+    ('final_wrap', False, 'aos', 333, 40, {'reset_acts': True, 'obs_dtype': 'bfloat16'}),
+    ('limited', True, 'aos', 129, 3, {}),
+    ('full', True, 'aos', 500, 2, {'classes': 3}),
+    ('simple', False, 'soa', 64, 1, {}),
+])
+def test_fused_rollout_two_wave_equals_one_wave_and_single_steps(mode, ext, layout, n, T, extra):
+    """dpenv_rollout runs an env wave and a row wave per 64 envs (round 4, rollout_ws_kernel); config.step_one_wave keeps the one-wave
+    kernel.  Rows, final state, counters, episode counters and current must be bit-identical between the two and equal to T single
+    steps - with a time limit of 7 steps (every env re-drawn many times, re-draws in consecutive steps), setpoints handed over ON steps
+    that re-draw (the prepared record must be re-made with the new setpoint first), reset_acts, drifting current, classes, both layouts,
+    a ragged last workgroup and launches of 1, 2 and 3 steps (the action pipeline's start-up)."""
+    import ml4ca_amd
+    torch = torch_()
+    variant, cont = H.MODES[mode]
+    extra = dict(extra)
+    k_classes = extra.pop('classes', 0)
+    vp = None
+    if k_classes:
+        base = np.array(ml4ca_amd.default_vessel(), np.float32)
+        vp = np.tile(base, (k_classes, 1))
+        vp[:, 0:4] *= (1.0 + 0.03 * np.arange(k_classes, dtype=np.float32))[:, None]
+    envs = []
+    for one_wave in (False, True, True):
+        e = ml4ca_amd.BatchedRevoltEnv(n, variant=variant, extended_state=ext, cont_ang=cont, device='cuda:0', auto_reset=True, terminate=True,
+                                       max_ep_len=14, seed=21, env_id_base=500, vessel_params=vp, layout=layout, step_one_wave=one_wave, **extra)
+        if k_classes:
+            e.set_vessel_class((torch.arange(n, device=e.device) % k_classes).to(torch.int32))
+        if extra.get('current'):
+            e.set_current(torch.full((n,), 0.2, device=e.device), torch.full((n,), 2.3, device=e.device))
+        e.reset()
+        envs.append(e)
+    assert envs[0].max_ep_len == 7
+    A = envs[0].num_actions
+    g = torch.Generator(device='cuda:0').manual_seed(5)
+    acts = torch.randn((T, n, A), generator=g, device='cuda:0') * 0.8
+    if layout == 'soa':
+        acts = acts.transpose(1, 2).contiguous()
+    # setpoints on steps 6, 13, 20 (the time limit re-draws every env on steps 6, 13, 20, ...: switch and re-draw coincide), and on step 0
+    switch = tuple(t for t in (0, 6, 13, 20, 33) if t < T)
+    refs = torch.randn((len(switch), 3, n), generator=g, device='cuda:0')
+    outs = [e.rollout(acts, switch_steps=switch, refs=refs) for e in envs[:2]]
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    for t in range(T):
+        nr = refs[switch.index(t)] if t in switch else None
+        o, r, d, _ = envs[2].step(acts[t], new_ref=nr)
+        assert torch.equal(o, outs[0][0][t]) and torch.equal(r, outs[0][1][t]) and torch.equal(d, outs[0][2][t]), t
+    assert int(outs[0][2].ne(0).sum()) >= (T // 7) * n
+    st = [e.get_state() for e in envs]
+    for k in (1, 2):
+        assert torch.equal(st[0][0], st[k][0]) and torch.equal(st[0][1], st[k][1]), k
+    if extra.get('current'):
+        cu = [e.get_current() for e in envs]
+        for k in (1, 2):
+            assert torch.equal(cu[0][0], cu[k][0]) and torch.equal(cu[0][1], cu[k][1])
+    # a second launch continues from the first one's state (episode counters, azimuth bookkeeping handed back by the row wave)
+    outs2 = [e.rollout(acts) for e in envs[:2]]
+    for a, b in zip(outs2[0], outs2[1]):
+        assert torch.equal(a, b)
+
+
 # --------------------------------------------------------------------------------------------
 # fused rollout == T single steps
 # --------------------------------------------------------------------------------------------

@@ -789,11 +789,11 @@ def main():
                          'same workload; NOT the headline value' % CHUNK,
                  'steps': KL, 'env_steps_per_s': n * KL / fwall, 'us_per_step': fwall / KL * 1e6, 'launch_us_events': fms * 1e3 / (KL // CHUNK),
                  'bytes_per_env_step_moved': ROLLOUT_BYTES_MOVED,
-                 'roofline': hbm_roofline('dpenv::rollout_kernel<%d,%s,false>' % env_kernel_args(env), ROLLOUT_BYTES_MOVED, n * KL, fms * 1e-3,
+                 'roofline': hbm_roofline('dpenv::rollout_ws_kernel<%d,%s,false>' % env_kernel_args(env), ROLLOUT_BYTES_MOVED, n * KL, fms * 1e-3,
                                           'bytes this kernel has to move per env-step (action row in; obs row, reward, done out: the state '
                                           'stays in registers for the %d steps of a launch); HIP events around %d launches' % (CHUNK, KL // CHUNK),
-                                          launches=KL // CHUNK, bound_in_practice='VALU issue of one wave per SIMD (DESIGN.md section 4)'),
-                 'roofline_at_177B_accounting': hbm_roofline('dpenv::rollout_kernel<%d,%s,false>' % env_kernel_args(env), ALGO_BYTES_PER_ENV_STEP, n * KL, fms * 1e-3,
+                                          launches=KL // CHUNK, bound_in_practice='VALU issue of the env wave (an env wave + a row wave per 64 envs: DESIGN.md section 4)'),
+                 'roofline_at_177B_accounting': hbm_roofline('dpenv::rollout_ws_kernel<%d,%s,false>' % env_kernel_args(env), ALGO_BYTES_PER_ENV_STEP, n * KL, fms * 1e-3,
                                                              'the SAME time priced at SURVEY 8(d)\'s 177 B per env-step of the one-launch-per-step '
                                                              'path (what the fusion saves is exactly the state traffic, so this is an '
                                                              'equivalent-work rate, not bytes moved)'),

@@ -346,6 +346,9 @@ __global__ __launch_bounds__(RBLOCK) void rollout_kernel(const StepArgs a, const
 //  sequence words (release / acquire at workgroup scope, no barrier in the loop).  Same device functions on the same values
 //  (env_decode_cmd, env_reward, reset_draw / reset_apply, env_step_chain): every row and the final state are bit-identical to
 //  rollout_kernel and to T single steps (tests).  config.step_one_wave keeps the one-wave kernel (A/B, tests).
+//  (The same split for the ONE-step launch - step_ws_kernel, round 4 - was built, bit-identical and slower: a wave that lives 3 us does not
+//  earn back a second wave's start-up and two hand-overs: 5.10 -> 5.19 us at 65 536 envs, profiles/r04_step_forms.txt.  Removed; dpenv_step
+//  keeps one wave per 64 envs, plus the reset wave when auto-reset is on.)
 // =============================================================================================
 __device__ __forceinline__ void mb_post(int* p, int v, int lane)
 {

@@ -40,7 +40,7 @@ def kname(k):
               'adv_apply_kernel', 'pack_policy_kernel'):
         if n in k:
             return n
-    return 'step_kernel' if 'step_kernel' in k else 'rollout_kernel' if 'rollout_kernel' in k else None
+    return 'step_kernel' if 'step_kernel' in k else 'rollout_ws_kernel' if 'dpenv::rollout_ws_kernel' in k else 'rollout_kernel' if 'rollout_kernel' in k else None
 
 
 ALL = sorted({kname(r['Kernel_Name']) for r in rows} - {None})
@@ -63,7 +63,7 @@ for name in ('pmc_fetch', 'pmc_write', 'pmc_sq', 'pmc_mfma', 'pmc_l2'):
             agg[(kn, r['Counter_Name'])].append(float(r['Counter_Value']))
     for (kn, c), v in agg.items():
         out['kernels'].setdefault(kn, {}).setdefault('pmc_median_per_launch', {})[c] = st.median(v)
-steps_per_launch = {'step_kernel': 1, 'rollout_kernel': 50, 'policy_rollout_kernel': 50, 'policy_rollout_x_kernel': 50,
+steps_per_launch = {'step_kernel': 1, 'rollout_kernel': 50, 'rollout_ws_kernel': 50, 'policy_rollout_kernel': 50, 'policy_rollout_x_kernel': 50,
                     'gae_kernel': 400, 'gae_finalize_kernel': 1, 'adv_apply_kernel': 400, 'pack_policy_kernel': 1}
 for kn, k in out['kernels'].items():
     if kn.startswith('policy_rollout_ws_kernel'):
@@ -84,7 +84,7 @@ for kn, k in out['kernels'].items():
         # SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the SIMDs that issue MFMAs; SQ_BUSY_CYCLES is per SE (32 on this part):
         # matrix-pipe share of the kernel = MFMA cycles / (4 SIMDs x 256 CUs x kernel cycles)
         k['mfma_cycles_per_wave_per_env_step'] = p['SQ_VALU_MFMA_BUSY_CYCLES'] / p.get('SQ_WAVES', 1) / steps_per_launch[kn]
-    if kn in ('step_kernel', 'rollout_kernel'):
+    if kn in ('step_kernel', 'rollout_kernel', 'rollout_ws_kernel'):
         k['algorithmic_bytes_per_launch'] = 177 * 65536 * steps_per_launch[kn]
 try:
     out['bench_line'] = json.loads(open(src + '/bench_plain.json').read())

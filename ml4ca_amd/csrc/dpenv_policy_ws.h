@@ -83,7 +83,10 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
 #ifndef DPENV_WS_STAGE_ACTOR
 #define DPENV_WS_STAGE_ACTOR 0
 #endif
-    constexpr bool STAGE = !SPLIT || (PREC == PREC_F32_ACTOR && DPENV_WS_STAGE_ACTOR);   // env-wave rows through LDS transposes (else per lane)
+    // env-wave rows through LDS transposes (else per lane).  Not in the three-role form: its env wave shares a SIMD with the critic wave and has
+    // 256 registers, not 512 - with the staging code the f16 env wave spilled 116 B per lane there (round 4; without it 243 registers, no
+    // scratch - and still 1-3 % slower than two roles for f16, so DPENV_WS_CRITIC_WAVE leaves f16 out: profiles/r04_critic_wave.txt)
+    constexpr bool STAGE = (!SPLIT && ROLES == 2) || (PREC == PREC_F32_ACTOR && DPENV_WS_STAGE_ACTOR);
     constexpr int NIMG = ws_images(PREC);           // weight images staged: pi_hi, v_hi (, pi_lo (, v_lo))
     // All-exact arithmetic with a SIMD per wave (GROUPS = 2): the CRITIC runs on the ENV wave (round 3).  Two exact evaluations one after
     // the other in the network wave bound the step at 10.8 us while the env wave idles for most of it; with the critic behind the env
@@ -584,8 +587,9 @@ using namespace dpenv;
 
 // which arithmetics get the critic wave (ROLES = 3) in the 128-env geometry: bit 0 f16, bit 1 all exact, bit 2 exact actor.  Measured
 // (same call, bit-identical rows, profiles/r04_critic_wave.txt; 32 768 / 8 192 envs): all exact 9.43 -> 7.85 / 9.24 -> 7.30 us per step, exact
-// actor 7.4-7.7 -> 7.3-7.45 / 7.23 -> 7.01; f16 5.20 -> 5.50 / 4.76 -> 5.03 (its env wave needs more than the 256 registers two waves on a
-// SIMD leave: 116 B of scratch) - so the two split arithmetics get it, f16 keeps two roles.
+// actor 7.4-7.7 -> 7.3-7.45 / 7.23 -> 7.01; f16 5.20 -> 5.50 / 4.76 -> 5.03 with row staging (116 B of scratch at the 256 registers two waves
+// on a SIMD leave), 5.27 -> 5.33 / 4.79 -> 4.92 without it (no scratch): the f16 step is its chain already - so the two split arithmetics
+// get the critic wave, f16 keeps two roles.
 #ifndef DPENV_WS_CRITIC_WAVE
 #define DPENV_WS_CRITIC_WAVE 6
 #endif
@@ -595,7 +599,7 @@ static hipError_t go(const StepArgs& a, const PolicyArgs& pa, hipStream_t s)
     constexpr int ROLES = (GROUPS == 2 && ((DPENV_WS_CRITIC_WAVE >> PREC) & 1)) ? 3 : 2;
     const dim3 grid((a.n + 64 * GROUPS - 1) / (64 * GROUPS));
     const size_t lds = (size_t)ws_images(PREC) * pa.nent * 16 + (size_t)2 * pa.nblk * 32 * 4 +
-                       (size_t)GROUPS * (((PREC == PREC_F16 || (PREC == PREC_F32_ACTOR && DPENV_WS_STAGE_ACTOR)) ? WS_GROUP_FLOATS : WS_GROUP_FLOATS_X) +
+                       (size_t)GROUPS * ((((PREC == PREC_F16 && ROLES == 2) || (PREC == PREC_F32_ACTOR && DPENV_WS_STAGE_ACTOR)) ? WS_GROUP_FLOATS : WS_GROUP_FLOATS_X) +
                                          (ROLES == 3 ? 64 * 9 : 0)) * 4;
     hipError_t e = hipFuncSetAttribute((const void*)policy_rollout_ws_kernel<MODE, EXT, KA, ROLES, PREC, GROUPS>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -312,10 +312,12 @@ int dpenv_set_rng_counters(dpenv_handle h, const uint32_t* noise_ctr_in, const u
 /* The observation of step t carries the thrust command of step t-1 (customEnv.py:196-205 fills state_ext before :126 updates
  * prev_thrust); the state block holds the command of step t.  A closed-loop launch that CONTINUES an episode therefore starts from
  * the observation its predecessor ended with: the library keeps that observation's thrust columns (device float[n_envs][4]: o[6], o[7],
- * o[8], unused) and uses them while nothing else (step, rollout, set_state) has touched the state in between - dpenv_step
- * callers hold the returned observation themselves.  dpenv_reset writes the columns of the envs it re-draws (the new episode's own
- * previous thrust / 100): a full reset makes them valid everywhere, a masked reset leaves the other envs' columns and their validity
- * alone.  get fails with DPENV_EINVAL when there is nothing to continue; set is for
+ * o[8], unused).  Every call that changes the state keeps them (round 4): dpenv_policy_rollout and dpenv_rollout leave the columns of the
+ * last observation they returned, dpenv_set_state those of an observation rebuilt from the state (previous thrust / 100), dpenv_reset
+ * those of the envs it re-draws (a masked reset leaves the other envs' columns alone), and dpenv_step those of the observation it returns -
+ * but only while a policy is in force (16 bytes per env-step that the plain step path does not pay): after a dpenv_step WITHOUT a policy
+ * the columns are stale, and a closed-loop launch that follows an upload rebuilds its first observation from the state block (its thrust
+ * columns are then the command of the last step, not of the one before).  get fails with DPENV_EINVAL while they are stale; set is for
  * restoring a mid-episode checkpoint (after dpenv_set_state).  Whether a launch continues or rebuilds is decided on the host when
  * dpenv_policy_rollout is CALLED: inside a captured graph the first closed-loop launch keeps the decision made at capture time on
  * every replay (capture a graph that starts with a continuing launch after one such launch has run). */

@@ -464,8 +464,12 @@ extern "C" int dpenv_step_ex(dpenv_handle h, const dpenv_step_io* io, dpenv_stre
     a.done = io->done;
     a.parts = io->reward_parts;
     a.final_obs = io->final_obs;
+    // the lagged thrust columns (S3) are kept by every kernel that changes the state; the one-launch-per-step kernel writes them only
+    // while a policy is in force (16 B per env-step more) - without one the columns are marked stale and a later closed-loop launch
+    // rebuilds its first observation from the state block
+    if (!h->has_policy) a.S3 = nullptr;
     HIP_TRY(h, dpenv_dev_launch_step(&a, h->mode, h->cfg.extended_state, h->n_classes > 1, h->cfg.step_one_wave ? 0 : 1, (hipStream_t)s));
-    h->lag_valid = false;
+    h->lag_valid = h->has_policy;
     return DPENV_OK;
 }
 
@@ -501,7 +505,7 @@ extern "C" int dpenv_rollout(dpenv_handle h, const dpenv_rollout_io* io, dpenv_s
     ra.n_switch = io->n_switch; ra.refs = io->refs;
     for (int k = 0; k < io->n_switch; ++k) ra.switch_step[k] = io->switch_step[k];
     HIP_TRY(h, dpenv_dev_launch_rollout(&a, &ra, h->mode, h->cfg.extended_state, h->n_classes > 1, h->cfg.step_one_wave ? 0 : 1, (hipStream_t)s));
-    h->lag_valid = false;
+    h->lag_valid = true;                                   // the rollout kernels leave the thrust columns of their last observation in S3
     return DPENV_OK;
 }
 
@@ -797,7 +801,7 @@ extern "C" int dpenv_set_state(dpenv_handle h, const float* state_in, const int3
     if (!h) return DPENV_EINVAL;
     DeviceGuard dev_guard(h->device);
     HIP_TRY(h, dpenv_dev_launch_set_state(&h->args, state_in, counters_in, (hipStream_t)s));
-    h->lag_valid = false;
+    if (state_in) h->lag_valid = true;                     // the kernel wrote the columns a state-rebuilt observation carries (pt / 100)
     return DPENV_OK;
 }
 
@@ -826,7 +830,7 @@ extern "C" int dpenv_set_rng_counters(dpenv_handle h, const uint32_t* noise_ctr_
 extern "C" int dpenv_get_obs_thrust(dpenv_handle h, float* out, dpenv_stream s)
 {
     if (!h || !out) return fail(h, DPENV_EINVAL, "dpenv_get_obs_thrust: NULL argument");
-    if (!h->lag_valid) return fail(h, DPENV_EINVAL, "no closed-loop launch since the last reset / step / set_state: the next launch starts from the state block alone");
+    if (!h->lag_valid) return fail(h, DPENV_EINVAL, "the lagged thrust columns are stale (dpenv_step ran without a policy in force, or a masked reset on stale columns): the next closed-loop launch starts from the state block alone");
     DeviceGuard dev_guard(h->device);
     HIP_TRY(h, hipMemcpyAsync(out, h->args.S3, sizeof(float4) * (size_t)h->cfg.n_envs, hipMemcpyDeviceToDevice, (hipStream_t)s));
     return DPENV_OK;

@@ -182,6 +182,10 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(const 
     // ---- stores ---------------------------------------------------------------------------------
     store_obs<OD>(a, a.obs, o_next, i, live, lds_io);
     if (live) {
+        // the thrust columns of the observation just returned: a closed-loop launch that follows continues from THIS observation, not
+        // from one rebuilt from the state block (which holds the command of this step, not of the one before: customEnv.py:196-205,126).
+        // Only when a policy is in force (a.S3 is NULL otherwise): 16 more bytes per env-step that the plain step path does not pay.
+        if (EXT && a.S3) a.S3[i] = make_float4(o_next[6], o_next[7], o_next[8], 0.0f);
         store_env(a, i, s, rf_dirty);
         a.rew[i] = out.reward;
         a.done[i] = (uint8_t)out.d;
@@ -267,6 +271,7 @@ __global__ __launch_bounds__(RBLOCK) void rollout_kernel(const StepArgs a, const
     };
     fetch(0);
     int next_switch = 0;
+    float lag[3] = {0.0f, 0.0f, 0.0f};
     for (int t = 0; t < ra.T; ++t) {
         float act[A];
         if (a.action_layout == LAYOUT_AOS) {
@@ -300,6 +305,7 @@ __global__ __launch_bounds__(RBLOCK) void rollout_kernel(const StepArgs a, const
             env_auto_reset<MODE>(a, s, a.env_id_base + i, episode, o_next);
             ++episode; ep_dirty = true; rf_dirty = true;
         }
+        lag[0] = o_next[6]; lag[1] = o_next[7]; lag[2] = o_next[8];
         if (live) {
             (ra.rew + (int64_t)t * n)[(unsigned)i] = out.reward;          // uniform row base + lane offset
             (ra.done + (int64_t)t * n)[(unsigned)i] = (uint8_t)out.d;
@@ -325,6 +331,7 @@ __global__ __launch_bounds__(RBLOCK) void rollout_kernel(const StepArgs a, const
     }
     if (live) {
         store_env(a, i, s, rf_dirty);
+        if (EXT) a.S3[i] = make_float4(lag[0], lag[1], lag[2], 0.0f);          // thrust columns of the last observation returned (see step_kernel)
         if (ep_dirty) a.episode[i] = (int)episode;
         if (a.current_drift) { a.cur_vc[i] = cur.vc; a.cur_beta[i] = cur.beta; a.drift_ctr[i] = cur.ctr; }
     }
@@ -435,6 +442,7 @@ __global__ __launch_bounds__(128) void rollout_ws_kernel(const StepArgs a, const
             }
         };
         float pre[A];
+        float lag[3] = {0.0f, 0.0f, 0.0f};
         auto fetch = [&](int t) __attribute__((always_inline)) {
             const float* src = ra.actions + (int64_t)t * step_stride_act;   // uniform
             if (a.action_layout == LAYOUT_AOS) {
@@ -483,6 +491,8 @@ __global__ __launch_bounds__(128) void rollout_ws_kernel(const StepArgs a, const
             const bool do_reset = resets && d != 0u && live;
             const bool any_reset = __ballot(do_reset) != 0ull;
 #pragma unroll
+            for (int k = 0; k < 3; ++k) lag[k] = do_reset ? rec_o[6 + k] : o[6 + k];            // thrust columns of the observation this step returns
+#pragma unroll
             for (int k = 0; k < 3; ++k) pt[k] = do_reset ? rec_pt[k] : thr[k];                   // ENV:126 / ENV:190
             if (do_reset) default_angles<MODE>(ang[0], ang[1], ang[2]);
             // observation row of step t: the new episode's first observation where the env was re-drawn
@@ -520,6 +530,7 @@ __global__ __launch_bounds__(128) void rollout_ws_kernel(const StepArgs a, const
         if (MODE == MODE_FINAL_CONT) { ang_mb[lane] = ang[1]; ang_mb[64 + lane] = ang[2]; }
         mb_post(&seq[3], 1, lane);
         if (live && ep_dirty) a.episode[i] = (int)episode;
+        if (EXT && live) a.S3[i] = make_float4(lag[0], lag[1], lag[2], 0.0f);  // see step_kernel
         return;
     }
 
@@ -663,6 +674,8 @@ __global__ __launch_bounds__(BLOCK) void set_state_kernel(const StepArgs a, cons
         a.S1[i] = make_float4(st[4 * n + i], st[5 * n + i], st[13 * n + i], st[14 * n + i]);
         a.RF[i] = make_float4(st[6 * n + i], st[7 * n + i], st[8 * n + i], st[12 * n + i]);
         s2.x = st[9 * n + i]; s2.y = st[10 * n + i]; s2.z = st[11 * n + i];
+        // the lagged thrust columns a closed-loop launch starts from: what an observation rebuilt from this state carries (make_obs: pt / 100)
+        a.S3[i] = make_float4(s2.x * 0.01f, s2.y * 0.01f, s2.z * 0.01f, 0.0f);
     }
     if (ctr) { s2.w = __int_as_float(ctr[i]); a.episode[i] = ctr[n + i]; }
     a.S2[i] = s2;

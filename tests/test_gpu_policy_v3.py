@@ -338,6 +338,42 @@ def test_upload_does_not_disturb_a_launch_in_flight_on_another_stream():
     assert torch.equal(mu1, ref['act'][0]) and not torch.equal(mu3, mu1)
 
 
+def test_closed_loop_continues_from_the_observation_a_single_step_returned():
+    """ADVICE r03 (low), closed in round 4: a closed-loop launch after dpenv_step / dpenv_rollout / dpenv_set_state starts from the
+    observation its predecessor returned (thrust columns = the command of the step BEFORE, customEnv.py:196-205,126), not from one
+    rebuilt from the state block.  Six closed-loop steps in one launch = three in a launch + one dpenv_step with the actor's own mean
+    + two in a launch; and = three + a one-step dpenv_rollout + two."""
+    import ml4ca_amd
+    from ml4ca_amd.policy import policy_forward, policy_rollout
+    torch = torch_()
+    n = 1000 + 7
+    envs = [ml4ca_amd.BatchedRevoltEnv(n, auto_reset=True, max_ep_len=100, seed=3) for _ in range(3)]
+    ac = make_ac(9, 7, (80, 80, 80), seed=4, device=envs[0].device)
+    for e in envs:
+        ac.upload(e, precision='f32_actor')
+        e.reset()
+    whole = policy_rollout(envs[0], 6, sample=False)
+    for k, e in enumerate(envs[1:]):
+        a = policy_rollout(e, 3, sample=False)
+        for key in ('obs', 'act', 'rew'):
+            assert torch.equal(a[key], whole[key][:3]), key
+        mu, _ = policy_forward(e, a['last_obs'].float().contiguous())
+        assert torch.equal(mu, whole['act'][3])
+        if k == 0:
+            o4, r3, d3, _ = e.step(mu.contiguous())
+        else:
+            o_, r_, d_ = e.rollout(mu.contiguous().unsqueeze(0))
+            o4, r3, d3 = o_[0], r_[0], d_[0]
+        assert torch.equal(r3, whole['rew'][3]) and torch.equal(o4, whole['obs'][4])
+        b = policy_rollout(e, 2, sample=False)
+        for key in ('obs', 'act', 'rew', 'val', 'logp'):
+            assert torch.equal(b[key], whole[key][4:6]), (k, key)
+    s0, c0 = envs[0].get_state()
+    for e in envs[1:]:
+        s1, c1 = e.get_state()
+        assert torch.equal(s0, s1) and torch.equal(c0, c1)
+
+
 def test_captured_rollout_sees_every_eager_upload():
     """a rollout recorded into a HIP graph has the weight image's address baked in.  With two alternating images only
     every second eager upload reached the replays (the others ran stale weights, silently).  From the capture on, uploads go in place
@@ -508,8 +544,13 @@ def test_new_entry_points_validate_their_arguments():
     assert lag is not None and torch.equal(lag[:, 0:3], out['last_obs'][:, 6:9])
     nc, dc = env.get_rng_counters()
     assert int(nc.min()) == 3 and int(dc.max()) == 0
-    env.step(out['act'][0].contiguous())
-    assert env.get_obs_thrust() is None                              # a single step invalidates the continuation
+    o1, _, _, _ = env.step(out['act'][0].contiguous())
+    lag1 = env.get_obs_thrust()                                      # a single step (policy in force) leaves the columns of the observation it returned
+    assert lag1 is not None and torch.equal(lag1[:, 0:3], o1[:, 6:9])
+    fresh = ml4ca_amd.BatchedRevoltEnv(300, auto_reset=True)
+    fresh.reset()
+    fresh.step(out['act'][0].contiguous())
+    assert fresh.get_obs_thrust() is None                            # without a policy the step path does not write them: stale
     big = ml4ca_amd.BatchedRevoltEnv(40000)
     make_ac(9, 7, (80, 80, 80), device=big.device).upload(big, precision='f16')
     assert policy_launch_form(big) == ('two_wave', 256)

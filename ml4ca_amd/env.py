@@ -449,20 +449,40 @@ class Revolt(object):
         self._ref = torch.zeros((3, 1), dtype=torch.float32, device=b.device)
         self._init = torch.zeros((6, 1), dtype=torch.float32, device=b.device)
         self._rng = np.random
+        # step() I/O in PINNED HOST memory that the kernel reads and writes directly (hipHostMalloc memory is mapped into the device's
+        # address space at the same address): one launch and one stream synchronisation per step instead of an H2D copy, a launch and
+        # three D2H copies with a synchronisation each.  The C ABI wants device-ACCESSIBLE pointers, which these are.
+        self._h_act = torch.zeros(b.action_shape, dtype=torch.float32).pin_memory()
+        self._h_ref = torch.zeros((3, 1), dtype=torch.float32).pin_memory()
+        self._h_obs = torch.zeros(b.obs_shape, dtype=torch.float32).pin_memory()
+        self._h_rew = torch.zeros(1, dtype=torch.float32).pin_memory()
+        self._h_done = torch.zeros(1, dtype=torch.uint8).pin_memory()
+        self._np_act, self._np_ref = self._h_act.numpy(), self._h_ref.numpy()
+        self._np_obs, self._np_rew, self._np_done = self._h_obs.numpy(), self._h_rew.numpy(), self._h_done.numpy()
+        self._sio = _lib.StepIO()
+        self._sio.struct_size = C.sizeof(_lib.StepIO)
+        self._sio.action = self._h_act.data_ptr()
+        self._sio.obs = self._h_obs.data_ptr()
+        self._sio.reward = self._h_rew.data_ptr()
+        self._sio.done = self._h_done.data_ptr()
 
     # ENV:92-133
     def step(self, action, new_ref=None):
         torch = _torch()
-        a = np.asarray(action, dtype=np.float32).reshape(self._benv.action_shape)
-        self._act.copy_(torch.from_numpy(a))
-        nr = None
+        b = self._benv
+        if b.obs_torch_dtype != torch.float32:
+            raise ValueError('the single-env adapter returns float64 observations made from float32 rows')
+        self._np_act[...] = np.asarray(action, dtype=np.float32).reshape(b.action_shape)
+        self._sio.new_ref = None
         if new_ref is not None:
-            self._ref.copy_(torch.tensor(new_ref, dtype=torch.float32).reshape(3, 1))
-            nr = self._ref
-        obs, rew, done, _ = self._benv.step(self._act, new_ref=nr)
-        o = obs.float().cpu().numpy().reshape(-1).astype(np.float64)
-        r = float(rew.cpu().numpy()[0])
-        d = bool(int(done.cpu().numpy()[0]) & (_lib.DONE_TERMINAL | _lib.DONE_FAULT))
+            self._np_ref[...] = np.asarray(new_ref, dtype=np.float32).reshape(3, 1)
+            self._sio.new_ref = self._h_ref.data_ptr()
+        stream = torch.cuda.current_stream(b.device)
+        _lib.check(b.lib.dpenv_step_ex(b._h, C.byref(self._sio), C.c_void_p(stream.cuda_stream)), b._h)
+        stream.synchronize()                     # the kernel's stores to the pinned rows are visible to the host from here
+        o = self._np_obs.reshape(-1).astype(np.float64)
+        r = float(self._np_rew[0])
+        d = bool(int(self._np_done[0]) & (_lib.DONE_TERMINAL | _lib.DONE_FAULT))
         return o, r, d, {'None': 0}
 
     # ENV:135-194

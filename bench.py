@@ -350,6 +350,17 @@ def config4_record(args, dev, rank, world, dist):
     nl, T, CH = args.config4_envs, 400, 50
     tot = world * nl * T
     rec = {'what': config4_record.__doc__.split('\n\n')[0].replace('\n    ', ' '), 'envs_per_rank': nl, 'T': T, 'ranks': world, 'total_envs': world * nl}
+    # Pre-flight, agreed by ALL ranks before the first collective of this record: the gathered blocks are world x the shard, twice (two
+    # output sets), plus the local blocks.  A rank that would run out of memory alone would leave the others waiting in an all-gather
+    # (ADVICE r03); with the minimum of the free memory over the ranks every rank takes the same decision.
+    shard_bytes = nl * T * 76
+    need = (2 * world + 8) * shard_bytes
+    free = torch.tensor([float(torch.cuda.mem_get_info(dev)[0])], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(free, op=dist.ReduceOp.MIN)
+    rec['memory'] = {'needed_GB': need / 1e9, 'free_GB_min_over_ranks': float(free[0]) / 1e9}
+    if float(free[0]) < 1.25 * need:
+        raise RuntimeError('config-4 record skipped on every rank: %.1f GB free on the tightest rank, %.1f GB needed' % (float(free[0]) / 1e9, 1.25 * need / 1e9))
     mk = lambda **kw: ml4ca_amd.BatchedRevoltEnv(nl, variant='final', extended_state=True, cont_ang=True, device=dev, terminate=True,
                                                  auto_reset=True, seed=4, env_id_base=rank * nl, **kw)
     env = mk()

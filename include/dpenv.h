@@ -118,8 +118,9 @@ typedef struct dpenv_config {
                                 reset_acts constructor flag, customEnv.py:30,179-188); drawn in the kernel by every kind of reset,
                                 Philox keyed (seed; global env id, episode) like the pose sample */
     int32_t step_one_wave;   /* 0 (default): dpenv_step with auto_reset on launches a second wave per 64 envs that prepares the re-draw of
-                                finished envs beside the plant loop, and dpenv_rollout runs an env wave and a row wave per 64 envs (same
-                                rows bit for bit).  1: the one-wave kernels - the A/B switch of tools/ and tests;
+                                finished envs beside the plant loop (up to 256 envs per CU), and dpenv_rollout runs an env wave and a row
+                                wave per 64 envs (up to 384 envs per CU) - same rows bit for bit, the one-wave kernels above those sizes
+                                (DESIGN.md section 4).  1: the one-wave kernels at every size - the A/B switch of tools/ and tests;
                                 was `reserved` (0) before round 4 */
 } dpenv_config;
 

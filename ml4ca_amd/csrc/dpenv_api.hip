@@ -468,7 +468,11 @@ extern "C" int dpenv_step_ex(dpenv_handle h, const dpenv_step_io* io, dpenv_stre
     // while a policy is in force (16 B per env-step more) - without one the columns are marked stale and a later closed-loop launch
     // rebuilds its first observation from the state block
     if (!h->has_policy) a.S3 = nullptr;
-    HIP_TRY(h, dpenv_dev_launch_step(&a, h->mode, h->cfg.extended_state, h->n_classes > 1, h->cfg.step_one_wave ? 0 : 1, (hipStream_t)s));
+    // the reset wave pays while the batch leaves it a SIMD slot beside its env wave (<= one env wave per SIMD = 256 envs per CU: 65 536 on
+    // MI355X); beyond that the extra waves queue behind env waves and the one-wave kernel is faster (98 304 envs: 6.92 vs 7.19 us, 1 M:
+    // 34.7 vs 39.2; profiles/r04_reset_wave.txt)
+    const int reset_wave = (!h->cfg.step_one_wave && (int64_t)h->cfg.n_envs <= (int64_t)256 * h->n_cus) ? 1 : 0;
+    HIP_TRY(h, dpenv_dev_launch_step(&a, h->mode, h->cfg.extended_state, h->n_classes > 1, reset_wave, (hipStream_t)s));
     h->lag_valid = h->has_policy;
     return DPENV_OK;
 }
@@ -504,7 +508,10 @@ extern "C" int dpenv_rollout(dpenv_handle h, const dpenv_rollout_io* io, dpenv_s
     ra.T = io->T; ra.actions = io->actions; ra.obs = io->obs; ra.rew = io->reward; ra.done = io->done;
     ra.n_switch = io->n_switch; ra.refs = io->refs;
     for (int k = 0; k < io->n_switch; ++k) ra.switch_step[k] = io->switch_step[k];
-    HIP_TRY(h, dpenv_dev_launch_rollout(&a, &ra, h->mode, h->cfg.extended_state, h->n_classes > 1, h->cfg.step_one_wave ? 0 : 1, (hipStream_t)s));
+    // env wave + row wave while the chip has issue slots to spare (measured: 16 384 ... 98 304 envs 5-20 % faster, 131 072 equal, 262 144 and
+    // above 10-15 % slower than one wave per 64 envs: profiles/r04_fused_two_wave.txt, r04_batch_sweep.txt)
+    const int two_wave = (!h->cfg.step_one_wave && (int64_t)h->cfg.n_envs <= (int64_t)384 * h->n_cus) ? 1 : 0;
+    HIP_TRY(h, dpenv_dev_launch_rollout(&a, &ra, h->mode, h->cfg.extended_state, h->n_classes > 1, two_wave, (hipStream_t)s));
     h->lag_valid = true;                                   // the rollout kernels leave the thrust columns of their last observation in S3
     return DPENV_OK;
 }

@@ -37,6 +37,8 @@ CHUNK = 50
 BOX_SWITCH_STEPS = (50, 300, 550, 700, 950)        # plot_pos.py:59 at dt = 0.2 s
 BOX_REFS = ((5.0, 0.0, 0.0), (5.0, -5.0, 0.0), (5.0, -5.0, -45.0), (0.0, -5.0, -45.0), (0.0, 0.0, 0.0))   # plot_pos.py:55-57
 ALGO_BYTES_PER_ENV_STEP = 177                      # 88 B read + 89 B written
+ALGO_BYTES_PER_ENV = 285                           # + 3 x 9 x 4 = 108 B of per-env parameter blocks read
+PER_ENV_BYTES_MOVED = 177 + 4 + 128                # what the kernel's layout moves: the ref block padded to 16 B, eight float4 of parameters
 HBM_PEAK_GBPS = 8000.0                             # MI355X_MICROARCH.md: 8.0 TB/s spec
 ALGO_FLOPS_PER_ENV_STEP = 20 * 80 + 400            # ~80 flop per plant sub-step (semi-implicit Euler, 20 x 10 ms) + ~400 decode / trig / reward
 VALU_PEAK_TFLOPS = 157.3                           # MI355X_MICROARCH.md: peak fp32 vector
@@ -60,10 +62,14 @@ def hbm_roofline(kernel, bytes_per_env_step, env_steps, seconds, what, launches=
     return rec
 
 
-def step_kernel_name(env):
-    """the instantiation dpenv_step launches for this env (dpenv_kernels.hip: step_kernel<MODE, EXT, PER_CLASS>; dpenv_dev.h MODE_*)"""
+def step_kernel_name(env, ves=None):
+    """the instantiation dpenv_step launches for this env (dpenv_kernels.hip: step_kernel<MODE, EXT, VES, RESETW>; dpenv_dev.h MODE_*, VES_*:
+    0 kernel arguments, 1 class table in LDS, 2 per-env blocks into registers, 3 per-env blocks through an LDS image, 4 = 2 + hull re-draw)"""
     mode = {'full': 0, 'simple': 1, 'limited': 2, 'final': 4 if env.cont_ang else 3}[env.variant]
-    return 'dpenv::step_kernel<%d,%s,%s>' % (mode, 'true' if env.extended_state else 'false', 'true' if env.n_classes > 1 else 'false')
+    if ves is None:
+        ves = 1 if env.n_classes > 1 else 0
+    resetw = env.auto_reset and not env.cfg.step_one_wave and env.n_envs <= 65536
+    return 'dpenv::step_kernel<%d,%s,%d,%s>' % (mode, 'true' if env.extended_state else 'false', ves, 'true' if resetw else 'false')
 
 
 def env_kernel_args(env):
@@ -73,11 +79,11 @@ def env_kernel_args(env):
 
 def policy_kernel_name(env, prec):
     """the closed-loop kernel DPENV_LAUNCH_AUTO resolved to (dpenv_policy_ws.h / dpenv_policy.hip / dpenv_policy_x.hip)"""
-    from ml4ca_amd.policy import policy_launch_form
+    from ml4ca_amd.policy import policy_launch_form, policy_launch_info
     form, epw = policy_launch_form(env)
     mode, ext = env_kernel_args(env)
     if form == 'two_wave':
-        roles = 3 if (epw == 128 and prec != 'f16') else 2       # dpenv_policy_ws.h: a critic wave of its own for the split arithmetics in the 128-env geometry
+        roles = policy_launch_info(env)['waves_per_64_envs']     # as the library resolved it (dpenv_policy_ws.h: a critic wave of its own for the split arithmetics in the 128-env geometry)
         return 'dpenv::policy_rollout_ws_kernel<%d,%s,KA=5,ROLES=%d,%s,GROUPS=%d>' % (mode, ext, roles, {'f16': 'F16', 'f32': 'F32', 'f32_actor': 'F32_ACTOR'}[prec], epw // 64)
     return 'dpenv::policy_rollout_%skernel<%d,%s,...>' % ('' if prec == 'f16' else 'x_', mode, ext)
 
@@ -108,7 +114,8 @@ def parse():
                                                              'episode exchange alone / synchronous / overlapped); default: on if gpus > 1')
     ap.add_argument('--config4-envs', type=int, default=32768)
     ap.add_argument('--classes', type=int, default=0, help='K > 0: also time dpenv_step with K vessel classes (LDS-staged [param][class] blocks) '
-                                                           'against the single-class SGPR path, and the closed loop with classes on')
+                                                           'against the single-class SGPR path, the closed loop with classes on, and per-ENV parameter '
+                                                           'blocks (registers vs LDS image, randomised hulls): the `vessel_classes` record')
     ap.add_argument('--init-timeout', type=float, default=180.0, help='seconds a rank waits for its peers in init_process_group / the first barrier '
                                                                        'before it gives up with a message and a non-zero exit code')
     ap.add_argument('--rendezvous-only', action='store_true', help='diagnostic: the ranks join the process group, exchange one all-reduce and rank 0 '
@@ -577,7 +584,164 @@ def classes_record(args, dev, n):
             r['closed_loop_us_per_step_' + prec] = (time.perf_counter() - t0) / (6 * CHUNK) * 1e6
         rec['classes_%d' % K] = r
         del env, gr
+    # ---- per-ENV blocks (dpenv_set_vessel_params): 65 536 distinct hulls, the two staging forms of SURVEY section 7 ("LDS [matrix_elem][lane]
+    #      vs plain VGPRs"), and the randomisation (hulls re-drawn by the reset path) on the config-2 workload --------------------------------
+    hulls = torch.from_numpy(np.ascontiguousarray(np.concatenate([
+        base[:26, None] * (1.0 + 0.15 * np.random.RandomState(7).uniform(-1, 1, size=(26, n))), np.zeros((6, n))]).astype(np.float32))).to(dev)
+    per_env = {'what': 'dpenv_step with every env on its OWN parameter block (+-15 % on all 26 parameters; float4 streams ET[8][n], 128 B per env-step '
+                       'read on top of the state), same envs / actions / 50-step graphs as the class legs; roofline at SURVEY 8(d)\'s 285 B per env-step'}
+
+    def time_steps(env, reps=40):
+        obs = torch.empty((n, 9), device=dev); rew = torch.empty(n, device=dev); done = torch.empty(n, dtype=torch.uint8, device=dev)
+
+        def chunk():
+            for k in range(CHUNK):
+                env.step(actions[k], out=(obs, rew, done))
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            chunk()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            chunk()
+        for _ in range(4):
+            gr.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for _ in range(reps):
+            gr.replay()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) * 1e-3 / (reps * CHUNK)
+
+    for tag, lds in (('registers', False), ('lds_image', True)):
+        env = ml4ca_amd.BatchedRevoltEnv(n, device=dev, terminate=False, time_limit=False, seed=1, per_env_lds=lds)
+        env.set_vessel_params(hulls)
+        env.reset()
+        sec = time_steps(env)
+        per_env[tag] = {'step_us': sec * 1e6,
+                        'path': 'eight global_load_lds_dwordx4 into a [group][lane] LDS image, read back with ds_read_b128' if lds else
+                                'eight coalesced global_load_dwordx4 per lane straight into registers',
+                        'roofline': hbm_roofline(step_kernel_name(env, 3 if lds else 2), ALGO_BYTES_PER_ENV, n, sec,
+                                                 'SURVEY 8(d): 177 B + 108 B of per-env parameters; the layout moves %d B (ref block padded to 16 B, '
+                                                 'parameter block padded to 128 B); HIP events around 40 replays of a 50-step graph' % PER_ENV_BYTES_MOVED,
+                                                 launches=1, GBps_moved=PER_ENV_BYTES_MOVED * n / sec / 1e9)}
+        del env
+    per_env['kept'] = 'registers' if per_env['registers']['step_us'] <= per_env['lds_image']['step_us'] else 'lds_image'
+    # closed loop and fused rollout: the block is loaded once per launch
+    env = ml4ca_amd.BatchedRevoltEnv(n, device=dev, terminate=False, time_limit=False, seed=1)
+    env.set_vessel_params(hulls)
+    env.reset()
+    ac = ActorCritic(9, 7, (80, 80, 80), seed=0, device=dev)
+    for prec in ('f16', 'f32_actor'):
+        ac.upload(env, precision=prec)
+        out = policy_rollout(env, CHUNK, sample=True)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(6):
+            policy_rollout(env, CHUNK, sample=True, out=out)
+        torch.cuda.synchronize(dev)
+        per_env['closed_loop_us_per_step_' + prec] = (time.perf_counter() - t0) / (6 * CHUNK) * 1e6
+    del env
+    # config-2 workload (termination + auto-reset on): shared hull / per-env blocks / per-env blocks re-drawn at every reset
+    rnd = {}
+    for tag in ('shared_default', 'per_env', 'per_env_randomised'):
+        env = ml4ca_amd.BatchedRevoltEnv(n, device=dev, terminate=True, auto_reset=True, seed=1)
+        if tag == 'per_env':
+            env.set_vessel_params(hulls)
+        if tag == 'per_env_randomised':
+            env.set_vessel_randomisation(0.15)
+        env.reset()
+        sec = time_steps(env, reps=20)
+        rnd[tag] = {'step_us': sec * 1e6, 'kernel': step_kernel_name(env, {'shared_default': 0, 'per_env': 2, 'per_env_randomised': 4}[tag])}
+        for prec in ('f16',):
+            ac.upload(env, precision=prec)
+            out = policy_rollout(env, CHUNK, sample=True)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(6):
+                policy_rollout(env, CHUNK, sample=True, out=out)
+            torch.cuda.synchronize(dev)
+            rnd[tag]['closed_loop_us_per_step_' + prec] = (time.perf_counter() - t0) / (6 * CHUNK) * 1e6
+            rnd[tag]['resets_per_env_step'] = float((out['done'] != 0).float().mean())
+        del env
+    per_env['config2_workload'] = dict(rnd, what='terminate + auto_reset on (the training workload): dpenv_step with its reset wave, and the f16 closed loop; '
+                                                 'per_env_randomised = dpenv_set_vessel_randomisation(0.15): every reset draws the new episode\'s hull '
+                                                 '(four Philox blocks) - in the reset wave of dpenv_step, in a separate instantiation of the closed-loop kernel')
+    rec['per_env'] = per_env
     return rec
+
+
+def eager_record(env, actions, dev):
+    """What a user's own Python loop pays per call of BatchedRevoltEnv.step - the call pattern of spinup/algos/tf1/ppo/ppo.py:291-293
+    (`o2, r, d, _ = env.step(a)` inside a `for`), no HIP graph: (a) the steady loop (wall and HIP events; the GPU is the bound if the host
+    issues faster than the kernel runs), (b) the HOST cost of one call alone (time to issue calls into an idle queue, no synchronisation
+    in between), with its shares: the raw ctypes call of dpenv_step_ex with a prebuilt dpenv_step_io (nothing but the C ABI), the binding's
+    plumbing on top (stream handle, data_ptr()s, argument checks of already-seen tensors), and the full argument checks a call with
+    tensors it has not seen before pays (a fresh view per call, e.g. actions[t])."""
+    import ctypes as C
+    import torch
+    from ml4ca_amd import _lib
+    n = env.n_envs
+    obs = torch.empty((n, 9), device=dev); rew = torch.empty(n, device=dev); done = torch.empty(n, dtype=torch.uint8, device=dev)
+    out = (obs, rew, done)
+    acts = [actions[k] for k in range(actions.shape[0])]          # tensor objects that live across the calls
+    NA = len(acts)
+
+    def loop_cached(k):
+        for t in range(k):
+            env.step(acts[t % NA], out=out)
+
+    def loop_fresh(k):
+        for t in range(k):
+            env.step(actions[t % NA], out=out)                    # a new view object per call: full argument checks
+
+    io = _lib.StepIO()
+    io.struct_size = C.sizeof(_lib.StepIO)
+    io.action, io.obs, io.reward, io.done = acts[0].data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr()
+    ref, h, fn = C.byref(io), env._h, env.lib.dpenv_step_ex
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def loop_raw(k):
+        for t in range(k):
+            fn(h, ref, stream)
+
+    def issue_cost(loop, k=400):
+        loop(50)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        loop(k)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize(dev)
+        return (t1 - t0) / k * 1e6
+
+    def steady(loop, k=4000):
+        loop(200)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        e0.record()
+        loop(k)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / k * 1e6, e0.elapsed_time(e1) * 1e3 / k
+
+    wall, ev = steady(loop_cached)
+    wall_f, ev_f = steady(loop_fresh)
+    wall_r, ev_r = steady(loop_raw)
+    h_c, h_f, h_r = issue_cost(loop_cached), issue_cost(loop_fresh), issue_cost(loop_raw)
+    return {'what': eager_record.__doc__.split('\n\n')[0].replace('\n    ', ' '),
+            'eager_us_per_step': wall, 'eager_us_per_step_hip_events': ev, 'env_steps_per_s': n / (wall * 1e-6),
+            'eager_us_per_step_fresh_views': wall_f, 'eager_us_per_step_raw_c_abi': wall_r,
+            'host_us_per_call': {'binding_cached_tensors': h_c, 'binding_fresh_views': h_f, 'raw_ctypes_dpenv_step_ex': h_r,
+                                 'plumbing_share': h_c - h_r, 'argument_check_share': h_f - h_c,
+                                 'note': 'time for the Python loop to ISSUE a call into an idle queue (400 calls, no synchronisation in between); when it is below the '
+                                         'kernel spacing of the graph-replayed headline the eager loop runs at the GPU\'s rate'},
+            'bound': 'gpu' if h_c < ev else 'host'}
 
 
 def main():
@@ -766,6 +930,11 @@ def main():
     # and clock ramp), more when --steps asks for more
     KL = max(25 * CHUNK, (K // CHUNK) * CHUNK)
     WL = CHUNK
+
+    # ---- eager loop: what a hand-written Python `for` over env.step pays (no graph) -------------------------------------------
+    eager = None
+    if side_legs and rank == 0:
+        eager = eager_record(env, actions, dev)
 
     # ---- fused-rollout leg (dpenv_rollout): same workload, CHUNK env steps per launch, state in registers -----
     fused = None
@@ -1021,6 +1190,8 @@ def main():
             res['config4'] = cfg4
         if classes:
             res['vessel_classes'] = classes
+        if eager:
+            res['eager_loop'] = eager
         if fused:
             res['fused_rollout'] = fused
         if closed:

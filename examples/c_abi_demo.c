@@ -1,6 +1,9 @@
 /* c_abi_demo.c - libdpenv.so from plain C: no Python, no torch.  Allocates the I/O buffers with the HIP runtime,
  * resets 65 536 environments, steps them 2 000 times with a fixed action block, and prints throughput and a
- * checksum.  Build (see tests/test_gpu_c_abi.py):
+ * checksum.  Then the FUSED entry points from the same C program (round 5): dpenv_rollout (50 env steps in one launch, one setpoint
+ * switch inside it) and, on the rows it wrote, dpenv_gae_stats + dpenv_adv_apply_stats (TrajectoryBuffer.finish_path / get of
+ * spinup/algos/tf1/ppo/ppo.py:65-105) - with checksums that tests/test_gpu_c_abi.py compares with the same calls made through
+ * the Python binding.  Build (see tests/test_gpu_c_abi.py):
  *   gcc -std=c11 -O2 -I include -I /opt/rocm/include examples/c_abi_demo.c -L ml4ca_amd/lib -ldpenv -L /opt/rocm/lib -lamdhip64 \
  *       -Wl,-rpath,$PWD/ml4ca_amd/lib -Wl,-rpath,/opt/rocm/lib -o build/c_abi_demo
  */
@@ -81,5 +84,75 @@ int main(int argc, char** argv)
     printf("c_abi_demo: %d envs x %d eager steps in %.3f ms = %.3e env-steps/s (%.2f us per step); mean reward %.4f; faults %d\n", n,
            steps, dt * 1e3, (double)n * steps / dt, dt / steps * 1e6, sum / n, faults);
     CHECK(dpenv_destroy(h));
-    return faults ? 2 : 0;
+    if (faults) return 2;
+
+    /* ---- fused entry points: dpenv_rollout + dpenv_gae_stats + dpenv_adv_apply_stats ------------------------------------------- */
+    const int n2 = argc > 3 ? atoi(argv[3]) : 4096, T = 50, SW = 20;
+    dpenv_default_config(&cfg);
+    cfg.n_envs = n2;
+    cfg.auto_reset = 1;
+    cfg.seed = 7;
+    h = NULL;
+    CHECK(dpenv_create(&cfg, NULL, 1, &h));
+    const size_t na = (size_t)T * n2 * ad, no = (size_t)T * n2 * od, nr = (size_t)T * n2;
+    float *acts, *obsT, *rewT, *valT, *advT, *retT, *refs;
+    uint8_t* doneT;
+    double* stats;
+    void* ws;
+    const size_t ws_bytes = (size_t)dpenv_gae_workspace_bytes(n2);
+    if (hipMalloc((void**)&acts, 4 * na) != hipSuccess || hipMalloc((void**)&obsT, 4 * no) != hipSuccess || hipMalloc((void**)&rewT, 4 * nr) != hipSuccess ||
+        hipMalloc((void**)&valT, 4 * nr) != hipSuccess || hipMalloc((void**)&advT, 4 * nr) != hipSuccess || hipMalloc((void**)&retT, 4 * nr) != hipSuccess ||
+        hipMalloc((void**)&doneT, nr) != hipSuccess || hipMalloc((void**)&refs, 4 * 3 * (size_t)n2) != hipSuccess ||
+        hipMalloc((void**)&stats, 2 * sizeof(double)) != hipSuccess || hipMalloc(&ws, ws_bytes) != hipSuccess) {
+        fprintf(stderr, "hipMalloc failed\n");
+        return 1;
+    }
+    float* hacts = (float*)malloc(4 * na);
+    s = 2024u;
+    for (size_t i = 0; i < na; ++i) {
+        s = s * 1664525u + 1013904223u;
+        hacts[i] = ((float)(s >> 8) / 16777216.0f - 0.5f) * 1.6f;
+    }
+    hipMemcpy(acts, hacts, 4 * na, hipMemcpyHostToDevice);
+    float* hrefs = (float*)malloc(4 * 3 * (size_t)n2);
+    for (int i = 0; i < n2; ++i) { hrefs[i] = 1.5f; hrefs[n2 + i] = -0.5f; hrefs[2 * n2 + i] = 0.1f; }      /* [1][3][n]: N, E, psi */
+    hipMemcpy(refs, hrefs, 4 * 3 * (size_t)n2, hipMemcpyHostToDevice);
+    CHECK(dpenv_reset(h, NULL, NULL, NULL, NULL, stream));
+    dpenv_rollout_io rio;
+    memset(&rio, 0, sizeof rio);
+    rio.struct_size = (uint32_t)sizeof rio;
+    rio.T = T; rio.actions = acts; rio.obs = obsT; rio.reward = rewT; rio.done = doneT;
+    rio.n_switch = 1; rio.switch_step[0] = SW; rio.refs = refs;            /* the setpoint handed over at step 20, visible from step 21 (customEnv.py:131) */
+    CHECK(dpenv_rollout(h, &rio, stream));
+    hipStreamSynchronize(stream);
+    float* hobs = (float*)malloc(4 * no);
+    float* hrewT = (float*)malloc(4 * nr);
+    uint8_t* hdoneT = (uint8_t*)malloc(nr);
+    hipMemcpy(hobs, obsT, 4 * no, hipMemcpyDeviceToHost);
+    hipMemcpy(hrewT, rewT, 4 * nr, hipMemcpyDeviceToHost);
+    hipMemcpy(hdoneT, doneT, nr, hipMemcpyDeviceToHost);
+    double obs_sum = 0.0, rew_sum = 0.0;
+    long done_count = 0;
+    for (size_t i = 0; i < no; ++i) obs_sum += hobs[i];
+    for (size_t i = 0; i < nr; ++i) { rew_sum += hrewT[i]; done_count += hdoneT[i] != 0; }
+    /* a stand-in critic: V = r / 2 (the scan only needs SOME value row; the closed-loop entry point writes the real one) */
+    for (size_t i = 0; i < nr; ++i) hrewT[i] *= 0.5f;
+    hipMemcpy(valT, hrewT, 4 * nr, hipMemcpyHostToDevice);
+    if (dpenv_gae_stats(rewT, valT, doneT, NULL, NULL, T, n2, 0.99f, 0.97f, advT, retT, ws, stats, stream) != DPENV_OK ||
+        dpenv_adv_apply_stats(advT, (int64_t)nr, stats, (double)nr, stream) != DPENV_OK) {
+        fprintf(stderr, "gae / normalisation failed: %s\n", dpenv_last_error(NULL));
+        return 1;
+    }
+    hipStreamSynchronize(stream);
+    double hstats[2], adv_sum = 0.0, adv_sq = 0.0, ret_sum = 0.0;
+    hipMemcpy(hstats, stats, sizeof hstats, hipMemcpyDeviceToHost);
+    hipMemcpy(hrewT, advT, 4 * nr, hipMemcpyDeviceToHost);
+    for (size_t i = 0; i < nr; ++i) { adv_sum += hrewT[i]; adv_sq += (double)hrewT[i] * hrewT[i]; }
+    hipMemcpy(hrewT, retT, 4 * nr, hipMemcpyDeviceToHost);
+    for (size_t i = 0; i < nr; ++i) ret_sum += hrewT[i];
+    printf("c_abi_demo fused: %d envs x %d steps in one dpenv_rollout launch, setpoint switch at step %d; checksums obs %.17g rew %.17g done %ld "
+           "gae_stats %.17g %.17g adv_norm_sum %.17g adv_norm_sq %.17g ret %.17g\n", n2, T, SW, obs_sum, rew_sum, done_count, hstats[0], hstats[1], adv_sum,
+           adv_sq, ret_sum);
+    CHECK(dpenv_destroy(h));
+    return 0;
 }

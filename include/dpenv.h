@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DPENV_ABI_VERSION 3
+#define DPENV_ABI_VERSION 4
 
 typedef struct dpenv_s* dpenv_handle;
 typedef void* dpenv_stream; /* hipStream_t; NULL = the null stream */
@@ -82,9 +82,10 @@ enum {
     DPENV_P_LX_BOW, DPENV_P_LX_PORT, DPENV_P_LX_STAR,
     DPENV_P_LY_BOW, DPENV_P_LY_PORT, DPENV_P_LY_STAR,
     DPENV_P_NUV, DPENV_P_YUR, /* speed-proportional cross-flow terms: yaw moment -N_uv u v (adds to the Munk moment -(m22-m11) u v; N_uv < -(m22-m11) would make the hull weathervane-stable), sway force -Y_ur u r */
-    DPENV_NPARAM = 32
+    DPENV_NPARAM = 32,   /* slots 26..31 reserved (zero) */
+    DPENV_NPARAM_USED = 26
 };
-#define DPENV_MAX_CLASSES 64
+#define DPENV_MAX_CLASSES 64   /* classes share LDS-staged tables; for more distinct hulls than that - one per env - see dpenv_set_vessel_params */
 
 typedef struct dpenv_config {
     uint32_t struct_size;    /* sizeof(dpenv_config), ABI check */
@@ -122,6 +123,10 @@ typedef struct dpenv_config {
                                 wave per 64 envs (up to 384 envs per CU) - same rows bit for bit, the one-wave kernels above those sizes
                                 (DESIGN.md section 4).  1: the one-wave kernels at every size - the A/B switch of tools/ and tests;
                                 was `reserved` (0) before round 4 */
+    int32_t per_env_lds;     /* per-env parameter blocks in dpenv_step: 0 (default) a lane loads its block straight into registers; 1: by
+                                LDS-DMA (global_load_lds_dwordx4) into a [group][lane] LDS image that the step reads back - the A/B SURVEY
+                                section 7 asks for ("LDS [matrix_elem][lane] vs plain VGPRs"); same rows bit for bit, slower (DESIGN.md
+                                section 4).  The T-step kernels load the block once per launch into registers either way. */
 } dpenv_config;
 
 /* Optional outputs / inputs of one step beyond the Gym tuple.  All device pointers, any may be NULL. */
@@ -156,6 +161,35 @@ const char* dpenv_last_error(dpenv_handle h);
 int dpenv_set_reset_fraction(dpenv_handle h, float fraction);
 /* class_id: device int32[n_envs], values in [0, n_classes).  Copied. */
 int dpenv_set_vessel_class(dpenv_handle h, const int32_t* class_id, dpenv_stream s);
+
+/* ---- per-env vessel parameter blocks (north_star: "per-env 3x3 mass / Coriolis / damping blocks"; SURVEY appendix D: "M, D as per-env
+ * SoA parameter arrays (domain randomisation) with a shared-default fast path") -----------------------------------------------------
+ * Every env gets its OWN hull and thruster parameters - the constants the reference hard-codes once for its one vessel
+ * (qp_allocator.py:51-55,69-70 K and lever arms, SupervisedTau.py:35-36,69-71) and the build-owned mass / damping terms of the plant
+ * that stands in for customEnv.py:124.  params: DEVICE float[DPENV_NPARAM][n_envs] (structure of arrays: row p = parameter DPENV_P_p of
+ * every env; rows 26..31 ignored), copied on the stream: one kernel derives each env's mass-matrix inverse (the same float operations
+ * as for a class, so an env given its class's numbers reproduces the class path bit for bit) and packs the block as eight float4
+ * streams.  dpenv_step then reads 128 B more per env-step (SURVEY 8d accounts 108 B: 285 B per env-step); the T-step kernels
+ * (dpenv_rollout, dpenv_policy_rollout) load the block once per launch.  A block that is not a vessel (mass matrix not positive
+ * definite, non-finite entry) is not rejected here (no host synchronisation): that env reports DPENV_DONE_FAULT at its first step.
+ * params == NULL: back to the vessel classes / the single class of dpenv_create (the shared-default fast path: parameters in SGPRs).
+ * Switching between the paths voids HIP graphs captured before (the table's address is a kernel argument). */
+int dpenv_set_vessel_params(dpenv_handle h, const float* params, dpenv_stream s);
+/* The parameter vectors in force: DEVICE float[DPENV_NPARAM][n_envs] (rows 26..31 zero).  Needs per-env blocks in force. */
+int dpenv_get_vessel_params(dpenv_handle h, float* params_out, dpenv_stream s);
+/* Domain randomisation through the reset path: from this call on EVERY reset of an env - dpenv_reset (also with explicit init),
+ * auto-reset inside dpenv_step / dpenv_rollout / dpenv_policy_rollout, reset_at_end - starts the new episode on a freshly drawn hull:
+ *   parameter p = nominal[p] * (1 + rel_range[p] * u),  u uniform in [-1, 1) (16 bits),
+ * Philox4x32-10 keyed by config.seed with counter (global env id, episode counter, tag 0x48000000 | block) - parameter p takes the
+ * 16-bit half (q & 1) of word (q & 7) >> 1 of block q >> 3, q = its slot in the order m11 m22 m23 m33 Xu (0..4) | Xuu Yv Yvv Yr Nv Nr Nrr
+ * Nuv (8..15) | Yur Kf[3] Kr[3] lx_bow (16..23) | lx_port lx_star ly[3] (24..28); u = h / 32768 - 1: a function of the env and of
+ * its episode like the pose sample, so hulls do not depend on the rank count or on the launch form, and a checkpoint (dpenv_get_state
+ * counters + dpenv_get_vessel_params) restores them.  nominal: HOST float[DPENV_NPARAM], NULL = class 0 of dpenv_create; rel_range:
+ * HOST float[DPENV_NPARAM], entries in [0, 1), 0 = that parameter is not randomised; every hull of the range must have a positive
+ * definite mass matrix (checked).  Until its first reset an env runs on the nominal hull.  Implies per-env blocks;
+ * rel_range == NULL stops the re-draws (the hulls in force stay); dpenv_set_vessel_params(h, NULL / table, s) ends it as well.
+ * With the randomisation on, a dpenv_reset with explicit init advances the episode counter too (it consumes random numbers). */
+int dpenv_set_vessel_randomisation(dpenv_handle h, const float* nominal, const float* rel_range, dpenv_stream s);
 /* vc, beta: device float[n_envs] current speed [m/s] and NED direction [rad].  Copied; they are both the
  * present value and the mean the drift process reverts to. */
 int dpenv_set_current(dpenv_handle h, const float* vc, const float* beta, dpenv_stream s);
@@ -254,6 +288,15 @@ int dpenv_set_policy_desc(dpenv_handle h, const dpenv_policy_desc* d, dpenv_stre
 /* What DPENV_LAUNCH_AUTO resolved to for the policy in force: *two_wave_out = 1 for the two-wave form, *envs_per_workgroup_out = 256 or
  * 128 (host ints, either may be NULL). */
 int dpenv_get_policy_launch(dpenv_handle h, int32_t* two_wave_out, int32_t* envs_per_workgroup_out);
+/* The same and more, as the library resolved it: out[0] two-wave form (0 / 1), out[1] envs per workgroup, out[2] waves per 64 envs (1 one-wave
+ * form, 2 env + network wave, 3 env + actor + critic wave), out[3] the arithmetic (DPENV_POLICY_*). */
+int dpenv_get_policy_launch_ex(dpenv_handle h, int32_t out[4]);
+/* Ends the pinning described above: call it when every HIP graph that recorded a dpenv_policy_rollout / dpenv_policy_forward of this handle
+ * has been destroyed (or will not be replayed again).  Until then an upload whose image LAYOUT differs from the one the graphs were captured
+ * with - another hidden shape, precision, activation, leak or launch form; the kernel nodes hold those by value next to the image's address -
+ * is refused with DPENV_EINVAL (it would be read with the old layout: wrong weights, no error); new weights of the same layout are what the
+ * in-place upload is for.  After the call uploads alternate between the two images again and any layout is accepted. */
+int dpenv_release_policy_graphs(dpenv_handle h);
 /* Convenience forms (host pointers, F16, AUTO, null stream):
  * pi: obs_dim -> act_dim, v: obs_dim -> 1 (same hidden shape); log_std: host float[act_dim]; leak: hidden
  * leaky-relu slope (0.2 = tf.nn.leaky_relu default; 0 = relu).  Packs and uploads; may be called again after
@@ -321,7 +364,9 @@ int dpenv_set_rng_counters(dpenv_handle h, const uint32_t* noise_ctr_in, const u
  * columns are then the command of the last step, not of the one before).  get fails with DPENV_EINVAL while they are stale; set is for
  * restoring a mid-episode checkpoint (after dpenv_set_state).  Whether a launch continues or rebuilds is decided on the host when
  * dpenv_policy_rollout is CALLED: inside a captured graph the first closed-loop launch keeps the decision made at capture time on
- * every replay (capture a graph that starts with a continuing launch after one such launch has run). */
+ * every replay (capture a graph that starts with a continuing launch after one such launch has run).  Likewise a dpenv_step RECORDED INTO A
+ * GRAPH before the first policy upload has "no policy in force" baked in (it does not write the columns): re-capture step graphs after the
+ * first upload if closed-loop launches are to continue from their observations. */
 int dpenv_get_obs_thrust(dpenv_handle h, float* out, dpenv_stream s);
 int dpenv_set_obs_thrust(dpenv_handle h, const float* in, dpenv_stream s);
 

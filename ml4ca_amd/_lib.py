@@ -19,8 +19,8 @@ ACT_LEAKY_RELU, ACT_TANH = 0, 1
 POLICY_F16, POLICY_F32, POLICY_F32_ACTOR = 0, 1, 2
 LAUNCH_AUTO, LAUNCH_ONE_WAVE, LAUNCH_TWO_WAVE = 0, 1, 2
 DONE_TERMINAL, DONE_TIMELIMIT, DONE_FAULT = 1, 2, 4
-NSTATE, NPARAM, MAX_CLASSES = 15, 32, 64
-ABI_VERSION = 3
+NSTATE, NPARAM, NPARAM_USED, MAX_CLASSES = 15, 32, 26, 64
+ABI_VERSION = 4
 
 # canonical state rows (dpenv.h DPENV_S_*)
 S = dict(N=0, E=1, PSI=2, U=3, V=4, R=5, REF_N=6, REF_E=7, REF_PSI=8,
@@ -39,7 +39,8 @@ class Config(C.Structure):
                 ('obs_layout', C.c_int32), ('obs_dtype', C.c_int32), ('current_enabled', C.c_int32),
                 ('seed', C.c_uint64), ('env_id_base', C.c_int64), ('reset_fraction', C.c_float),
                 ('hold_plant', C.c_int32), ('current_drift', C.c_int32), ('current_tau', C.c_float),
-                ('current_sigma_v', C.c_float), ('current_sigma_beta', C.c_float), ('reset_acts', C.c_int32), ('step_one_wave', C.c_int32)]
+                ('current_sigma_v', C.c_float), ('current_sigma_beta', C.c_float), ('reset_acts', C.c_int32), ('step_one_wave', C.c_int32),
+                ('per_env_lds', C.c_int32)]
 
 
 class StepIO(C.Structure):
@@ -84,6 +85,9 @@ SYMBOLS = {
     'dpenv_last_error': (C.c_char_p, [_VP]),
     'dpenv_set_reset_fraction': (C.c_int, [_VP, _F]),
     'dpenv_set_vessel_class': (C.c_int, [_VP, _VP, _VP]),
+    'dpenv_set_vessel_params': (C.c_int, [_VP, _VP, _VP]),
+    'dpenv_get_vessel_params': (C.c_int, [_VP, _VP, _VP]),
+    'dpenv_set_vessel_randomisation': (C.c_int, [_VP, C.POINTER(C.c_float), C.POINTER(C.c_float), _VP]),
     'dpenv_set_current': (C.c_int, [_VP, _VP, _VP, _VP]),
     'dpenv_set_current_present': (C.c_int, [_VP, _VP, _VP, _VP]),
     'dpenv_get_current': (C.c_int, [_VP, _VP, _VP, _VP]),
@@ -102,6 +106,8 @@ SYMBOLS = {
     'dpenv_set_rng_counters': (C.c_int, [_VP, _VP, _VP, _VP]),
     'dpenv_get_obs_thrust': (C.c_int, [_VP, _VP, _VP]),
     'dpenv_get_policy_launch': (C.c_int, [_VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    'dpenv_get_policy_launch_ex': (C.c_int, [_VP, C.POINTER(C.c_int32)]),
+    'dpenv_release_policy_graphs': (C.c_int, [_VP]),
     'dpenv_set_obs_thrust': (C.c_int, [_VP, _VP, _VP]),
     'dpenv_thrust_map': (C.c_int, [C.POINTER(C.c_float), _VP, _VP, _VP, _I32, _VP]),
     'dpenv_gae': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _F, _F, _VP, _VP, _VP]),

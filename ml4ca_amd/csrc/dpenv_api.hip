@@ -31,18 +31,28 @@ struct dpenv_s {
     float* cur_beta0;
     uint32_t* drift_ctr;
     int32_t* class_id;
+    float4* env_tab;        // per-env parameter blocks ET[ENV_GROUPS][env_stride] (dpenv_dev.h), always allocated
+    int env_stride;
+    float* rand_tab;        // device float[RAND_TAB_FLOATS]: nominal | relative half-range of the domain randomisation
+    float rand_host[RAND_TAB_FLOATS];   // its host image (the source of the stream-ordered upload must outlive the call)
+    float raw0[DPENV_NPARAM];           // public parameter vector of class 0 (the randomisation's default nominal hull)
+    bool per_env;           // the kernels take every env's vessel from env_tab (dpenv_set_vessel_params / dpenv_set_vessel_randomisation)
+    bool randomise;         // every reset re-draws the env's hull
     bool classes_assigned;
     bool current_set;
     uint32_t* noise_ctr;
     PolicyArgs pol;         // persistent part (weights, std) of the policy kernel arguments
     void* pol_buf;          // fragments | bias tiles | constants, as the kernels stage them: TWO images of pol_buf_bytes / 2 each,
     size_t pol_buf_bytes;   //   written alternately, so that an upload never touches the image the launches before it read
-    int pol_slot;           // image the NEXT upload writes (0 / 1)
+    int pol_slot;           // image the NEXT alternating upload writes (0 / 1)
+    int pol_cur;            // image the LAST upload wrote = the one launches read
     hipEvent_t pol_read[2]; // recorded behind the last launch that read image k: the upload that reuses it waits for that
     bool pol_read_valid[2];
     hipStream_t pol_read_stream[2];   // the stream that event was last recorded on (a reader on another stream chains behind it)
     int pol_pinned;         // >= 0: a captured graph reads this image (PolicyArgs.frags is baked into the graph's kernel nodes by value):
                             //   every later upload is written IN PLACE into it, so that a replay sees the latest weights
+    PolicyArgs pol_pin_layout;   // ... and the kernel node ALSO holds the image's layout and the launch form by value (nent, nblk, ks, n_hidden,
+                            //   act, leak, split, critic_f16, ws, ws_groups): what an in-place upload must not change (layout_differs)
     int n_cus;
     float* pol_raw;         // device staging of raw fp32 weights for the host-pointer form of set_policy
     size_t pol_raw_bytes;
@@ -246,9 +256,12 @@ extern "C" int dpenv_create(const dpenv_config* cfg, const float* vessel_params,
     h->n_classes = n_classes;
     h->device = dev;
     h->classes_assigned = false;
+    h->per_env = false;
+    h->randomise = false;
     h->current_set = false;
     h->pol_buf = nullptr; h->pol_buf_bytes = 0;
     h->pol_slot = 0;
+    h->pol_cur = 0;
     h->pol_read[0] = h->pol_read[1] = nullptr;
     h->pol_read_valid[0] = h->pol_read_valid[1] = false;
     h->pol_read_stream[0] = h->pol_read_stream[1] = nullptr;
@@ -273,6 +286,7 @@ extern "C" int dpenv_create(const dpenv_config* cfg, const float* vessel_params,
             delete h;
             return fail(nullptr, DPENV_EINVAL, "vessel class %d: %s", c, why.c_str());
         }
+        if (c == 0) std::memcpy(h->raw0, p, sizeof h->raw0);
     }
 
     const size_t n = (size_t)cfg->n_envs;
@@ -292,6 +306,8 @@ extern "C" int dpenv_create(const dpenv_config* cfg, const float* vessel_params,
     const size_t o_nc = off; off += npad * 4;
     const size_t o_s3 = off; off += npad * 16;
     const size_t o_ct = off; off += align_up(sizeof(VesselDev) * MAX_CLASSES, 256);
+    const size_t o_rt = off; off += align_up(sizeof(float) * RAND_TAB_FLOATS, 256);
+    const size_t o_et = off; off += npad * 16 * ENV_GROUPS;
     h->blob_bytes = off;
     void* blob = nullptr;
     e = hipMalloc(&blob, off);
@@ -318,6 +334,9 @@ extern "C" int dpenv_create(const dpenv_config* cfg, const float* vessel_params,
     h->drift_ctr = (uint32_t*)(b + o_dc);
     h->class_id = (int32_t*)(b + o_ci);
     h->noise_ctr = (uint32_t*)(b + o_nc);
+    h->env_tab = (float4*)(b + o_et);
+    h->env_stride = (int)npad;
+    h->rand_tab = (float*)(b + o_rt);
     a.class_tab = (const float*)(b + o_ct);
     a.n_classes = n_classes;
     a.v0 = tab[0];
@@ -429,6 +448,69 @@ static void bind_optional(dpenv_handle h, StepArgs& a)
     a.cur_beta0 = h->cur_beta0;
     a.drift_ctr = h->drift_ctr;
     a.class_id = h->class_id;
+    a.env_tab = h->per_env ? h->env_tab : nullptr;
+    a.env_stride = h->env_stride;
+    a.rand_tab = (h->per_env && h->randomise) ? h->rand_tab : nullptr;
+}
+
+// where the kernels take a lane's vessel from (dpenv_dev.h VES_*)
+static int vessel_source(dpenv_handle h)
+{
+    if (h->per_env) return h->randomise ? VES_ENV_RND : (h->cfg.per_env_lds ? VES_ENV_LDS : VES_ENV_VGPR);
+    return h->n_classes > 1 ? VES_CLASS_LDS : VES_ARGS;
+}
+
+static bool classes_missing(dpenv_handle h) { return !h->per_env && h->n_classes > 1 && !h->classes_assigned; }
+
+// ---- per-env parameter blocks ------------------------------------------------------------------------------------------------
+extern "C" int dpenv_set_vessel_params(dpenv_handle h, const float* params, dpenv_stream s)
+{
+    if (!h) return DPENV_EINVAL;
+    DeviceGuard dev_guard(h->device);
+    h->randomise = false;
+    if (!params) { h->per_env = false; return DPENV_OK; }              // back to the classes / the single class
+    HIP_TRY(h, dpenv_dev_launch_pack_env_vessels(params, (int64_t)h->cfg.n_envs, 1, h->env_tab, h->env_stride, h->cfg.n_envs, (hipStream_t)s));
+    h->per_env = true;
+    return DPENV_OK;
+}
+
+extern "C" int dpenv_get_vessel_params(dpenv_handle h, float* params_out, dpenv_stream s)
+{
+    if (!h || !params_out) return fail(h, DPENV_EINVAL, "dpenv_get_vessel_params: NULL argument");
+    if (!h->per_env) return fail(h, DPENV_EINVAL, "no per-env parameter blocks in force (dpenv_set_vessel_params / dpenv_set_vessel_randomisation)");
+    DeviceGuard dev_guard(h->device);
+    HIP_TRY(h, dpenv_dev_launch_unpack_env_vessels(h->env_tab, h->env_stride, params_out, h->cfg.n_envs, (hipStream_t)s));
+    return DPENV_OK;
+}
+
+extern "C" int dpenv_set_vessel_randomisation(dpenv_handle h, const float* nominal, const float* rel_range, dpenv_stream s)
+{
+    if (!h) return DPENV_EINVAL;
+    DeviceGuard dev_guard(h->device);
+    if (!rel_range) { h->randomise = false; return DPENV_OK; }         // hulls stay as they are, no more re-draws
+    const float* nom = nominal ? nominal : h->raw0;
+    for (int p = 0; p < DPENV_NPARAM; ++p) {
+        const float r = p < RAND_NPARAM ? rel_range[p] : 0.0f;
+        if (!std::isfinite(nom[p]) || !(r >= 0.0f && r < 1.0f))
+            return fail(h, DPENV_EINVAL, "parameter %d: nominal must be finite and the relative half-range in [0, 1)", p);
+        h->rand_host[p] = nom[p];
+        h->rand_host[32 + p] = r;
+    }
+    {
+        // every hull the draw can produce must be a vessel: the corner of the range with the lightest diagonal and the largest coupling
+        const double m11 = (double)nom[DPENV_P_M11] * (1.0 - rel_range[DPENV_P_M11]);
+        const double m22 = (double)nom[DPENV_P_M22] * (1.0 - rel_range[DPENV_P_M22]);
+        const double m33 = (double)nom[DPENV_P_M33] * (1.0 - rel_range[DPENV_P_M33]);
+        const double m23 = std::fabs((double)nom[DPENV_P_M23]) * (1.0 + rel_range[DPENV_P_M23]);
+        if (!(m11 > 0.0) || !(m22 > 0.0) || !(m22 * m33 - m23 * m23 > 0.0))
+            return fail(h, DPENV_EINVAL, "the range admits a mass matrix that is not positive definite");
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->rand_tab, h->rand_host, sizeof h->rand_host, hipMemcpyHostToDevice, (hipStream_t)s));
+    // until its first reset every env runs on the nominal hull
+    HIP_TRY(h, dpenv_dev_launch_pack_env_vessels(h->rand_tab, 1, 0, h->env_tab, h->env_stride, h->cfg.n_envs, (hipStream_t)s));
+    h->per_env = true;
+    h->randomise = true;
+    return DPENV_OK;
 }
 
 extern "C" int dpenv_reset(dpenv_handle h, const uint8_t* mask, const float* init, const float* ref, void* obs_out,
@@ -453,7 +535,7 @@ extern "C" int dpenv_step_ex(dpenv_handle h, const dpenv_step_io* io, dpenv_stre
     if (!io || io->struct_size != sizeof(dpenv_step_io)) return fail(h, DPENV_EINVAL, "dpenv_step_io ABI mismatch");
     if (!io->action || !io->obs || !io->reward || !io->done)
         return fail(h, DPENV_EINVAL, "action, obs, reward and done buffers are required");
-    if (h->n_classes > 1 && !h->classes_assigned)
+    if (classes_missing(h))
         return fail(h, DPENV_EINVAL, "n_classes > 1 but dpenv_set_vessel_class was never called");
     StepArgs a = h->args;
     bind_optional(h, a);
@@ -472,7 +554,7 @@ extern "C" int dpenv_step_ex(dpenv_handle h, const dpenv_step_io* io, dpenv_stre
     // MI355X); beyond that the extra waves queue behind env waves and the one-wave kernel is faster (98 304 envs: 6.92 vs 7.19 us, 1 M:
     // 34.7 vs 39.2; profiles/r04_reset_wave.txt)
     const int reset_wave = (!h->cfg.step_one_wave && (int64_t)h->cfg.n_envs <= (int64_t)256 * h->n_cus) ? 1 : 0;
-    HIP_TRY(h, dpenv_dev_launch_step(&a, h->mode, h->cfg.extended_state, h->n_classes > 1, reset_wave, (hipStream_t)s));
+    HIP_TRY(h, dpenv_dev_launch_step(&a, h->mode, h->cfg.extended_state, vessel_source(h), reset_wave, (hipStream_t)s));
     h->lag_valid = h->has_policy;
     return DPENV_OK;
 }
@@ -499,7 +581,7 @@ extern "C" int dpenv_rollout(dpenv_handle h, const dpenv_rollout_io* io, dpenv_s
     for (int k = 0; k < io->n_switch; ++k)
         if (io->switch_step[k] < 0 || io->switch_step[k] >= io->T || (k > 0 && io->switch_step[k] <= io->switch_step[k - 1]))
             return fail(h, DPENV_EINVAL, "switch_step must be strictly increasing within [0, T)");
-    if (h->n_classes > 1 && !h->classes_assigned)
+    if (classes_missing(h))
         return fail(h, DPENV_EINVAL, "n_classes > 1 but dpenv_set_vessel_class was never called");
     StepArgs a = h->args;
     bind_optional(h, a);
@@ -510,9 +592,12 @@ extern "C" int dpenv_rollout(dpenv_handle h, const dpenv_rollout_io* io, dpenv_s
     for (int k = 0; k < io->n_switch; ++k) ra.switch_step[k] = io->switch_step[k];
     // env wave + row wave while the chip has issue slots to spare (measured: 16 384 ... 98 304 envs 5-20 % faster, 131 072 equal, 262 144 and
     // above 10-15 % slower than one wave per 64 envs: profiles/r04_fused_two_wave.txt, r04_batch_sweep.txt)
-    const int two_wave = (!h->cfg.step_one_wave && (int64_t)h->cfg.n_envs <= (int64_t)384 * h->n_cus) ? 1 : 0;
-    HIP_TRY(h, dpenv_dev_launch_rollout(&a, &ra, h->mode, h->cfg.extended_state, h->n_classes > 1, two_wave, (hipStream_t)s));
-    h->lag_valid = true;                                   // the rollout kernels leave the thrust columns of their last observation in S3
+    // (the randomisation's instantiation needs 201 VGPRs: two waves per SIMD, i.e. up to 256 envs per CU)
+    const int two_wave = (!h->cfg.step_one_wave && (int64_t)h->cfg.n_envs <= (int64_t)(vessel_source(h) == VES_ENV_RND ? 256 : 384) * h->n_cus) ? 1 : 0;
+    HIP_TRY(h, dpenv_dev_launch_rollout(&a, &ra, h->mode, h->cfg.extended_state, vessel_source(h), two_wave, (hipStream_t)s));
+    // the rollout kernels leave the thrust columns of their last observation in S3 - with the extended state (without it no observation has
+    // thrust columns and S3 is never written: the flag keeps what it was)
+    if (h->cfg.extended_state) h->lag_valid = true;
     return DPENV_OK;
 }
 
@@ -600,7 +685,21 @@ extern "C" int dpenv_set_policy_desc(dpenv_handle h, const dpenv_policy_desc* d,
     // happened (pol_pinned) an alternating upload would leave every second set of weights invisible to the replays - so from then on
     // every eager upload goes in place into the pinned image, ordered behind the eager readers by their event and behind graph
     // replays by stream order (the caller replays and uploads on one stream, or orders them itself: dpenv.h).
-    const int slot = (!capturing && h->pol_pinned >= 0) ? h->pol_pinned : h->pol_slot;
+    //  An upload recorded INTO a graph after an image has been pinned goes into the pinned image as well: alternating there would
+    // pin the other image at the next captured launch, and the graphs captured first would stop seeing uploads.
+    const int slot = (h->pol_pinned >= 0) ? h->pol_pinned : h->pol_slot;
+    const int ws_new = d->launch_form == DPENV_LAUNCH_TWO_WAVE ? 1 : (d->launch_form == DPENV_LAUNCH_ONE_WAVE ? 0 : (fits_two ? 1 : 0));
+    const int groups_new = (d->activation == DPENV_ACT_LEAKY_RELU && (h->cfg.n_envs + 127) / 128 <= h->n_cus) ? 2 : 4;
+    if (h->pol_pinned >= 0) {
+        // the captured kernel nodes hold nent, nblk, ks, n_hidden, act, leak, split, critic_f16, ws, ws_groups BY VALUE next to the image's
+        // address: an in-place upload of another shape, arithmetic, activation or launch form would be read with the old layout - wrong
+        // weights and no error.  Refused; dpenv_release_policy_graphs() ends the pin once the graphs are gone.
+        const PolicyArgs& q = h->pol_pin_layout;
+        if (q.nent != nent || q.nblk != nblk || q.ks != ks || q.n_hidden != n_hidden || q.act != d->activation || q.leak != d->leak ||
+            q.split != split || q.critic_f16 != (d->precision == DPENV_POLICY_F32_ACTOR ? 1 : 0) || q.ws != ws_new || q.ws_groups != groups_new)
+            return fail(h, DPENV_EINVAL, "a captured graph reads the policy image with another layout (hidden shape, precision, activation, leak or launch "
+                                         "form differ): destroy the graphs and call dpenv_release_policy_graphs() before uploading this policy");
+    }
     if (!capturing && h->pol_read_valid[slot]) HIP_TRY(h, hipStreamWaitEvent((hipStream_t)s, h->pol_read[slot], 0));
     PackNet pn[2];
     const float* ls_dev = d->log_std;
@@ -660,13 +759,14 @@ extern "C" int dpenv_set_policy_desc(dpenv_handle h, const dpenv_policy_desc* d,
     pa.n_hidden = n_hidden;
     pa.leak = d->leak;
     // AUTO: the two-wave form where it exists and fits (the faster one), else one wave per 64 envs
-    pa.ws = d->launch_form == DPENV_LAUNCH_TWO_WAVE ? 1 : (d->launch_form == DPENV_LAUNCH_ONE_WAVE ? 0 : (fits_two ? 1 : 0));
+    pa.ws = ws_new;
     // two-wave geometry: 128-env workgroups (a SIMD per wave) while one round of them fits the chip, else 256-env workgroups;
     // tanh has the 256-env form only
-    pa.ws_groups = (d->activation == DPENV_ACT_LEAKY_RELU && (h->cfg.n_envs + 127) / 128 <= h->n_cus) ? 2 : 4;
+    pa.ws_groups = groups_new;
     h->pol_form = d->launch_form;
     h->has_policy = true;
-    h->pol_slot = slot ^ 1;                                  // "current" = the image just written (pinned or not)
+    h->pol_cur = slot;                                       // "current" = the image just written (pinned or not)
+    h->pol_slot = slot ^ 1;
     // host pointers: the caller's arrays (and the shared staging area) must be done with before this returns
     if (!d->device_pointers && !capturing) HIP_TRY(h, hipStreamSynchronize((hipStream_t)s));
     return DPENV_OK;
@@ -675,11 +775,12 @@ extern "C" int dpenv_set_policy_desc(dpenv_handle h, const dpenv_policy_desc* d,
 // behind every launch that reads the current image: the event an upload into that image waits for
 static int mark_policy_read(dpenv_handle h, dpenv_stream s)
 {
-    const int cur = h->pol_slot ^ 1;                        // the image the last upload wrote
+    const int cur = h->pol_cur;                             // the image the last upload wrote
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing((hipStream_t)s, &cap);
     if (cap != hipStreamCaptureStatusNone) {
         h->pol_pinned = cur;                                // a graph now holds this image's address: uploads go in place from here on
+        h->pol_pin_layout = h->pol;                         // ... and its layout / launch form, by value
         return DPENV_OK;
     }
     if (!h->pol_read[cur] && hipEventCreateWithFlags(&h->pol_read[cur], hipEventDisableTiming) != hipSuccess) {
@@ -727,6 +828,26 @@ extern "C" int dpenv_get_policy_launch(dpenv_handle h, int32_t* two_wave_out, in
     return DPENV_OK;
 }
 
+extern "C" int dpenv_get_policy_launch_ex(dpenv_handle h, int32_t out[4])
+{
+    if (!h || !out) return fail(h, DPENV_EINVAL, "dpenv_get_policy_launch_ex: NULL argument");
+    if (!h->has_policy) return fail(h, DPENV_EINVAL, "dpenv_set_policy has not been called");
+    const PolicyArgs& pa = h->pol;
+    const int prec = !pa.split ? PREC_F16 : (pa.critic_f16 ? PREC_F32_ACTOR : PREC_F32);
+    out[0] = pa.ws ? 1 : 0;
+    out[1] = pa.ws ? 64 * pa.ws_groups : 256;
+    out[2] = !pa.ws ? 1 : ((pa.ws_groups == 2 && ((DPENV_WS_CRITIC_WAVE >> prec) & 1)) ? 3 : 2);      // waves per 64 envs (dpenv_policy_ws.h: go<>)
+    out[3] = prec;
+    return DPENV_OK;
+}
+
+extern "C" int dpenv_release_policy_graphs(dpenv_handle h)
+{
+    if (!h) return DPENV_EINVAL;
+    h->pol_pinned = -1;                                      // uploads alternate between the two images again
+    return DPENV_OK;
+}
+
 extern "C" int dpenv_policy_forward(dpenv_handle h, const float* obs, float* mu_out, float* v_out, int32_t n, dpenv_stream s)
 {
     if (!h) return DPENV_EINVAL;
@@ -767,7 +888,7 @@ extern "C" int dpenv_policy_rollout(dpenv_handle h, const dpenv_policy_rollout_i
         return fail(h, DPENV_EINVAL, "T > 0 and every output block are required");
     if (h->cfg.action_layout != DPENV_AOS || h->cfg.obs_layout != DPENV_AOS)
         return fail(h, DPENV_EINVAL, "policy rollout needs AOS layouts");
-    if (h->n_classes > 1 && !h->classes_assigned)
+    if (classes_missing(h))
         return fail(h, DPENV_EINVAL, "n_classes > 1 but dpenv_set_vessel_class was never called");
     if (io->n_switch < 0 || io->n_switch > DPENV_MAX_SWITCH || (io->n_switch > 0 && !io->refs))
         return fail(h, DPENV_EINVAL, "bad setpoint schedule");
@@ -789,6 +910,10 @@ extern "C" int dpenv_policy_rollout(dpenv_handle h, const dpenv_policy_rollout_i
 #ifdef DPENV_WS_SELFCHECK
     pa.dbg = g_selfcheck_buf;
 #endif
+    // the two-wave kernels carry the randomisation's hull re-draw in an instantiation of their own, built for the shipped training configuration
+    // (final / continuous angles / extended state, leaky-relu or relu networks); everything else runs the one-wave kernels while the
+    // randomisation is on - the same rows bit for bit, the draw a run-time switch there
+    if (a.rand_tab && pa.ws && !(h->mode == MODE_FINAL_CONT && h->cfg.extended_state && pa.act == DPENV_ACT_LEAKY_RELU)) pa.ws = 0;
     if (pa.split) HIP_TRY(h, dpenv_dev_launch_policy_rollout_x(&a, &pa, h->mode, h->cfg.extended_state, (hipStream_t)s));
     else HIP_TRY(h, dpenv_dev_launch_policy_rollout(&a, &pa, h->mode, h->cfg.extended_state, (hipStream_t)s));
     h->lag_valid = true;

@@ -35,6 +35,26 @@ struct VesselDev {
     float p[VD_COUNT];
 };
 
+// Per-ENV parameter blocks (dpenv_set_vessel_params / dpenv_set_vessel_randomisation; north_star: "per-env 3x3 mass / Coriolis /
+// damping blocks", SURVEY appendix D: domain randomisation).  One block = the VD_COUNT derived floats above + the raw m33 (so that the
+// public parameter vector can be read back) + 2 pad = ENV_GROUPS float4.  HBM layout float4 ET[ENV_GROUPS][stride] - group g of env i at
+// ET[g * stride + i], the same structure-of-float4-streams form as the state (S0..S3): a wave-level access is one coalesced 1 KiB
+// dwordx4 transaction.  128 B per env-step read by dpenv_step (SURVEY 8d accounts 3 x 9 x 4 = 108 B for it: 285 B per env-step).
+constexpr int VD_M33 = VD_COUNT;          // slot of the raw m33 in a per-env block
+constexpr int ENV_GROUPS = 8;
+constexpr int ENV_BLOCK_FLOATS = 4 * ENV_GROUPS;
+static_assert(VD_COUNT + 1 <= ENV_BLOCK_FLOATS, "per-env block: derived parameters + m33 must fit eight float4");
+constexpr int RAND_NPARAM = 26;           // public parameters DPENV_P_M11 .. DPENV_P_YUR (include/dpenv.h); slots 26..31 of the vector are reserved
+constexpr int RAND_TAB_FLOATS = 64;       // device table of the randomisation: [0..31] nominal public parameters, [32..63] relative half-ranges
+
+// where step_kernel takes a lane's vessel from (template argument VES)
+enum { VES_ARGS = 0,      // one class: kernel arguments (SGPRs)
+       VES_CLASS_LDS = 1, // vessel classes: [class][param] table staged into LDS as [param][class]
+       VES_ENV_VGPR = 2,  // per-env blocks: eight coalesced float4 loads per lane straight into registers
+       VES_ENV_LDS = 3,   // per-env blocks: LDS-DMA (global_load_lds_dwordx4) into a [group][lane] image, read back when needed (the A/B of SURVEY 7)
+       VES_ENV_RND = 4 }; // VES_ENV_VGPR + the domain randomisation's hull re-draw compiled into the reset paths (its own instantiation: the draw's
+                          //   four Philox blocks cost the register allocation of the other forms 15-70 VGPRs when they share the code)
+
 struct StepArgs {
     // library-owned state streams (see dpenv_kernels.hip header)
     float4* S0;
@@ -82,6 +102,11 @@ struct StepArgs {
     int32_t reset_acts;       // customEnv.py:179-188: previous thrust drawn at reset
     uint32_t* noise_ctr;      // per-env count of exploration-noise draws made so far (in-kernel sampling)
     float4* S3;               // thrust columns (o[6..8]) of the observation the LAST closed-loop launch ended with, see PolicyArgs.use_lag
+    float4* env_tab;          // per-env parameter blocks ET[ENV_GROUPS][env_stride], NULL = classes / the single class (written by the kernels only
+                              //   when the randomisation re-draws a hull)
+    int32_t env_stride;
+    const float* rand_tab;    // domain randomisation on: device float[RAND_TAB_FLOATS] (nominal | relative half-range); every reset - explicit,
+                              //   auto, reset_at_end - re-draws the env's hull for the new episode, Philox keyed (seed; global env id, episode)
 };
 
 // fused T-step rollout (dpenv_rollout)
@@ -144,6 +169,11 @@ struct PackNet {
     int32_t n_layers, in_dim, H, out_dim;
 };
 
+// which arithmetics get a critic wave of their own (ROLES = 3) in the 128-env geometry of the two-wave closed loop: bit 0 f16, bit 1 all
+// exact, bit 2 exact actor (dpenv_policy_ws.h has the measurements); here because dpenv_get_policy_launch_ex reports the resolved form
+#ifndef DPENV_WS_CRITIC_WAVE
+#define DPENV_WS_CRITIC_WAVE 6
+#endif
 constexpr int POLICY_WS_MAILBOX_BYTES = 4 * (64 * 9 * 5 + 64 * 4 + 64) * 4;   // two-wave form: four groups of mailboxes
 constexpr int POLICY_WS_MAILBOX_X_BYTES = 4 * (64 * 9 * 4 + 64 * 4 + 64) * 4; // the same for the split arithmetics (no row staging area)
 constexpr int PREC_F16 = 0, PREC_F32 = 1, PREC_F32_ACTOR = 2;                 // = DPENV_POLICY_* of include/dpenv.h
@@ -168,9 +198,14 @@ hipError_t dpenv_dev_launch_policy_forward(const dpenv::PolicyArgs* pa, int od, 
                                            float* v, int n, hipStream_t s);
 hipError_t dpenv_dev_launch_policy_rollout(const dpenv::StepArgs* a, const dpenv::PolicyArgs* pa, int mode, int ext,
                                            hipStream_t s);
-hipError_t dpenv_dev_launch_rollout(const dpenv::StepArgs* a, const dpenv::RolloutArgs* ra, int mode, int ext, int per_class, int two_wave,
+hipError_t dpenv_dev_launch_rollout(const dpenv::StepArgs* a, const dpenv::RolloutArgs* ra, int mode, int ext, int ves, int two_wave,
                                     hipStream_t s);
-hipError_t dpenv_dev_launch_step(const dpenv::StepArgs* a, int mode, int ext, int per_class, int reset_wave, hipStream_t s);
+// ves: VES_* (where the vessel of a lane comes from)
+hipError_t dpenv_dev_launch_step(const dpenv::StepArgs* a, int mode, int ext, int ves, int reset_wave, hipStream_t s);
+// raw public parameters -> per-env blocks: raw[p * p_stride + i * i_stride] (SoA block: p_stride = n, i_stride = 1; one vector for every env:
+// p_stride = 1, i_stride = 0); and back (out[p * n + i])
+hipError_t dpenv_dev_launch_pack_env_vessels(const float* raw, int64_t p_stride, int64_t i_stride, float4* tab, int stride, int n, hipStream_t s);
+hipError_t dpenv_dev_launch_unpack_env_vessels(const float4* tab, int stride, float* out, int n, hipStream_t s);
 hipError_t dpenv_dev_launch_reset(const dpenv::StepArgs* a, int mode, int ext, const uint8_t* mask, const float* init,
                                   const float* ref, hipStream_t s);
 hipError_t dpenv_dev_launch_get_state(const dpenv::StepArgs* a, float* st, int32_t* ctr, hipStream_t s);

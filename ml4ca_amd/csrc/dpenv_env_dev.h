@@ -188,6 +188,181 @@ __device__ __forceinline__ Vessel vessel_from_table(const float* tab, int cls)
     return vessel_from_args(d);
 }
 
+// ---- per-env parameter blocks (dpenv_dev.h: float4 ET[ENV_GROUPS][stride]) ------------------------------------------------
+// A lane's own block straight into registers: eight coalesced 16-byte loads (1 KiB per wave-instruction), no LDS.
+__device__ __forceinline__ Vessel vessel_from_env(const float4* tab, int stride, int il)
+{
+    VesselDev d;
+    float4 q[ENV_GROUPS];
+#pragma unroll
+    for (int g = 0; g < ENV_GROUPS; ++g) q[g] = tab[(int64_t)g * stride + il];
+#pragma unroll
+    for (int k = 0; k < VD_COUNT; ++k) {
+        const float4& v = q[k >> 2];
+        d.p[k] = (k & 3) == 0 ? v.x : (k & 3) == 1 ? v.y : (k & 3) == 2 ? v.z : v.w;
+    }
+    return vessel_from_args(d);
+}
+
+// The same block from an LDS image [group][lane] of float4 (ds_read_b128: a lane's 16 bytes, conflict-free)
+__device__ __forceinline__ Vessel vessel_from_env_lds(const float4* lds, int lane)
+{
+    VesselDev d;
+#pragma unroll
+    for (int g = 0; g < ENV_GROUPS; ++g) {
+        const float4 v = lds[g * 64 + lane];
+        if (4 * g + 0 < VD_COUNT) d.p[4 * g + 0] = v.x;
+        if (4 * g + 1 < VD_COUNT) d.p[4 * g + 1] = v.y;
+        if (4 * g + 2 < VD_COUNT) d.p[4 * g + 2] = v.z;
+        if (4 * g + 3 < VD_COUNT) d.p[4 * g + 3] = v.w;
+    }
+    return vessel_from_args(d);
+}
+
+// raw public parameters (DPENV_P_* order, include/dpenv.h) -> one per-env block: the SAME float operations in the same order as the
+// host's derive_vessel (dpenv_api.hip), so that an env given its class's parameters integrates with the
+// class path's constants bit for bit.  fp32 division is IEEE-correct here (no -ffast-math; hipcc's default correctly rounded divide).
+// A block that is not a vessel (mass matrix not positive definite, non-finite entries) becomes NaN: the env then reports
+// DPENV_DONE_FAULT at its first step instead of integrating garbage.
+__device__ __forceinline__ void derive_env_block(const float raw[RAND_NPARAM], float d[ENV_BLOCK_FLOATS])
+{
+    const float m11 = raw[0], m22 = raw[1], m23 = raw[2], m33 = raw[3];
+    const float fdet = m22 * m33 - m23 * m23;
+    d[VD_M11] = m11; d[VD_M22] = m22; d[VD_M23] = m23;
+    d[VD_INV11] = 1.0f / m11;
+    d[VD_I22] = m33 / fdet; d[VD_I23] = -m23 / fdet; d[VD_I33] = m22 / fdet;
+    d[VD_XU] = raw[4]; d[VD_XUU] = raw[5]; d[VD_YV] = raw[6]; d[VD_YVV] = raw[7]; d[VD_YR] = raw[8];
+    d[VD_NV] = raw[9]; d[VD_NR] = raw[10]; d[VD_NRR] = raw[11];
+    d[VD_NUV] = raw[24]; d[VD_YUR] = raw[25];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        d[VD_KF + k] = raw[12 + k]; d[VD_KR + k] = raw[15 + k]; d[VD_LX + k] = raw[18 + k]; d[VD_LY + k] = raw[21 + k];
+    }
+    d[VD_M33] = m33;
+#pragma unroll
+    for (int k = VD_M33 + 1; k < ENV_BLOCK_FLOATS; ++k) d[k] = 0.0f;
+    float chk = 0.0f;
+#pragma unroll
+    for (int k = 0; k < RAND_NPARAM; ++k) chk += raw[k];
+    const bool ok = (m11 > 0.0f) && (m22 > 0.0f) && (fdet > 0.0f) && (fabsf(chk) <= 3.0e38f);
+    if (!ok) {
+#pragma unroll
+        for (int k = 0; k < ENV_BLOCK_FLOATS; ++k) d[k] = __builtin_nanf("");
+    }
+}
+
+__device__ __forceinline__ void store_env_block(float4* tab, int stride, int i, const float d[ENV_BLOCK_FLOATS])
+{
+#pragma unroll
+    for (int g = 0; g < ENV_GROUPS; ++g) tab[(int64_t)g * stride + i] = make_float4(d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]);
+}
+
+// Domain randomisation: the hull of episode `episode` of env `gid`.  Public parameter p = nominal[p] x (1 + range[p] u),
+// u uniform in [-1, 1) with 16 bits (steps of 2^-15: every operation up to the product is exact or a single rounding), from four
+// Philox4x32-10 blocks keyed by the seed with counter (global env id, episode, tag 0x48000000 | block): a pure function of the env and
+// of its episode, like the pose sample (tags 0, 1) and the reset thrust (tag 2) - so a sharded run draws the hulls of a single-process run.
+// A parameter's 16 bits are half (q & 1) of word (q & 7) >> 1 of block q >> 3, q = its SLOT: the parameters are numbered in the order
+// of the packed block (m11 m22 m23 m33 Xu | Xuu Yv Yvv Yr Nv Nr Nrr Nuv | Yur Kf Kr lx_bow | lx_port lx_star ly), so that Philox block b
+// yields exactly float4 groups 2b and 2b + 1 of the block: the draw is STREAMED - one Philox block, eight parameters, two groups handed
+// to `emit(g, float4)` - and never holds more than a dozen values (a reset sits inside kernels that have no registers to spare).
+// The slot table is part of the definition of the draw (include/dpenv.h, dpenv_set_vessel_randomisation).
+struct HullKey {            // what the draw needs of the kernel arguments
+    const float* rand_tab;
+    uint32_t seed_lo, seed_hi;
+};
+__device__ __forceinline__ HullKey hull_key(const StepArgs& a) { return HullKey{a.rand_tab, a.seed_lo, a.seed_hi}; }
+
+__device__ __forceinline__ float rand_param(const HullKey& a, const uint32_t w[4], int p, int q)
+{
+    const uint32_t h16 = (w[(q & 7) >> 1] >> (16 * (q & 1))) & 0xffffu;
+    const float u = (float)h16 * (1.0f / 32768.0f) - 1.0f;
+    const float sc = 1.0f + a.rand_tab[32 + p] * u;          // two roundings (multiply, add), never contracted: plain IEEE, reproducible on a host
+    return a.rand_tab[p] * sc;
+}
+
+template <class Emit>
+__device__ __forceinline__ void draw_env_groups(const HullKey& a, int64_t gid, uint32_t episode, Emit&& emit)
+{
+    const uint32_t g0 = (uint32_t)((uint64_t)gid & 0xffffffffu), g1 = (uint32_t)((uint64_t)gid >> 32);
+    const float nan = __builtin_nanf("");
+    uint32_t w[4];
+    float m33;
+    bool ok;
+    {
+        philox4x32_10(g0, g1, episode, 0x48000000u, a.seed_lo, a.seed_hi, w);
+        const float m11 = rand_param(a, w, 0, 0), m22 = rand_param(a, w, 1, 1), m23 = rand_param(a, w, 2, 2);
+        m33 = rand_param(a, w, 3, 3);
+        const float Xu = rand_param(a, w, 4, 4);
+        // the mass-matrix inverse with derive_env_block's operations (the range was checked on the host: every hull is a vessel;
+        // a non-finite nominal entry set behind the library's back still ends as NaN blocks, i.e. as DPENV_DONE_FAULT)
+        const float fdet = m22 * m33 - m23 * m23;
+        ok = (m11 > 0.0f) && (m22 > 0.0f) && (fdet > 0.0f);
+        emit(0, ok ? make_float4(m11, m22, m23, 1.0f / m11) : make_float4(nan, nan, nan, nan));
+        emit(1, ok ? make_float4(m33 / fdet, -m23 / fdet, m22 / fdet, Xu) : make_float4(nan, nan, nan, nan));
+    }
+    {
+        philox4x32_10(g0, g1, episode, 0x48000001u, a.seed_lo, a.seed_hi, w);
+        emit(2, make_float4(rand_param(a, w, 5, 8), rand_param(a, w, 6, 9), rand_param(a, w, 7, 10), rand_param(a, w, 8, 11)));        // Xuu Yv Yvv Yr
+        emit(3, make_float4(rand_param(a, w, 9, 12), rand_param(a, w, 10, 13), rand_param(a, w, 11, 14), rand_param(a, w, 24, 15)));   // Nv Nr Nrr Nuv
+    }
+    {
+        philox4x32_10(g0, g1, episode, 0x48000002u, a.seed_lo, a.seed_hi, w);
+        emit(4, make_float4(rand_param(a, w, 25, 16), rand_param(a, w, 12, 17), rand_param(a, w, 13, 18), rand_param(a, w, 14, 19)));  // Yur Kf
+        emit(5, make_float4(rand_param(a, w, 15, 20), rand_param(a, w, 16, 21), rand_param(a, w, 17, 22), rand_param(a, w, 18, 23)));  // Kr lx_bow
+    }
+    {
+        philox4x32_10(g0, g1, episode, 0x48000003u, a.seed_lo, a.seed_hi, w);
+        emit(6, make_float4(rand_param(a, w, 19, 24), rand_param(a, w, 20, 25), rand_param(a, w, 21, 26), rand_param(a, w, 22, 27)));  // lx_port lx_star ly_bow ly_port
+        emit(7, make_float4(rand_param(a, w, 23, 28), ok ? m33 : nan, 0.0f, 0.0f));                                                     // ly_star | raw m33
+    }
+}
+
+// group g of a packed block -> the fields of a Vessel (VD order, dpenv_dev.h)
+__device__ __forceinline__ void vessel_set_group(Vessel& v, int g, const float4& q)
+{
+    switch (g) {
+    case 0: v.m11 = q.x; v.m22 = q.y; v.m23 = q.z; v.inv11 = q.w; break;
+    case 1: v.i22 = q.x; v.i23 = q.y; v.i33 = q.z; v.Xu = q.w; break;
+    case 2: v.Xuu = q.x; v.Yv = q.y; v.Yvv = q.z; v.Yr = q.w; break;
+    case 3: v.Nv = q.x; v.Nr = q.y; v.Nrr = q.z; v.Nuv = q.w; break;
+    case 4: v.Yur = q.x; v.Kf[0] = q.y; v.Kf[1] = q.z; v.Kf[2] = q.w; break;
+    case 5: v.Kr[0] = q.x; v.Kr[1] = q.y; v.Kr[2] = q.z; v.lx[0] = q.w; break;
+    case 6: v.lx[1] = q.x; v.lx[2] = q.y; v.ly[0] = q.z; v.ly[1] = q.w; break;
+    default: v.ly[2] = q.x; break;
+    }
+}
+
+// a reset with the randomisation on: draw the new episode's hull group by group, into the table ...
+__device__ __forceinline__ void redraw_vessel_table(const StepArgs& a, int i, uint32_t episode)
+{
+    draw_env_groups(hull_key(a), a.env_id_base + i, episode, [&](int g, const float4& q) { a.env_tab[(int64_t)g * a.env_stride + i] = q; });
+}
+// ... and into the registers the launch runs on with
+__device__ __forceinline__ void redraw_vessel(const StepArgs& a, int i, uint32_t episode, Vessel& ve)
+{
+    draw_env_groups(hull_key(a), a.env_id_base + i, episode, [&](int g, const float4& q) {
+        a.env_tab[(int64_t)g * a.env_stride + i] = q;
+        vessel_set_group(ve, g, q);
+    });
+}
+// The two-wave closed-loop kernels run at the edge of the register file (243-256 VGPRs, dpenv_policy_ws.h).  Three ways of giving their
+// reset branch the hull draw behind a RUN-TIME switch were built and read off the ISA (round 5): inlined - 180-370 B of scratch per lane in
+// the hot loop; pre-drawn into a side table while the env wave waits for the actor - 476 B; a real function call - the 256-env f16 form
+// went from 18 scratch instructions to 86.  So there the randomisation is its own INSTANTIATION (template flag RND, the shipped training
+// configuration only: dpenv_policy_ws.h), and inside it the draw is a function call - the only one in the library: its registers are its
+// own, what it clobbers is saved around it inside the cold branch, and the caller re-reads the block from the table group by group.
+static __device__ __attribute__((noinline)) void redraw_vessel_table_call(const float* rand_tab, uint32_t seed_lo, uint32_t seed_hi, float4* env_tab,
+                                                                          int env_stride, int64_t gid, int i, uint32_t episode)
+{
+    draw_env_groups(HullKey{rand_tab, seed_lo, seed_hi}, gid, episode, [&](int g, const float4& q) { env_tab[(int64_t)g * env_stride + i] = q; });
+}
+__device__ __forceinline__ void redraw_vessel_cold(const StepArgs& a, int i, uint32_t episode, Vessel& ve)
+{
+    redraw_vessel_table_call(a.rand_tab, a.seed_lo, a.seed_hi, a.env_tab, a.env_stride, a.env_id_base + i, i, episode);
+#pragma unroll
+    for (int g = 0; g < ENV_GROUPS; ++g) vessel_set_group(ve, g, a.env_tab[(int64_t)g * a.env_stride + i]);
+}
+
 // SupervisedTau.py:42-83: tau = B(alpha) F, F_i = K_i n_i |n_i|
 // sc != nullptr: sin/cos of the port and starboard azimuths are already known (sc = {sin_p, cos_p, sin_s, cos_s})
 __device__ __forceinline__ void thrust_map(const Vessel& ve, const float n[3], const float al[3], float& tx, float& ty,

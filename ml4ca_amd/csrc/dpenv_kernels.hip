@@ -24,7 +24,9 @@
 // through LDS (odd row strides 7 / 9 / 5 / 3 -> conflict-free ds_read/ds_write) so that global
 // traffic stays fully coalesced.  Per-vessel-class parameter blocks (mass, damping, thruster
 // geometry) are staged in LDS as [param][class] when more than one class exists; with a single
-// class they arrive as kernel arguments (SGPRs).  No MFMA: this is batched 3x3 physics.
+// class they arrive as kernel arguments (SGPRs); per-ENV blocks (dpenv_set_vessel_params, domain
+// randomisation) are eight more float4 streams ET[g][i], loaded straight into registers (or, for the
+// A/B, by LDS-DMA into a [group][lane] image).  No MFMA: this is batched 3x3 physics.
 #include "dpenv_env_dev.h"
 
 namespace dpenv {
@@ -85,19 +87,38 @@ __device__ __forceinline__ void reset_from_lds(const float* lds, int lane, Env& 
     s.sn = lds[15 * 64 + lane]; s.cs = lds[16 * 64 + lane];
 }
 
-template <int MODE, bool EXT, bool PER_CLASS, bool RESETW = false>
+// VES (dpenv_dev.h VES_*): where a lane's vessel comes from - kernel arguments, the LDS-staged class table, or its own per-env block
+// (straight into registers, or through an LDS image filled by LDS-DMA: the A/B SURVEY section 7 asks for, bench.py `vessel_classes.per_env`).
+template <int MODE, bool EXT, int VES, bool RESETW = false>
 __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(const StepArgs a)
 {
     constexpr int A = ModeTraits<MODE>::A;
     constexpr int OD = EXT ? 9 : 6;
+    constexpr bool PER_CLASS = VES == VES_CLASS_LDS;
+    constexpr bool RND = VES == VES_ENV_RND;            // domain randomisation: a reset re-draws the hull
+    constexpr bool ENV_VGPR = VES == VES_ENV_VGPR || RND;
     static_assert(!RESETW || BLOCK == 64, "the reset wave pairs with ONE env wave");
+    static_assert(VES != VES_ENV_LDS || BLOCK == 64, "the LDS-DMA image is [group][lane] of one wave");
     __shared__ float lds_io[BLOCK * 9];
     __shared__ float lds_cls[PER_CLASS ? VD_COUNT * MAX_CLASSES : 1];
+    __shared__ float4 lds_pe[VES == VES_ENV_LDS ? ENV_GROUPS * 64 : 1];
     __shared__ float lds_rst[RESETW ? RESETW_FIELDS * 64 : 1];
+    __shared__ uint32_t lds_fin[RESETW ? 64 : 1];      // env wave -> reset wave: this env finished and is being re-drawn
 
     if (RESETW && threadIdx.x >= BLOCK) {
-        reset_wave<MODE>(a, lds_rst, threadIdx.x - BLOCK, blockIdx.x);
+        const int lane = threadIdx.x - BLOCK;
+        reset_wave<MODE>(a, lds_rst, lane, blockIdx.x);
+        // domain randomisation: the hull of the episode that would start now, drawn beside the plant loop as well; the env wave says
+        // which envs finished, and this wave - whose registers hold the block - puts it into the table, off the env wave's way
+        float4 hull[ENV_GROUPS];
+        const int i = blockIdx.x * 64 + lane;
+        if (RND)
+            draw_env_groups(hull_key(a), a.env_id_base + i, __float_as_uint(lds_rst[17 * 64 + lane]), [&](int g, const float4& q) { hull[g] = q; });
         __syncthreads();
+        if (RND && lds_fin[lane] != 0u) {
+#pragma unroll
+            for (int g = 0; g < ENV_GROUPS; ++g) a.env_tab[(int64_t)g * a.env_stride + i] = hull[g];
+        }
         return;
     }
     const int tid = threadIdx.x;
@@ -138,6 +159,16 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(const 
             lds_cls[p * a.n_classes + c] = a.class_tab[k];
         }
     }
+    Vessel ve_env;
+    if (ENV_VGPR) ve_env = vessel_from_env(a.env_tab, a.env_stride, il);                 // eight more 16-byte loads in the same burst
+    if (VES == VES_ENV_LDS) {
+        // LDS-DMA: eight global_load_lds_dwordx4, each a lane's 16 bytes -> lds_pe[g][lane] (wave-uniform base + lane x 16), no VGPR
+        // destination; landed when vmcnt reaches 0 (below, where the step needs its inputs anyway)
+#pragma unroll
+        for (int g = 0; g < ENV_GROUPS; ++g)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.env_tab + ((int64_t)g * a.env_stride + il)),
+                                             (__attribute__((address_space(3))) void*)(lds_pe + g * 64), 16, 0, 0);
+    }
     if (a.action_layout == LAYOUT_AOS) {
 #pragma unroll
         for (int j = 0; j < A; ++j) lds_io[j * BLOCK + tid] = act[j];
@@ -147,7 +178,12 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(const 
 #pragma unroll
         for (int k = 0; k < A; ++k) act[k] = lds_io[tid * A + k];
     }
-    const Vessel ve = PER_CLASS ? vessel_from_lds(lds_cls, a.n_classes, cls) : vessel_from_args(a.v0);
+    if (VES == VES_ENV_LDS) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the DMA writes have landed in this wave's image
+        __builtin_amdgcn_wave_barrier();
+    }
+    const Vessel ve = ENV_VGPR ? ve_env : VES == VES_ENV_LDS ? vessel_from_env_lds(lds_pe, tid)
+                    : PER_CLASS ? vessel_from_lds(lds_cls, a.n_classes, cls) : vessel_from_args(a.v0);
 
     StepOut out;
     env_step<MODE, EXT>(a, ve, s, act, a.new_ref != nullptr, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out);
@@ -162,7 +198,10 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(const 
     for (int k = 0; k < 9; ++k) o_next[k] = out.o[k];
 
     // ---- auto-reset (divergent, rare): the batched form of ppo.py:305-322 -------------------------
-    if (RESETW) __syncthreads();        // the reset wave's results are in LDS (it finished long ago: ~250 instructions against ~1 000)
+    if (RESETW) {
+        lds_fin[tid] = (a.auto_reset && out.d != 0u && live) ? 1u : 0u;
+        __syncthreads();                // the reset wave's results are in LDS (it finished long ago: ~250 instructions against ~1 000)
+    }
     if (a.auto_reset && out.d != 0u && live) {
         if (a.final_obs) {
             // scattered 36-byte rows, only from lanes that finished an episode
@@ -175,7 +214,10 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(const 
         const uint32_t ep = RESETW ? __float_as_uint(lds_rst[17 * 64 + tid]) : (uint32_t)a.episode[i];
         a.episode[i] = (int)(ep + 1u);
         if (RESETW) reset_from_lds<MODE>(lds_rst, tid, s, o_next);
-        else env_auto_reset<MODE>(a, s, a.env_id_base + i, ep, o_next);
+        else {
+            env_auto_reset<MODE>(a, s, a.env_id_base + i, ep, o_next);
+            if (RND) redraw_vessel_table(a, i, ep);            // domain randomisation: the new episode's hull (the reset wave does this in the two-wave form)
+        }
         rf_dirty = true;
     }
 
@@ -214,11 +256,12 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(const 
 //  observation / reward / done row written (69 B instead of 177 B).
 //  One wave per workgroup: the LDS transposes are wave-private, barriers are free.
 // =============================================================================================
-template <int MODE, bool EXT, bool PER_CLASS>
+template <int MODE, bool EXT, int VES>
 __global__ __launch_bounds__(RBLOCK) void rollout_kernel(const StepArgs a, const RolloutArgs ra)
 {
     constexpr int A = ModeTraits<MODE>::A;
     constexpr int OD = EXT ? 9 : 6;
+    constexpr bool PER_CLASS = VES == VES_CLASS_LDS, RND = VES == VES_ENV_RND, PER_ENV = VES == VES_ENV_VGPR || RND;
     __shared__ float lds_act[RBLOCK * 7];
     __shared__ float lds_obs[RBLOCK * 9];
     __shared__ float lds_cls[PER_CLASS ? VD_COUNT * MAX_CLASSES : 1];
@@ -248,8 +291,11 @@ __global__ __launch_bounds__(RBLOCK) void rollout_kernel(const StepArgs a, const
         }
         lds_order<RBLOCK>();
     }
-    Vessel ve = PER_CLASS ? vessel_from_lds(lds_cls, a.n_classes, cls) : vessel_from_args(a.v0);
-    if (!PER_CLASS) pin_vessel_in_vgprs(ve);
+    // per-env blocks (a.env_tab): a lane's own block, once per launch, straight into registers - for a T-step kernel the register file
+    // is the staging area
+    Vessel ve = PER_ENV ? vessel_from_env(a.env_tab, a.env_stride, il)
+                        : (PER_CLASS ? vessel_from_lds(lds_cls, a.n_classes, cls) : vessel_from_args(a.v0));
+    if (!PER_CLASS && !PER_ENV) pin_vessel_in_vgprs(ve);
     uint32_t episode = a.auto_reset ? (uint32_t)a.episode[il] : 0u;
     bool ep_dirty = false, rf_dirty = (MODE == MODE_FULL);
 
@@ -303,6 +349,7 @@ __global__ __launch_bounds__(RBLOCK) void rollout_kernel(const StepArgs a, const
         for (int k = 0; k < 9; ++k) o_next[k] = out.o[k];
         if (a.auto_reset && out.d != 0u && live) {
             env_auto_reset<MODE>(a, s, a.env_id_base + i, episode, o_next);
+            if (RND) redraw_vessel(a, i, episode, ve);            // domain randomisation: the new episode runs on a new hull
             ++episode; ep_dirty = true; rf_dirty = true;
         }
         lag[0] = o_next[6]; lag[1] = o_next[7]; lag[2] = o_next[8];
@@ -357,26 +404,32 @@ __global__ __launch_bounds__(RBLOCK) void rollout_kernel(const StepArgs a, const
 //  earn back a second wave's start-up and two hand-overs: 5.10 -> 5.19 us at 65 536 envs, profiles/r04_step_forms.txt.  Removed; dpenv_step
 //  keeps one wave per 64 envs, plus the reset wave when auto-reset is on.)
 // =============================================================================================
+// all lanes release their mailbox rows with a workgroup-scope fence, lane 0 stores the sequence word; the waiter acquires after its poll
+// loop (on gfx950: the same s_waitcnt lgkmcnt(0) as before, now outside the lane-0 branch, and nothing on the acquire side)
 __device__ __forceinline__ void mb_post(int* p, int v, int lane)
 {
-    if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void mb_wait(int* p, int v)
 {
-    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < v)
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < v)
         __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 constexpr int RW_REC = 18;              // re-draw record: N, E, psi | o[0..8] | pt[0..2] | sin psi, cos psi | (unused)
-template <int MODE, bool EXT, bool PER_CLASS>
+template <int MODE, bool EXT, int VES>
 __global__ __launch_bounds__(128) void rollout_ws_kernel(const StepArgs a, const RolloutArgs ra)
 {
     constexpr int A = ModeTraits<MODE>::A;
     constexpr int OD = EXT ? 9 : 6;
+    constexpr bool PER_CLASS = VES == VES_CLASS_LDS, RND = VES == VES_ENV_RND, PER_ENV = VES == VES_ENV_VGPR || RND;
     __shared__ float act_mb[2][64 * 7];          // a_t rows by step parity, [lane * A + k]
     __shared__ float post_mb[2][64 * 9];         // o_t+1 rows (pre-reset) by step parity, [lane * OD + k]: also the staged image of the row store
     __shared__ uint32_t done_mb[2][64];
     __shared__ float rec_mb[RW_REC * 64];        // the prepared re-draw, [field][lane]
+    __shared__ float hull_mb[RND ? ENV_BLOCK_FLOATS * 64 : 1]; // the prepared re-draw's hull (domain randomisation), [field][lane]; part of the record
     __shared__ float ang_mb[2 * 64];             // stern azimuths in force after the last step (MODE_FINAL_CONT: the row wave keeps them)
     __shared__ int seq[8];                       // [0] actions posted, [1] steps posted, [2] re-draw record version, [3] final
     __shared__ float lds_cls[PER_CLASS ? VD_COUNT * MAX_CLASSES : 1];
@@ -415,6 +468,7 @@ __global__ __launch_bounds__(128) void rollout_ws_kernel(const StepArgs a, const
         bool ep_dirty = false;
         int next_switch = 0, version = 0;
         float rec_o[9], rec_pt[3];
+        constexpr bool rnd = RND;               // domain randomisation: the record carries the hull of the episode that would start now
         // the re-draw an env would get if it finished NOW: (seed, global env id, episode) and the setpoint in force
         auto prepare = [&]() __attribute__((always_inline)) {
             Env s;
@@ -422,6 +476,11 @@ __global__ __launch_bounds__(128) void rollout_ws_kernel(const StepArgs a, const
             ResetDraw d;
             reset_draw<MODE>(a, a.env_id_base + i, episode, d);
             reset_apply<MODE>(a, s, d, rec_o);
+            if (rnd)
+                draw_env_groups(hull_key(a), a.env_id_base + i, episode, [&](int g, const float4& q) {
+                    hull_mb[(4 * g + 0) * 64 + lane] = q.x; hull_mb[(4 * g + 1) * 64 + lane] = q.y;
+                    hull_mb[(4 * g + 2) * 64 + lane] = q.z; hull_mb[(4 * g + 3) * 64 + lane] = q.w;
+                });
             rec_mb[0 * 64 + lane] = s.N; rec_mb[1 * 64 + lane] = s.E; rec_mb[2 * 64 + lane] = s.psi;
 #pragma unroll
             for (int k = 0; k < 9; ++k) rec_mb[(3 + k) * 64 + lane] = rec_o[k];
@@ -517,7 +576,15 @@ __global__ __launch_bounds__(128) void rollout_ws_kernel(const StepArgs a, const
                 store_rows<OD, 64>(ra.obs, (int64_t)t * step_stride_obs + blk_obs, step_stride_obs - blk_obs, a.obs_bf16, pm, lane);
             }
             if (any_reset) {
-                if (do_reset) { ++episode; ep_dirty = true; }
+                if (do_reset) {
+                    if (rnd) {                                               // the hull the env wave took from the record goes into the table
+#pragma unroll
+                        for (int g = 0; g < ENV_GROUPS; ++g)
+                            a.env_tab[(int64_t)g * a.env_stride + i] = make_float4(hull_mb[(4 * g + 0) * 64 + lane], hull_mb[(4 * g + 1) * 64 + lane],
+                                                                                   hull_mb[(4 * g + 2) * 64 + lane], hull_mb[(4 * g + 3) * 64 + lane]);
+                    }
+                    ++episode; ep_dirty = true;
+                }
                 prepare();                                                   // lanes whose episode did not move re-make the same record
             }
             look_ahead(t + 1);
@@ -545,8 +612,9 @@ __global__ __launch_bounds__(128) void rollout_ws_kernel(const StepArgs a, const
         if (a.current_drift) { vc0 = a.cur_vc0[il]; beta0 = a.cur_beta0[il]; cur.ctr = a.drift_ctr[il]; }
         current_components(cur);
     }
-    Vessel ve = PER_CLASS ? vessel_from_lds(lds_cls, a.n_classes, cls) : vessel_from_args(a.v0);
-    if (!PER_CLASS) pin_vessel_in_vgprs(ve);
+    Vessel ve = PER_ENV ? vessel_from_env(a.env_tab, a.env_stride, il)
+                        : (PER_CLASS ? vessel_from_lds(lds_cls, a.n_classes, cls) : vessel_from_args(a.v0));
+    if (!PER_CLASS && !PER_ENV) pin_vessel_in_vgprs(ve);
     bool rf_dirty = (MODE == MODE_FULL);
     int next_switch = 0, need = 1;               // re-draw record version this wave may read: 1 + setpoint switches so far + re-draw events so far
     for (int t = 0; t < ra.T; ++t) {
@@ -577,6 +645,12 @@ __global__ __launch_bounds__(128) void rollout_ws_kernel(const StepArgs a, const
             if (do_reset) {
                 float o_new[9];
                 reset_from_lds<MODE>(rec_mb, lane, s, o_new);
+                if (RND) {                                                   // the record's hull (the row wave keeps the table)
+                    VesselDev hd;
+#pragma unroll
+                    for (int k = 0; k < VD_COUNT; ++k) hd.p[k] = hull_mb[k * 64 + lane];
+                    ve = vessel_from_args(hd);
+                }
                 rf_dirty = true;
             }
             ++need;
@@ -616,7 +690,7 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(const StepArgs a, const ui
         float eta[3], nu[3], pt[3] = {0.0f, 0.0f, 0.0f};
         // the episode counter advances with every reset that consumes random numbers (sampled pose, or drawn thrust)
         const uint32_t ep = (uint32_t)a.episode[i];
-        if (!init || a.reset_acts) a.episode[i] = (int)(ep + 1u);
+        if (!init || a.reset_acts || a.rand_tab) a.episode[i] = (int)(ep + 1u);
         if (init) {
             // explicit **init (ENV:141,152,159-161); the 50 held sub-steps (ENV:164-167) keep it in place
             for (int k = 0; k < 3; ++k) { eta[k] = init[(int64_t)k * n + i]; nu[k] = init[(int64_t)(3 + k) * n + i]; }
@@ -635,6 +709,7 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(const StepArgs a, const ui
         // the lagged thrust columns a closed-loop launch starts from (PolicyArgs.use_lag): a new episode's observation carries the
         // reset's own previous thrust (ENV:190,196-205) - written per env, so that a MASKED reset leaves the other envs' lag alone
         a.S3[i] = make_float4(pt[0] * 0.01f, pt[1] * 0.01f, pt[2] * 0.01f, 0.0f);
+        if (a.rand_tab) redraw_vessel_table(a, i, ep);      // domain randomisation: every reset starts its episode on a freshly drawn hull
     }
     if (a.obs) {
         const float pt[3] = {s2.x, s2.y, s2.z};
@@ -679,6 +754,41 @@ __global__ __launch_bounds__(BLOCK) void set_state_kernel(const StepArgs a, cons
     }
     if (ctr) { s2.w = __int_as_float(ctr[i]); a.episode[i] = ctr[n + i]; }
     a.S2[i] = s2;
+}
+
+// ---- per-env parameter blocks: public parameter vectors <-> the packed float4 streams (dpenv_set / get_vessel_params) -------------
+__global__ __launch_bounds__(BLOCK) void pack_env_vessels_kernel(const float* raw, int64_t p_stride, int64_t i_stride, float4* tab, int stride, int n)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float r[RAND_NPARAM], d[ENV_BLOCK_FLOATS];
+#pragma unroll
+    for (int p = 0; p < RAND_NPARAM; ++p) r[p] = raw[p * p_stride + i * i_stride];
+    derive_env_block(r, d);
+    store_env_block(tab, stride, i, d);
+}
+
+__global__ __launch_bounds__(BLOCK) void unpack_env_vessels_kernel(const float4* tab, int stride, float* out, int n)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float d[ENV_BLOCK_FLOATS];
+#pragma unroll
+    for (int g = 0; g < ENV_GROUPS; ++g) {
+        const float4 q = tab[(int64_t)g * stride + i];
+        d[4 * g] = q.x; d[4 * g + 1] = q.y; d[4 * g + 2] = q.z; d[4 * g + 3] = q.w;
+    }
+    float r[32];
+    r[0] = d[VD_M11]; r[1] = d[VD_M22]; r[2] = d[VD_M23]; r[3] = d[VD_M33];
+    r[4] = d[VD_XU]; r[5] = d[VD_XUU]; r[6] = d[VD_YV]; r[7] = d[VD_YVV]; r[8] = d[VD_YR];
+    r[9] = d[VD_NV]; r[10] = d[VD_NR]; r[11] = d[VD_NRR];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { r[12 + k] = d[VD_KF + k]; r[15 + k] = d[VD_KR + k]; r[18 + k] = d[VD_LX + k]; r[21 + k] = d[VD_LY + k]; }
+    r[24] = d[VD_NUV]; r[25] = d[VD_YUR];
+#pragma unroll
+    for (int p = RAND_NPARAM; p < 32; ++p) r[p] = 0.0f;
+#pragma unroll
+    for (int p = 0; p < 32; ++p) out[(int64_t)p * n + i] = r[p];
 }
 
 // ---- stateless force map (SupervisedTau.py:42-83) -------------------------------------------------
@@ -904,30 +1014,33 @@ __device__ double g_sum_partials[2 * SUM_MAXGRID];
 // =============================================================================================
 using namespace dpenv;
 
-template <int MODE>
-static hipError_t launch_step_mode(const StepArgs& a, bool ext, bool per_class, bool reset_wave, hipStream_t s)
+template <int MODE, int VES>
+static hipError_t launch_step_ves(const StepArgs& a, bool ext, bool reset_wave, hipStream_t s)
 {
     const dim3 grid((a.n + BLOCK - 1) / BLOCK), block(BLOCK);
     if (a.auto_reset && BLOCK == 64 && reset_wave) {
         // auto-reset on: a second wave per workgroup prepares the re-draws beside the plant loop (RESETW above)
         const dim3 block2(2 * BLOCK);
-        if (ext) {
-            if (per_class) hipLaunchKernelGGL((step_kernel<MODE, true, true, BLOCK == 64>), grid, block2, 0, s, a);
-            else hipLaunchKernelGGL((step_kernel<MODE, true, false, BLOCK == 64>), grid, block2, 0, s, a);
-        } else {
-            if (per_class) hipLaunchKernelGGL((step_kernel<MODE, false, true, BLOCK == 64>), grid, block2, 0, s, a);
-            else hipLaunchKernelGGL((step_kernel<MODE, false, false, BLOCK == 64>), grid, block2, 0, s, a);
-        }
+        if (ext) hipLaunchKernelGGL((step_kernel<MODE, true, VES, BLOCK == 64>), grid, block2, 0, s, a);
+        else hipLaunchKernelGGL((step_kernel<MODE, false, VES, BLOCK == 64>), grid, block2, 0, s, a);
         return hipGetLastError();
     }
-    if (ext) {
-        if (per_class) hipLaunchKernelGGL((step_kernel<MODE, true, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((step_kernel<MODE, true, false>), grid, block, 0, s, a);
-    } else {
-        if (per_class) hipLaunchKernelGGL((step_kernel<MODE, false, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((step_kernel<MODE, false, false>), grid, block, 0, s, a);
-    }
+    if (ext) hipLaunchKernelGGL((step_kernel<MODE, true, VES>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((step_kernel<MODE, false, VES>), grid, block, 0, s, a);
     return hipGetLastError();
+}
+
+template <int MODE>
+static hipError_t launch_step_mode(const StepArgs& a, bool ext, int ves, bool reset_wave, hipStream_t s)
+{
+    switch (ves) {
+    case VES_ARGS: return launch_step_ves<MODE, VES_ARGS>(a, ext, reset_wave, s);
+    case VES_CLASS_LDS: return launch_step_ves<MODE, VES_CLASS_LDS>(a, ext, reset_wave, s);
+    case VES_ENV_VGPR: return launch_step_ves<MODE, VES_ENV_VGPR>(a, ext, reset_wave, s);
+    case VES_ENV_LDS: return launch_step_ves<MODE, (BLOCK == 64 ? VES_ENV_LDS : VES_ENV_VGPR)>(a, ext, reset_wave, s);
+    case VES_ENV_RND: return launch_step_ves<MODE, VES_ENV_RND>(a, ext, reset_wave, s);
+    }
+    return hipErrorInvalidValue;
 }
 
 #ifdef DPENV_STEP_TRACE
@@ -937,52 +1050,71 @@ extern "C" int dpenv_debug_set_step_trace(void* p)      // device buffer of STEP
 }
 #endif
 
-extern "C" hipError_t dpenv_dev_launch_step(const StepArgs* a, int mode, int ext, int per_class, int reset_wave, hipStream_t s)
+extern "C" hipError_t dpenv_dev_launch_step(const StepArgs* a, int mode, int ext, int ves, int reset_wave, hipStream_t s)
 {
+    if (ves >= VES_ENV_VGPR && !a->env_tab) return hipErrorInvalidValue;
+    if (ves == VES_ENV_RND && !a->rand_tab) return hipErrorInvalidValue;
     switch (mode) {
-    case MODE_FULL: return launch_step_mode<MODE_FULL>(*a, ext, per_class, reset_wave != 0, s);
-    case MODE_SIMPLE: return launch_step_mode<MODE_SIMPLE>(*a, ext, per_class, reset_wave != 0, s);
-    case MODE_LIMITED: return launch_step_mode<MODE_LIMITED>(*a, ext, per_class, reset_wave != 0, s);
-    case MODE_FINAL_WRAP: return launch_step_mode<MODE_FINAL_WRAP>(*a, ext, per_class, reset_wave != 0, s);
-    case MODE_FINAL_CONT: return launch_step_mode<MODE_FINAL_CONT>(*a, ext, per_class, reset_wave != 0, s);
+    case MODE_FULL: return launch_step_mode<MODE_FULL>(*a, ext, ves, reset_wave != 0, s);
+    case MODE_SIMPLE: return launch_step_mode<MODE_SIMPLE>(*a, ext, ves, reset_wave != 0, s);
+    case MODE_LIMITED: return launch_step_mode<MODE_LIMITED>(*a, ext, ves, reset_wave != 0, s);
+    case MODE_FINAL_WRAP: return launch_step_mode<MODE_FINAL_WRAP>(*a, ext, ves, reset_wave != 0, s);
+    case MODE_FINAL_CONT: return launch_step_mode<MODE_FINAL_CONT>(*a, ext, ves, reset_wave != 0, s);
     }
     return hipErrorInvalidValue;
 }
 
-template <int MODE>
-static hipError_t launch_rollout_mode(const StepArgs& a, const RolloutArgs& ra, bool ext, bool per_class, bool two_wave, hipStream_t s)
+extern "C" hipError_t dpenv_dev_launch_pack_env_vessels(const float* raw, int64_t p_stride, int64_t i_stride, float4* tab, int stride, int n,
+                                                        hipStream_t s)
+{
+    hipLaunchKernelGGL(pack_env_vessels_kernel, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, raw, p_stride, i_stride, tab, stride, n);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t dpenv_dev_launch_unpack_env_vessels(const float4* tab, int stride, float* out, int n, hipStream_t s)
+{
+    hipLaunchKernelGGL(unpack_env_vessels_kernel, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, tab, stride, out, n);
+    return hipGetLastError();
+}
+
+template <int MODE, int VES>
+static hipError_t launch_rollout_ves(const StepArgs& a, const RolloutArgs& ra, bool ext, bool two_wave, hipStream_t s)
 {
     const dim3 grid((a.n + RBLOCK - 1) / RBLOCK), block(RBLOCK);
     if (two_wave) {
         const dim3 block2(128);
-        if (ext) {
-            if (per_class) hipLaunchKernelGGL((rollout_ws_kernel<MODE, true, true>), grid, block2, 0, s, a, ra);
-            else hipLaunchKernelGGL((rollout_ws_kernel<MODE, true, false>), grid, block2, 0, s, a, ra);
-        } else {
-            if (per_class) hipLaunchKernelGGL((rollout_ws_kernel<MODE, false, true>), grid, block2, 0, s, a, ra);
-            else hipLaunchKernelGGL((rollout_ws_kernel<MODE, false, false>), grid, block2, 0, s, a, ra);
-        }
+        if (ext) hipLaunchKernelGGL((rollout_ws_kernel<MODE, true, VES>), grid, block2, 0, s, a, ra);
+        else hipLaunchKernelGGL((rollout_ws_kernel<MODE, false, VES>), grid, block2, 0, s, a, ra);
         return hipGetLastError();
     }
-    if (ext) {
-        if (per_class) hipLaunchKernelGGL((rollout_kernel<MODE, true, true>), grid, block, 0, s, a, ra);
-        else hipLaunchKernelGGL((rollout_kernel<MODE, true, false>), grid, block, 0, s, a, ra);
-    } else {
-        if (per_class) hipLaunchKernelGGL((rollout_kernel<MODE, false, true>), grid, block, 0, s, a, ra);
-        else hipLaunchKernelGGL((rollout_kernel<MODE, false, false>), grid, block, 0, s, a, ra);
-    }
+    if (ext) hipLaunchKernelGGL((rollout_kernel<MODE, true, VES>), grid, block, 0, s, a, ra);
+    else hipLaunchKernelGGL((rollout_kernel<MODE, false, VES>), grid, block, 0, s, a, ra);
     return hipGetLastError();
 }
 
-extern "C" hipError_t dpenv_dev_launch_rollout(const StepArgs* a, const RolloutArgs* ra, int mode, int ext, int per_class, int two_wave,
+template <int MODE>
+static hipError_t launch_rollout_mode(const StepArgs& a, const RolloutArgs& ra, bool ext, int ves, bool two_wave, hipStream_t s)
+{
+    switch (ves) {
+    case VES_ARGS: return launch_rollout_ves<MODE, VES_ARGS>(a, ra, ext, two_wave, s);
+    case VES_CLASS_LDS: return launch_rollout_ves<MODE, VES_CLASS_LDS>(a, ra, ext, two_wave, s);
+    case VES_ENV_VGPR: case VES_ENV_LDS: return launch_rollout_ves<MODE, VES_ENV_VGPR>(a, ra, ext, two_wave, s);   // a T-step kernel's staging area is the register file
+    case VES_ENV_RND: return launch_rollout_ves<MODE, VES_ENV_RND>(a, ra, ext, two_wave, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+extern "C" hipError_t dpenv_dev_launch_rollout(const StepArgs* a, const RolloutArgs* ra, int mode, int ext, int ves, int two_wave,
                                                hipStream_t s)
 {
+    if (ves >= VES_ENV_VGPR && !a->env_tab) return hipErrorInvalidValue;
+    if (ves == VES_ENV_RND && !a->rand_tab) return hipErrorInvalidValue;
     switch (mode) {
-    case MODE_FULL: return launch_rollout_mode<MODE_FULL>(*a, *ra, ext, per_class, two_wave != 0, s);
-    case MODE_SIMPLE: return launch_rollout_mode<MODE_SIMPLE>(*a, *ra, ext, per_class, two_wave != 0, s);
-    case MODE_LIMITED: return launch_rollout_mode<MODE_LIMITED>(*a, *ra, ext, per_class, two_wave != 0, s);
-    case MODE_FINAL_WRAP: return launch_rollout_mode<MODE_FINAL_WRAP>(*a, *ra, ext, per_class, two_wave != 0, s);
-    case MODE_FINAL_CONT: return launch_rollout_mode<MODE_FINAL_CONT>(*a, *ra, ext, per_class, two_wave != 0, s);
+    case MODE_FULL: return launch_rollout_mode<MODE_FULL>(*a, *ra, ext, ves, two_wave != 0, s);
+    case MODE_SIMPLE: return launch_rollout_mode<MODE_SIMPLE>(*a, *ra, ext, ves, two_wave != 0, s);
+    case MODE_LIMITED: return launch_rollout_mode<MODE_LIMITED>(*a, *ra, ext, ves, two_wave != 0, s);
+    case MODE_FINAL_WRAP: return launch_rollout_mode<MODE_FINAL_WRAP>(*a, *ra, ext, ves, two_wave != 0, s);
+    case MODE_FINAL_CONT: return launch_rollout_mode<MODE_FINAL_CONT>(*a, *ra, ext, ves, two_wave != 0, s);
     }
     return hipErrorInvalidValue;
 }

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
         current_components(cur);
     }
     // single class: SGPR-resident (the VGPRs are needed by the MLP); classes: per lane from the table, once per launch
-    const Vessel ve = (a.n_classes > 1) ? vessel_from_table(a.class_tab, a.class_id[il]) : vessel_from_args(a.v0);
+    Vessel ve = launch_vessel_plain(a, il);                      // re-drawn with the episode when the randomisation is on
     uint32_t episode = a.auto_reset ? (uint32_t)a.episode[il] : 0u;
     bool ep_dirty = false, rf_dirty = (MODE == MODE_FULL);
     const PolicyConsts<A> pc = load_policy_consts<A>(pa);
@@ -189,6 +189,7 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
             }
             if (do_reset) {
                 env_auto_reset<MODE>(a, s, a.env_id_base + i, episode, o);
+                if (a.rand_tab) redraw_vessel_cold(a, i, episode, ve);    // domain randomisation: the new episode runs on a new hull
                 ++episode; ep_dirty = true; rf_dirty = true;
             }
         }
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
         if (__ballot(do_reset) != 0ull) {                       // wave-uniform: rare
             if (do_reset) {
                 env_auto_reset<MODE>(a, s, a.env_id_base + i, episode, o);
+                if (a.rand_tab) redraw_vessel_cold(a, i, episode, ve);    // domain randomisation: the new episode runs on a new hull
                 ++episode; ep_dirty = true; rf_dirty = true;
             }
             obs_to_frags<OD>(o, in0, in1);

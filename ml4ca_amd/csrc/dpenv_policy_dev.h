@@ -481,11 +481,17 @@ __device__ __forceinline__ float mean_action(const PolicyConsts<A>& c, const flo
     return logp;
 }
 
-// this lane's vessel: its class block from the table in HBM, or the single class of the kernel arguments; either way in
-// vector registers for the whole launch
+// this lane's vessel: its own per-env block (dpenv_set_vessel_params / domain randomisation), its class block from the table in HBM,
+// or the single class of the kernel arguments - loaded once per launch; the T-step kernels' staging area is the register file
+__device__ __forceinline__ Vessel launch_vessel_plain(const StepArgs& a, int il)
+{
+    if (a.env_tab) return vessel_from_env(a.env_tab, a.env_stride, il);
+    return (a.n_classes > 1) ? vessel_from_table(a.class_tab, a.class_id[il]) : vessel_from_args(a.v0);
+}
+// ... and pinned in vector registers for the whole launch
 __device__ __forceinline__ Vessel launch_vessel(const StepArgs& a, int il)
 {
-    Vessel ve = (a.n_classes > 1) ? vessel_from_table(a.class_tab, a.class_id[il]) : vessel_from_args(a.v0);
+    Vessel ve = launch_vessel_plain(a, il);
     pin_vessel_in_vgprs(ve);
     return ve;
 }

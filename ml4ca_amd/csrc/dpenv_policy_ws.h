@@ -42,17 +42,23 @@ __host__ __device__ constexpr int ws_images(int prec) { return prec == PREC_F16 
 
 // pair-level hand-over inside a workgroup: a sequence word in LDS, released by one wave and acquired by its partner.
 // Both waves of a pair belong to the same workgroup, so they are always co-resident; the waiter sleeps between polls.
+// Every lane's mailbox rows are released by a workgroup-scope fence that ALL lanes execute (the sequence word is stored by lane 0 alone);
+// the waiter acquires with a fence after its poll loop.  On gfx950 (waves of a workgroup share a CU, no tgsplit) the release fence is the
+// s_waitcnt lgkmcnt(0) that used to sit inside the lane-0 branch, the acquire fence emits nothing: same instructions, but ordered by the
+// memory model instead of by in-order LDS issue and the compiler's good will.
 __device__ __forceinline__ void ws_post(int* p, int v, int lane)
 {
-    if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void ws_wait(int* p, int v)
 {
 #ifndef DPENV_WS_POLL_SLEEP
 #define DPENV_WS_POLL_SLEEP 2      // x 64 cycles between polls (A/B'd in round 3: 0 / 1 / 2 / 4 within noise in both geometries)
 #endif
-    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < v)
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < v)
         __builtin_amdgcn_s_sleep(DPENV_WS_POLL_SLEEP);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 #ifdef DPENV_WS_PROFILE
 #define WS_WAIT_T(acc, p, v) do { const uint64_t t0_ = __builtin_amdgcn_s_memtime(); ws_wait(p, v); acc += __builtin_amdgcn_s_memtime() - t0_; } while (0)
@@ -73,7 +79,9 @@ __device__ __forceinline__ void ws_wait(int* p, int v)
 #else
 #define WS_EVAL(W_, B_, f0_, f1_) mlp_eval<KA>(W_, B_, pa.n_hidden, f0_, f1_, leak, outv)
 #endif
-template <int MODE, bool EXT, int KA, int ROLES, int PREC = PREC_F16, int GROUPS = 4>
+//  RND: the domain randomisation's hull re-draw compiled into the reset branch (instantiated for the shipped training configuration only -
+//  final variant, continuous angles, extended state, leaky-relu - see dpenv_ws_launch::pick and dpenv_env_dev.h redraw_vessel_cold).
+template <int MODE, bool EXT, int KA, int ROLES, int PREC = PREC_F16, int GROUPS = 4, bool RND = false>
 __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(const StepArgs a, const PolicyArgs pa)
 {
     constexpr int A = ModeTraits<MODE>::A;
@@ -294,7 +302,12 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
     float vc0 = 0.0f, beta0 = 0.0f;
     bool ep_dirty = false, rf_dirty = (MODE == MODE_FULL);
     float o[9];
-    const Vessel ve = launch_vessel(a, il);                                  // in VGPRs: this wave has them to spare
+    Vessel ve = launch_vessel(a, il);                                        // in VGPRs: this wave has them to spare; re-drawn with the episode
+                                                                             // when the randomisation is on
+    // With the randomisation compiled in, two waves per SIMD (GROUPS = 4: 256 registers) have no room for the 29 parameters ACROSS the step
+    // next to the re-draw: the block is re-read from the table at the top of every step instead (eight 16-byte loads, L2-resident, issued
+    // while this wave waits for the actor's answer) and a reset only rewrites the table.
+    constexpr bool VE_RELOAD = RND && (GROUPS == 4 || ROLES == 3);          // (the three-role form: a critic wave shares the env wave's SIMD)
     const PolicyConsts<A> pc = load_policy_consts<A>(pa);
     const bool draw = pa.noise == nullptr && pa.sample != 0;
     uint32_t nctr = draw ? a.noise_ctr[il] : 0u;
@@ -400,6 +413,7 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
             if (!M_NOISE) policy_noise<A>(a, a.env_id_base + i, nctr, xi);
             ++nctr;
         }
+        if constexpr (VE_RELOAD) ve = vessel_from_env(a.env_tab, a.env_stride, il);
         if (PREDRAW && __ballot(need_draw) != 0ull) {                        // wave-uniform; lanes whose episode did not move redraw the same values
             reset_draw<MODE>(a, a.env_id_base + i, episode, rdraw);
             need_draw = false;
@@ -507,6 +521,8 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
             if (do_reset) {
                 if constexpr (PREDRAW) { reset_apply<MODE>(a, s, rdraw, o); need_draw = true; }
                 else env_auto_reset<MODE>(a, s, a.env_id_base + i, episode, o);
+                if constexpr (VE_RELOAD) redraw_vessel_table_call(a.rand_tab, a.seed_lo, a.seed_hi, a.env_tab, a.env_stride, a.env_id_base + i, i, episode);
+                else if constexpr (RND) redraw_vessel_cold(a, i, episode, ve);   // domain randomisation: the new episode runs on a new hull
                 ++episode; ep_dirty = true; rf_dirty = true;
             }
         }
@@ -590,10 +606,8 @@ using namespace dpenv;
 // actor 7.4-7.7 -> 7.3-7.45 / 7.23 -> 7.01; f16 5.20 -> 5.50 / 4.76 -> 5.03 with row staging (116 B of scratch at the 256 registers two waves
 // on a SIMD leave), 5.27 -> 5.33 / 4.79 -> 4.92 without it (no scratch): the f16 step is its chain already - so the two split arithmetics
 // get the critic wave, f16 keeps two roles.
-#ifndef DPENV_WS_CRITIC_WAVE
-#define DPENV_WS_CRITIC_WAVE 6
-#endif
-template <int MODE, bool EXT, int KA, int PREC, int GROUPS>
+// (DPENV_WS_CRITIC_WAVE: dpenv_dev.h, default 6)
+template <int MODE, bool EXT, int KA, int PREC, int GROUPS, bool RND = false>
 static hipError_t go(const StepArgs& a, const PolicyArgs& pa, hipStream_t s)
 {
     constexpr int ROLES = (GROUPS == 2 && ((DPENV_WS_CRITIC_WAVE >> PREC) & 1)) ? 3 : 2;
@@ -601,11 +615,23 @@ static hipError_t go(const StepArgs& a, const PolicyArgs& pa, hipStream_t s)
     const size_t lds = (size_t)ws_images(PREC) * pa.nent * 16 + (size_t)2 * pa.nblk * 32 * 4 +
                        (size_t)GROUPS * ((((PREC == PREC_F16 && ROLES == 2) || (PREC == PREC_F32_ACTOR && DPENV_WS_STAGE_ACTOR)) ? WS_GROUP_FLOATS : WS_GROUP_FLOATS_X) +
                                          (ROLES == 3 ? 64 * 9 : 0)) * 4;
-    hipError_t e = hipFuncSetAttribute((const void*)policy_rollout_ws_kernel<MODE, EXT, KA, ROLES, PREC, GROUPS>,
+    hipError_t e = hipFuncSetAttribute((const void*)policy_rollout_ws_kernel<MODE, EXT, KA, ROLES, PREC, GROUPS, RND>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((policy_rollout_ws_kernel<MODE, EXT, KA, ROLES, PREC, GROUPS>), grid, dim3(64 * GROUPS * ROLES), lds, s, a, pa);
+    hipLaunchKernelGGL((policy_rollout_ws_kernel<MODE, EXT, KA, ROLES, PREC, GROUPS, RND>), grid, dim3(64 * GROUPS * ROLES), lds, s, a, pa);
     return hipGetLastError();
+}
+
+// the randomisation's instantiation exists for the shipped training configuration (train.py:47-54: final, continuous angles, extended
+// state) with leaky-relu / relu networks; dpenv_policy_rollout refuses the others while the randomisation is on (dpenv.h)
+template <int MODE, bool EXT, int KA, int PREC, int GROUPS>
+static hipError_t pick(const StepArgs& a, const PolicyArgs& pa, hipStream_t s)
+{
+    if (a.rand_tab) {
+        if constexpr (MODE == MODE_FINAL_CONT && EXT && KA < 16) return go<MODE, EXT, KA, PREC, GROUPS, true>(a, pa, s);
+        else return hipErrorNotSupported;
+    }
+    return go<MODE, EXT, KA, PREC, GROUPS, false>(a, pa, s);
 }
 
 template <int MODE, bool EXT, int PREC>
@@ -615,16 +641,16 @@ static hipError_t by_shape(const StepArgs& a, const PolicyArgs& pa, hipStream_t 
     const bool two = pa.ws_groups == 2;
 #ifdef DPENV_DEV_FAST
     if (ka != 5) return hipErrorInvalidValue;
-    return two ? go<MODE, EXT, 5, PREC, 2>(a, pa, s) : go<MODE, EXT, 5, PREC, 4>(a, pa, s);
+    return two ? pick<MODE, EXT, 5, PREC, 2>(a, pa, s) : pick<MODE, EXT, 5, PREC, 4>(a, pa, s);
 #else
     switch (ka) {
-    case 5: return two ? go<MODE, EXT, 5, PREC, 2>(a, pa, s) : go<MODE, EXT, 5, PREC, 4>(a, pa, s);
-    case 6: return two ? go<MODE, EXT, 6, PREC, 2>(a, pa, s) : go<MODE, EXT, 6, PREC, 4>(a, pa, s);
+    case 5: return two ? pick<MODE, EXT, 5, PREC, 2>(a, pa, s) : pick<MODE, EXT, 5, PREC, 4>(a, pa, s);
+    case 6: return two ? pick<MODE, EXT, 6, PREC, 2>(a, pa, s) : pick<MODE, EXT, 6, PREC, 4>(a, pa, s);
     }
     if constexpr (PREC == PREC_F16) {
         if (two) return hipErrorInvalidValue;
-        if (ka == 21) return go<MODE, EXT, 21, PREC, 4>(a, pa, s);
-        if (ka == 22) return go<MODE, EXT, 22, PREC, 4>(a, pa, s);
+        if (ka == 21) return pick<MODE, EXT, 21, PREC, 4>(a, pa, s);
+        if (ka == 22) return pick<MODE, EXT, 22, PREC, 4>(a, pa, s);
     }
     return hipErrorInvalidValue;
 #endif

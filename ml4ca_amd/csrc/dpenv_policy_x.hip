@@ -89,7 +89,7 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_x_kernel(const StepArgs
         if (a.current_drift) { vc0 = a.cur_vc0[il]; beta0 = a.cur_beta0[il]; cur.ctr = a.drift_ctr[il]; }
         current_components(cur);
     }
-    const Vessel ve = (a.n_classes > 1) ? vessel_from_table(a.class_tab, a.class_id[il]) : vessel_from_args(a.v0);
+    Vessel ve = launch_vessel_plain(a, il);                      // re-drawn with the episode when the randomisation is on
     uint32_t episode = a.auto_reset ? (uint32_t)a.episode[il] : 0u;
     bool ep_dirty = false, rf_dirty = (MODE == MODE_FULL);
     const PolicyConsts<A> pc = load_policy_consts<A>(pa);
@@ -160,6 +160,7 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_x_kernel(const StepArgs
             }
             if (do_reset) {
                 env_auto_reset<MODE>(a, s, a.env_id_base + i, episode, o);
+                if (a.rand_tab) redraw_vessel_cold(a, i, episode, ve);    // domain randomisation: the new episode runs on a new hull
                 ++episode; ep_dirty = true; rf_dirty = true;
             }
         }

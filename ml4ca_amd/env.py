@@ -16,6 +16,7 @@ PyTorch is plumbing here (device memory, streams); all env arithmetic runs in li
 """
 import ctypes as C
 import math
+import weakref
 
 import numpy as np
 
@@ -87,7 +88,7 @@ class BatchedRevoltEnv(object):
                  wrap_mode='reference', seed=0, env_id_base=0, obs_dtype='float32', current=False,
                  vessel_params=None, layout='aos', reset_fraction=0.8, time_limit=True, hold_plant=False,
                  current_drift=False, current_tau=100.0, current_sigma_v=0.02, current_sigma_beta=5.0 * math.pi / 180.0,
-                 n_steps=None, reset_acts=False, step_one_wave=False):
+                 n_steps=None, reset_acts=False, step_one_wave=False, per_env_lds=False):
         torch = _torch()
         if not torch.cuda.is_available():
             raise RuntimeError('BatchedRevoltEnv needs a ROCm device: the env.step path is a HIP kernel and has no CPU fallback')
@@ -147,6 +148,7 @@ class BatchedRevoltEnv(object):
         cfg.current_sigma_beta = float(current_sigma_beta)
         cfg.reset_acts = int(self.reset_actions)                     # drawn inside the reset kernels, ENV:179-188
         cfg.step_one_wave = int(bool(step_one_wave))                 # A/B switch: dpenv_step's re-draw on the env wave (dpenv.h)
+        cfg.per_env_lds = int(bool(per_env_lds))                     # A/B switch: per-env blocks through an LDS image in dpenv_step (dpenv.h)
         self.cfg = cfg
         self.layout = layout
         self.auto_reset = bool(auto_reset)
@@ -166,25 +168,47 @@ class BatchedRevoltEnv(object):
         oshape = (n, od) if layout == 'aos' else (od, n)
         self._obs = [torch.empty(oshape, dtype=self.obs_torch_dtype, device=self.device) for _ in range(2)]
         self._flip = 0
+        self._f32, self._u8 = torch.float32, torch.uint8
         self._rew = torch.empty(n, dtype=torch.float32, device=self.device)
         self._done = torch.empty(n, dtype=torch.uint8, device=self.device)
         self._final_obs = None
         self._io = _lib.StepIO()
         self._io.struct_size = C.sizeof(_lib.StepIO)
+        self._io_ref = C.byref(self._io)
+        self._ok = {}
+        self._dev_index = cfg.device
+        self._raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+        self._ashape, self._oshape = tuple(self.action_shape), tuple(self.obs_shape)
+        self._n1, self._r3, self._p4 = (n,), (3, n), (4, n)
+        self._step_ex = self.lib.dpenv_step_ex
 
     # -- plumbing -----------------------------------------------------------------------------
+    # What a Python `for` over step() pays per call besides the launch is this plumbing (bench.py `eager_loop`): the stream handle and
+    # the argument checks.  Both are kept cheap: the raw stream of the CURRENT stream context comes from torch's C binding where it
+    # has one (a graph capture's side stream included), and a tensor object that passed the checks once is recognised by identity (a
+    # weak reference, so a recycled id() cannot alias another tensor) and not checked again - shape, dtype, device and contiguity of a
+    # live tensor object do not change short of resize_() / set_().
     def _stream(self):
+        raw = self._raw_stream
+        if raw is not None:
+            return C.c_void_p(raw(self._dev_index))
         return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
 
     def _chk(self, t, shape, dtype, what):
-        torch = _torch()
         if t is None:
             return None
+        ok = self._ok.get(id(t))
+        if ok is not None and ok[0]() is t and ok[1] == shape and ok[2] is dtype:
+            return t
+        torch = _torch()
         if not (isinstance(t, torch.Tensor) and t.device == self.device and t.dtype == dtype
                 and tuple(t.shape) == tuple(shape) and t.is_contiguous()):
             raise ValueError('%s must be a contiguous %s tensor of shape %s on %s (got %s)' % (
                 what, dtype, tuple(shape), self.device,
                 (tuple(t.shape), t.dtype, t.device) if isinstance(t, torch.Tensor) else type(t)))
+        if len(self._ok) > 512:
+            self._ok.clear()
+        self._ok[id(t)] = (weakref.ref(t), tuple(shape), dtype)
         return t
 
     @staticmethod
@@ -240,28 +264,26 @@ class BatchedRevoltEnv(object):
         action: float32 [n, act_dim] (or [act_dim, n] with layout='soa'); new_ref: float32 [3, n], visible from
         the NEXT observation (ENV:131).  out: optional (obs, reward, done) tensors to write into (e.g. rows of a
         [T, n, .] rollout buffer); otherwise internal buffers are reused (obs is double-buffered)."""
-        torch = _torch()
-        n = self.n_envs
-        self._chk(action, self.action_shape, torch.float32, 'action')
-        new_ref = self._chk(new_ref, (3, n), torch.float32, 'new_ref')
+        f32, chk = self._f32, self._chk
+        chk(action, self._ashape, f32, 'action')
         if out is None:
             obs, rew, done = self._next_obs(), self._rew, self._done
         else:
             obs, rew, done = out
-            self._chk(obs, self.obs_shape, self.obs_torch_dtype, 'out[0]')
-            self._chk(rew, (n,), torch.float32, 'out[1]')
-            self._chk(done, (n,), torch.uint8, 'out[2]')
-        self._chk(reward_parts, (4, n), torch.float32, 'reward_parts')
-        self._chk(final_obs, self.obs_shape, self.obs_torch_dtype, 'final_obs')
+            chk(obs, self._oshape, self.obs_torch_dtype, 'out[0]')
+            chk(rew, self._n1, f32, 'out[1]')
+            chk(done, self._n1, self._u8, 'out[2]')
         io = self._io
         io.action = action.data_ptr()
-        io.new_ref = new_ref.data_ptr() if new_ref is not None else None
+        io.new_ref = chk(new_ref, self._r3, f32, 'new_ref').data_ptr() if new_ref is not None else None
         io.obs = obs.data_ptr()
         io.reward = rew.data_ptr()
         io.done = done.data_ptr()
-        io.reward_parts = reward_parts.data_ptr() if reward_parts is not None else None
-        io.final_obs = final_obs.data_ptr() if final_obs is not None else None
-        _lib.check(self.lib.dpenv_step_ex(self._h, C.byref(io), self._stream()), self._h)
+        io.reward_parts = chk(reward_parts, self._p4, f32, 'reward_parts').data_ptr() if reward_parts is not None else None
+        io.final_obs = chk(final_obs, self._oshape, self.obs_torch_dtype, 'final_obs').data_ptr() if final_obs is not None else None
+        rc = self._step_ex(self._h, self._io_ref, self._stream())
+        if rc:
+            _lib.check(rc, self._h)
         return obs, rew, done, {'None': 0}
 
     def rollout(self, actions, switch_steps=(), refs=None, out=None):
@@ -332,9 +354,11 @@ class BatchedRevoltEnv(object):
 
     def get_obs_thrust(self):
         """float32 [n, 4]: thrust columns of the observation the last closed-loop launch ended with (a mid-episode checkpoint needs
-        them: the observation lags the stored thrust command by one step, customEnv.py:196-205,126); after a full reset the new
-        episodes' own previous thrust / 100; None if the next launch would start from the state block alone (after step / rollout /
-        set_state, or a masked reset of a handle whose columns were not valid)."""
+        them: the observation lags the stored thrust command by one step, customEnv.py:196-205,126).  Every call that changes the state
+        keeps them: rollouts leave those of the last observation they returned, set_state those of an observation rebuilt from the state
+        (previous thrust / 100), a reset those of the envs it re-draws, step() those of the observation it returns while a policy is in
+        force.  None only while they are stale: after a step() WITHOUT a policy uploaded, or after a masked reset of a handle whose
+        columns were already stale - the next closed-loop launch then starts from the state block alone."""
         torch = _torch()
         t = torch.empty((self.n_envs, 4), dtype=torch.float32, device=self.device)
         rc = self.lib.dpenv_get_obs_thrust(self._h, self._ptr(t), self._stream())
@@ -368,6 +392,41 @@ class BatchedRevoltEnv(object):
         if int(class_id.min()) < 0 or int(class_id.max()) >= self.n_classes:
             raise ValueError('class ids must be in [0, %d)' % self.n_classes)
         _lib.check(self.lib.dpenv_set_vessel_class(self._h, self._ptr(class_id), self._stream()), self._h)
+
+    def set_vessel_params(self, params):
+        """Per-env hull / thruster parameters (dpenv_set_vessel_params): float32 [NPARAM, n] device tensor, row p = parameter
+        _lib.P[...] of every env (rows 26..31 ignored) - the constants the reference hard-codes for its one vessel
+        (qp_allocator.py:51-55,69-70; SupervisedTau.py:35-36,69-71) and the build-owned plant's mass / damping terms.  None returns to
+        the vessel classes / the single class given to the constructor."""
+        torch = _torch()
+        self._chk(params, (_lib.NPARAM, self.n_envs), torch.float32, 'params')
+        _lib.check(self.lib.dpenv_set_vessel_params(self._h, self._ptr(params), self._stream()), self._h)
+
+    def get_vessel_params(self):
+        """float32 [NPARAM, n]: the per-env parameter vectors in force (set explicitly, or drawn by the randomisation)."""
+        torch = _torch()
+        out = torch.empty((_lib.NPARAM, self.n_envs), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.dpenv_get_vessel_params(self._h, self._ptr(out), self._stream()), self._h)
+        return out
+
+    def set_vessel_randomisation(self, rel_range, nominal=None):
+        """Domain randomisation through the reset path (dpenv_set_vessel_randomisation): every reset starts its episode on a hull with
+        parameter p = nominal[p] * (1 + rel_range[p] * u), u ~ U[-1, 1), keyed (seed; global env id, episode).  rel_range: a float (the
+        same relative half-range for all 26 parameters), a length-NPARAM sequence, or None to stop re-drawing; nominal: a parameter
+        vector, default class 0."""
+        if rel_range is None:
+            _lib.check(self.lib.dpenv_set_vessel_randomisation(self._h, None, None, self._stream()), self._h)
+            return
+        rr = np.zeros(_lib.NPARAM, np.float32)
+        if np.isscalar(rel_range):
+            rr[:_lib.NPARAM_USED] = float(rel_range)
+        else:
+            rr[:] = np.asarray(rel_range, np.float32).reshape(_lib.NPARAM)
+        nom = None
+        if nominal is not None:
+            nom_np = np.ascontiguousarray(np.asarray(nominal, np.float32).reshape(_lib.NPARAM))
+            nom = nom_np.ctypes.data_as(C.POINTER(C.c_float))
+        _lib.check(self.lib.dpenv_set_vessel_randomisation(self._h, nom, rr.ctypes.data_as(C.POINTER(C.c_float)), self._stream()), self._h)
 
     def render(self):
         pass   # ENV:246-247
@@ -472,7 +531,10 @@ class Revolt(object):
         b = self._benv
         if b.obs_torch_dtype != torch.float32:
             raise ValueError('the single-env adapter returns float64 observations made from float32 rows')
-        self._np_act[...] = np.asarray(action, dtype=np.float32).reshape(b.action_shape)
+        a = np.asarray(action, dtype=np.float32)
+        if a.size != b.num_actions:
+            raise ValueError('action must have %d elements for the %s env (got shape %s)' % (b.num_actions, b.name, a.shape))
+        self._np_act[...] = a.reshape(b.action_shape)
         self._sio.new_ref = None
         if new_ref is not None:
             self._np_ref[...] = np.asarray(new_ref, dtype=np.float32).reshape(3, 1)

@@ -25,8 +25,10 @@ class ActorCritic(object):
         """activation: the reference's --activation choices (train.py:24,31): 'leaky' (slope `leak`, default 0.2 as
         tf.nn.leaky_relu), 'relu' (= leaky with slope 0) or 'tanh'."""
         torch = _torch()
-        assert len(set(hidden_sizes)) == 1 and 1 <= len(hidden_sizes) <= 4, 'equal hidden widths, 1..4 hidden layers'
-        assert activation in ('leaky', 'relu', 'tanh'), activation
+        if not (len(set(hidden_sizes)) == 1 and 1 <= len(hidden_sizes) <= 4):
+            raise ValueError('equal hidden widths, 1..4 hidden layers (got %r)' % (tuple(hidden_sizes),))
+        if activation not in ('leaky', 'relu', 'tanh'):
+            raise ValueError("activation must be 'leaky', 'relu' or 'tanh' (got %r)" % (activation,))
         if activation == 'relu':
             leak = 0.0
         self.activation = activation
@@ -93,7 +95,11 @@ class ActorCritic(object):
         desc = tf_graph.describe_actor_critic(g)
         act, alpha = tf_graph.hidden_activation(desc)
         for net in ('pi', 'v'):                            # the shape this library evaluates: dense stacks, no activation behind the last layer
-            assert all(len(l['ops']) == 3 for l in desc[net][:-1]) and desc[net][-1]['ops'] == ['MatMul', 'BiasAdd'], desc[net]
+            for l in desc[net][:-1]:
+                if len(l['ops']) != 3:
+                    raise ValueError('unsupported saved graph: hidden layer %r is %r, expected MatMul -> BiasAdd -> activation' % (l['layer'], l['ops']))
+            if desc[net][-1]['ops'] != ['MatMul', 'BiasAdd']:
+                raise ValueError('unsupported saved graph: an activation (%r) follows the last layer %r' % (desc[net][-1]['ops'], desc[net][-1]['layer']))
         ac = cls.from_tensors(read_bundle(os.path.join(model_dir, 'variables', 'variables')), leak=float(np.float32(alpha)), device=device,
                               activation=act)
         ac.graph = desc
@@ -188,6 +194,20 @@ def policy_launch_form(env):
     tw, epw = C.c_int32(0), C.c_int32(0)
     _lib.check(env.lib.dpenv_get_policy_launch(env._h, C.byref(tw), C.byref(epw)), env._h)
     return ('two_wave' if tw.value else 'one_wave'), int(epw.value)
+
+
+def policy_launch_info(env):
+    """dict(two_wave, envs_per_workgroup, waves_per_64_envs, precision) of the uploaded policy as the LIBRARY resolved it
+    (dpenv_get_policy_launch_ex): waves 1 = one-wave form, 2 = env + network wave, 3 = env + actor + critic wave."""
+    out = (C.c_int32 * 4)()
+    _lib.check(env.lib.dpenv_get_policy_launch_ex(env._h, out), env._h)
+    return dict(two_wave=bool(out[0]), envs_per_workgroup=int(out[1]), waves_per_64_envs=int(out[2]),
+                precision={_lib.POLICY_F16: 'f16', _lib.POLICY_F32: 'f32', _lib.POLICY_F32_ACTOR: 'f32_actor'}[int(out[3])])
+
+
+def release_policy_graphs(env):
+    """dpenv_release_policy_graphs: the HIP graphs that recorded closed-loop launches of this env are gone; uploads of any layout are accepted again."""
+    _lib.check(env.lib.dpenv_release_policy_graphs(env._h), env._h)
 
 
 def policy_forward(env, obs):

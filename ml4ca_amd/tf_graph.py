@@ -188,7 +188,8 @@ def mlp_chain(g, scope):
         rec = {'layer': name, 'input': mm['inputs'][0], 'kernel': mm['inputs'][1],
                'transpose_a': bool(mm['attr'].get('transpose_a', False)), 'transpose_b': bool(mm['attr'].get('transpose_b', False))}
         ba = name + '/BiasAdd'
-        assert ba in g.nodes and g.nodes[ba]['op'] == 'BiasAdd' and g.nodes[ba]['inputs'][0] == name + '/MatMul', name
+        if not (ba in g.nodes and g.nodes[ba]['op'] == 'BiasAdd' and g.nodes[ba]['inputs'][0] == name + '/MatMul'):
+            raise ValueError('unsupported graph: layer %r has no BiasAdd on its MatMul (%r)' % (name, g.nodes.get(ba)))
         rec['bias'] = g.nodes[ba]['inputs'][1]
         ops, out = ['MatMul', 'BiasAdd'], ba
         users = [n for n in g.order if n.startswith(name + '/') and ba in g.nodes[n]['inputs']]
@@ -196,14 +197,17 @@ def mlp_chain(g, scope):
             lk = name + '/LeakyRelu'
             if lk in g.nodes and g.nodes[lk]['op'] == 'Maximum':
                 mul = g.nodes[lk]['inputs'][0]
-                assert g.nodes[lk]['inputs'][1] == ba and g.nodes[mul]['op'] == 'Mul' and g.nodes[mul]['inputs'][1] == ba, (lk, g.nodes[lk])
-                assert sorted(users) == sorted([mul, lk]), users
+                if not (g.nodes[lk]['inputs'][1] == ba and g.nodes[mul]['op'] == 'Mul' and g.nodes[mul]['inputs'][1] == ba):
+                    raise ValueError('unsupported graph: %r is not Maximum(Mul(alpha, x), x) of its BiasAdd: %r' % (lk, g.nodes[lk]))
+                if sorted(users) != sorted([mul, lk]):
+                    raise ValueError('unsupported graph: BiasAdd of layer %r has other users than its leaky-relu: %r' % (name, users))
                 rec['alpha'] = float(np.asarray(g.const(g.nodes[mul]['inputs'][0])).reshape(-1)[0])
                 rec['form'] = 'Maximum(Mul(alpha, x), x)'
                 ops.append('LeakyRelu')
                 out = lk
             else:
-                assert len(users) == 1, users
+                if len(users) != 1:
+                    raise ValueError('unsupported graph: BiasAdd of layer %r feeds %d ops (%r), expected one activation' % (name, len(users), users))
                 a = g.nodes[users[0]]
                 ops.append(a['op'])
                 if 'alpha' in a['attr']:
@@ -214,7 +218,8 @@ def mlp_chain(g, scope):
         layers.append(rec)
         i += 1
     for a, b in zip(layers[:-1], layers[1:]):              # layer k + 1 reads layer k's output
-        assert b['input'] == a['output'], (a, b)
+        if b['input'] != a['output']:
+            raise ValueError('unsupported graph: layer %r does not read the output of layer %r (%r)' % (b['layer'], a['layer'], (a, b)))
     return layers
 
 

@@ -372,13 +372,48 @@ void FN(dpo_policy_noise)(const dpo_config* c, int64_t gid, uint32_t draw, int32
     for (int k = 0; k < adim && k < 8; ++k) xi[k] = z[k];
 }
 
+/*
+ * Build-defined ("M, D as per-env SoA parameter arrays (domain randomisation)"): the hull of episode `episode` of env
+ * `gid`.  rand_tab = { nominal[32] | relative half-range[32] } in the public parameter order; parameter p = nominal[p] * (1 + range[p] * u),
+ * u uniform in [-1, 1) with 16 bits, taken from four Philox4x32-10 blocks keyed by the seed with counter (global env id, episode,
+ * tag 0x48000000 | block).  The 16 bits of a parameter are half (q & 1) of word (q & 7) >> 1 of block q >> 3 for its slot q: the
+ * parameters numbered in the order the kernels pack a per-env block (m11 m22 m23 m33 Xu | Xuu Yv Yvv Yr Nv Nr Nrr Nuv | Yur Kf Kr lx_bow |
+ * lx_port lx_star ly), so that one Philox block fills two float4 groups there.  The parameters it randomises are the constants the
+ * reference hard-codes once for its one vessel (QPROS:51-55,69-70, STAU:35-36,69-71) and the build-owned hull terms.
+ */
+static const int FN(RAND_SLOT)[26] = {0, 1, 2, 3, 4, 8, 9, 10, 11, 12, 13, 14, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 15, 16};
+
+void FN(dpo_draw_vessel)(const dpo_config* c, const REAL* rand_tab, int64_t gid, uint32_t episode, REAL* p)
+{
+    uint32_t key[2] = {(uint32_t)(c->seed & 0xffffffffu), (uint32_t)(c->seed >> 32)};
+    uint32_t w[4][4];
+    for (int b = 0; b < 4; ++b) {
+        uint32_t ctr[4] = {(uint32_t)((uint64_t)gid & 0xffffffffu), (uint32_t)((uint64_t)gid >> 32), episode, 0x48000000u | (uint32_t)b};
+        dpo_philox4x32_10(ctr, key, w[b]);
+    }
+    for (int k = 0; k < DPO_NPARAM; ++k) p[k] = R(0);
+    for (int k = 0; k < 26; ++k) {
+        const int q = FN(RAND_SLOT)[k];
+        const uint32_t h16 = (w[q >> 3][(q & 7) >> 1] >> (16 * (q & 1))) & 0xffffu;
+        const REAL u = R(h16) * R(1.0 / 32768.0) - R(1);
+        const REAL sc = R(1) + rand_tab[32 + k] * u;
+        p[k] = rand_tab[k] * sc;
+    }
+}
+
 static void FN(reset_one)(const dpo_config* c, int32_t n, int32_t i, REAL* state, int32_t* counters,
-                          const REAL* init, const REAL* ref)
+                          const REAL* init, const REAL* ref, REAL* vessel_env, const REAL* rand_tab)
 {
     REAL eta[3], nu[3], ang[3], pt[3] = {R(0), R(0), R(0)};
     /* the episode counter advances with every reset that consumes random numbers (sampled pose, or drawn thrust) */
     const uint32_t ep = (uint32_t)counters[n + i];
-    if (!init || c->reset_acts) counters[n + i] += 1;
+    if (!init || c->reset_acts || (rand_tab && vessel_env)) counters[n + i] += 1;
+    if (rand_tab && vessel_env) {
+        /* domain randomisation: every reset starts its episode on a freshly drawn hull */
+        REAL pv[DPO_NPARAM];
+        FN(dpo_draw_vessel)(c, rand_tab, c->env_id_base + i, ep, pv);
+        for (int k = 0; k < DPO_NPARAM; ++k) vessel_env[(int64_t)k * n + i] = pv[k];
+    }
     if (init) {
         /* explicit **init (ENV:141,152,159-161) */
         for (int k = 0; k < 3; ++k) { eta[k] = init[k * n + i]; nu[k] = init[(3 + k) * n + i]; }
@@ -424,11 +459,11 @@ static void FN(obs_of_state)(const dpo_config* c, int32_t n, int32_t i, const RE
 
 /* ENV:135-194.  mask NULL = all envs; init [6][n] SoA or NULL = sample; ref [3][n] or NULL = keep. */
 void FN(dpo_reset)(const dpo_config* c, int32_t n, REAL* state, int32_t* counters, const uint8_t* mask,
-                   const REAL* init, const REAL* ref, REAL* obs)
+                   const REAL* init, const REAL* ref, REAL* obs, REAL* vessel_env, const REAL* rand_tab)
 {
     const int od = FN(dpo_obs_dim)(c);
     for (int32_t i = 0; i < n; ++i) {
-        if (!mask || mask[i]) FN(reset_one)(c, n, i, state, counters, init, ref);
+        if (!mask || mask[i]) FN(reset_one)(c, n, i, state, counters, init, ref, vessel_env, rand_tab);
         if (obs) FN(obs_of_state)(c, n, i, state, obs + (int64_t)i * od);
     }
 }
@@ -463,8 +498,10 @@ static void FN(current_drift)(const dpo_config* c, int64_t gid, uint32_t* ctr, R
 void FN(dpo_step)(const dpo_config* c, const REAL* vessel, int32_t n, REAL* state, int32_t* counters,
                   const REAL* action, const REAL* new_ref, const REAL* plant_override, REAL* current,
                   REAL* obs, REAL* rew, uint8_t* done, REAL* parts_out, REAL* final_obs, const REAL* current_mean,
-                  uint32_t* drift_ctr)
+                  uint32_t* drift_ctr, REAL* vessel_env, const REAL* rand_tab)
 {
+    /* vessel_env [DPO_NPARAM][n] or NULL: every env's OWN parameter vector (the kernels' per-env blocks) instead of the shared `vessel`;
+     * rand_tab { nominal[32] | range[32] } or NULL: domain randomisation - an auto-reset re-draws the env's column of vessel_env */
     const int ad = FN(dpo_act_dim)(c), od = FN(dpo_obs_dim)(c);
     /* envs are independent (trainer.py:61-75: one simulator per env); threads only split the loop */
 #pragma omp parallel for schedule(static) if (n >= 4096)
@@ -482,7 +519,9 @@ void FN(dpo_step)(const dpo_config* c, const REAL* vessel, int32_t n, REAL* stat
         } else {
             REAL cur[2];
             if (current) { cur[0] = current[i]; cur[1] = current[n + i]; }
-            FN(dpo_plant)(c, vessel, eta, nu, thrust, ang_cur, current ? cur : (const REAL*)0);   /* ENV:124 */
+            REAL pv[DPO_NPARAM];
+            if (vessel_env) for (int k = 0; k < DPO_NPARAM; ++k) pv[k] = vessel_env[(int64_t)k * n + i];
+            FN(dpo_plant)(c, vessel_env ? pv : vessel, eta, nu, thrust, ang_cur, current ? cur : (const REAL*)0);   /* ENV:124 */
         }
         if (current && c->current_drift && current_mean && drift_ctr)
             FN(current_drift)(c, c->env_id_base + i, &drift_ctr[i], &current[i], &current[n + i], current_mean[i],
@@ -509,7 +548,7 @@ void FN(dpo_step)(const dpo_config* c, const REAL* vessel, int32_t n, REAL* stat
         if (c->auto_reset && d) {
             /* ppo.py:305-322: finished envs are reset and the next policy input is the reset obs */
             if (final_obs) for (int k = 0; k < od; ++k) final_obs[(int64_t)i * od + k] = o[k];
-            FN(reset_one)(c, n, i, state, counters, (const REAL*)0, (const REAL*)0);
+            FN(reset_one)(c, n, i, state, counters, (const REAL*)0, (const REAL*)0, vessel_env, rand_tab);
             FN(obs_of_state)(c, n, i, state, o);
         }
     }

@@ -155,16 +155,32 @@ class Oracle(object):
     def new_state(self, n):
         return np.zeros((NSTATE, n), self.dtype), np.zeros((2, n), np.int32)
 
-    def reset(self, state, counters, mask=None, init=None, ref=None):
+    def draw_vessel(self, rand_tab, gid, episode):
+        """The randomisation's hull of episode `episode` of env `gid`: rand_tab = [nominal (32) | relative half-range (32)]."""
+        rt = self._a(rand_tab, (2 * NPARAM,))
+        p = np.zeros(NPARAM, self.dtype)
+        self._f('dpo_draw_vessel')(C.byref(self.cfg), _p(rt), C.c_int64(int(gid)), C.c_uint32(int(episode)), _p(p))
+        return p
+
+    def _vessel_env(self, vessel_env, rand_tab, n):
+        """per-env parameter table [NPARAM, n] (updated IN PLACE by resets when rand_tab is given) and the randomisation table"""
+        if vessel_env is not None:
+            assert vessel_env.dtype == self.dtype and vessel_env.flags.c_contiguous and vessel_env.shape == (NPARAM, n)
+        if rand_tab is not None:
+            assert vessel_env is not None
+        return vessel_env, self._a(rand_tab, (2 * NPARAM,))
+
+    def reset(self, state, counters, mask=None, init=None, ref=None, vessel_env=None, rand_tab=None):
         n = state.shape[1]
         obs = np.zeros((n, self.obs_dim), self.dtype)
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        ve, rt = self._vessel_env(vessel_env, rand_tab, n)
         self._f('dpo_reset')(C.byref(self.cfg), C.c_int32(n), _p(state), _p(counters), _p(m),
-                             _p(self._a(init, (6, n))), _p(self._a(ref, (3, n))), _p(obs))
+                             _p(self._a(init, (6, n))), _p(self._a(ref, (3, n))), _p(obs), _p(ve), _p(rt))
         return obs
 
     def step(self, state, counters, action, new_ref=None, plant_override=None, current=None,
-             want_parts=False, want_final_obs=False, current_mean=None, drift_ctr=None):
+             want_parts=False, want_final_obs=False, current_mean=None, drift_ctr=None, vessel_env=None, rand_tab=None):
         """current [2][n] is updated IN PLACE when the config enables drift (pass a contiguous array of the
         oracle's dtype together with current_mean [2][n] and drift_ctr uint32[n])."""
         n = state.shape[1]
@@ -181,10 +197,11 @@ class Oracle(object):
             cur = current
         else:
             cur = self._a(current, (2, n))
+        ve, rt = self._vessel_env(vessel_env, rand_tab, n)
         self._f('dpo_step')(C.byref(self.cfg), _p(self.vessel), C.c_int32(n), _p(state), _p(counters), _p(a),
                             _p(self._a(new_ref, (3, n))), _p(self._a(plant_override, (6, n))),
                             _p(cur), _p(obs), _p(rew), _p(done), _p(parts), _p(fobs),
-                            _p(self._a(current_mean, (2, n))), _p(drift_ctr))
+                            _p(self._a(current_mean, (2, n))), _p(drift_ctr), _p(ve), _p(rt))
         out = [obs, rew, done]
         if want_parts:
             out.append(parts)
@@ -196,7 +213,7 @@ class Oracle(object):
         """step() writing into caller-provided arrays: nothing but the C loop runs (used for CPU timing)."""
         n = state.shape[1]
         self._f('dpo_step')(C.byref(self.cfg), _p(self.vessel), C.c_int32(n), _p(state), _p(counters), _p(action),
-                            _p(new_ref), None, None, _p(obs), _p(rew), _p(done), None, None, None, None)
+                            _p(new_ref), None, None, _p(obs), _p(rew), _p(done), None, None, None, None, None, None)
 
     def discount_cumsum(self, x, discount):
         x = self._a(x)

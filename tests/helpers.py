@@ -26,7 +26,7 @@ def make_pair(mode, n, ext=True, dtype=np.float32, device='cuda:0', **kw):
         current_drift=kw.get('current_drift', False), current_tau=kw.get('current_tau', 100.0),
         current_sigma_v=kw.get('current_sigma_v', 0.02), current_sigma_beta=kw.get('current_sigma_beta', 5.0 * np.pi / 180.0),
         n_steps=kw.get('n_steps'), testing=kw.get('testing', False), realtime=kw.get('realtime', False),
-        reset_acts=kw.get('reset_acts', False))
+        reset_acts=kw.get('reset_acts', False), step_one_wave=kw.get('step_one_wave', False), per_env_lds=kw.get('per_env_lds', False))
     cfg = O.make_config(variant=ovar, extended_state=int(ext), cont_ang=ocont, n_substeps=env.n_steps,
                         wrap_mode=O.WRAP_RADIANS if kw.get('wrap_mode') == 'radians' else O.WRAP_REFERENCE,
                         terminate=int(kw.get('terminate', True)),
@@ -65,3 +65,23 @@ def random_actions(rng, n, act_dim, scale=0.8):
 def to_dev(x, device='cuda:0'):
     import torch
     return torch.from_numpy(np.ascontiguousarray(x)).to(device)
+
+
+def random_hulls(rng, n, rel=0.15, base=None):
+    """[NPARAM, n] float32: every env its own parameter vector, each of the 26 parameters of the default hull scaled by an
+    independent factor in [1 - rel, 1 + rel] (the constants the reference fixes once for its one vessel: qp_allocator.py:51-55,69-70,
+    SupervisedTau.py:35-36,69-71, and the build-owned mass / damping terms)."""
+    import ml4ca_amd
+    base = np.asarray(ml4ca_amd.default_vessel() if base is None else base, np.float32)
+    tab = np.zeros((O.NPARAM, n), np.float32)
+    tab[:26] = base[:26, None] * (1.0 + rel * rng.uniform(-1, 1, size=(26, n))).astype(np.float32)
+    return tab
+
+
+def rand_table(rel, nominal=None):
+    """[nominal (32) | relative half-range (32)] as the library holds it (float32)"""
+    import ml4ca_amd
+    rt = np.zeros(2 * O.NPARAM, np.float32)
+    rt[:O.NPARAM] = np.asarray(ml4ca_amd.default_vessel() if nominal is None else nominal, np.float32)
+    rt[O.NPARAM:O.NPARAM + 26] = np.float32(rel)
+    return rt

@@ -349,3 +349,52 @@ def test_tolerance_floors_follow_from_the_ulp_argument():
     # ... and out of reach of fp32 for the body-frame position errors, whoever computes them (psi~ sits right at it: 1.03e-5)
     assert rep['obs.x~']['err_in_ulps_of_S'] <= 0.5 * TOL.DERIVATION['x'][1] and rep['obs.psi~']['err_in_ulps_of_S'] <= 0.5 * TOL.DERIVATION['psi'][1]
     assert rep['obs.x~']['rel_err_floor_1e-2'] > 5 * TOL.RTOL_F32 and rep['obs.y~']['rel_err_floor_1e-2'] > 5 * TOL.RTOL_F32
+
+
+def test_per_env_vessels_and_the_randomisation_draw_in_the_oracle():
+    """Round 5 (build-owned, like the plant: SURVEY appendix D).  The oracle's per-env form is its shared-vessel form when every env is
+    given the same vector, and rows follow the env's OWN column otherwise; the randomisation draw (dpo_draw_vessel) is uniform on
+    [1 - r, 1 + r) x nominal with 16-bit resolution, a function of (seed, global env id, episode) alone, and the fp32 build agrees with
+    the float64 build to rounding.  The parameters it varies are the constants the reference fixes once for its one vessel
+    (qp_allocator.py:51-55,69-70; SupervisedTau.py:35-36,69-71) plus the hull terms of the plant behind customEnv.py:124."""
+    from tests import helpers as H
+    n = 512
+    rng = np.random.RandomState(2)
+    cfg = O.make_config(max_ep_len=400, seed=77, auto_reset=1, terminate=1)
+    o32, o64 = O.Oracle(cfg, np.float32), O.Oracle(cfg, np.float64)
+    st = H.random_state(rng, n, 0.5)
+    ctr = np.zeros((2, n), np.int32)
+    act = H.random_actions(rng, n, 7)
+    shared = o32.step(st.copy(), ctr.copy(), act)
+    same = np.ascontiguousarray(np.tile(o32.vessel[:, None], (1, n)))
+    per_env = o32.step(st.copy(), ctr.copy(), act, vessel_env=same)
+    assert all(np.array_equal(a, b) for a, b in zip(shared, per_env))
+    hulls = H.random_hulls(rng, n)
+    mixed = o32.step(st.copy(), ctr.copy(), act, vessel_env=hulls)
+    for i in (0, 17, n - 1):                                  # env i alone on ITS vector
+        one = O.Oracle(cfg, np.float32, vessel=hulls[:, i]).step(np.ascontiguousarray(st[:, i:i + 1]), np.ascontiguousarray(ctr[:, i:i + 1]), act[i:i + 1])
+        assert np.array_equal(one[0][0], mixed[0][i]) and one[1][0] == mixed[1][i]
+    assert np.abs(mixed[0] - shared[0])[:, 3:6].max() > 1e-3
+    # the draw
+    rt = np.zeros(64)
+    rt[:32] = o64.vessel
+    rt[32:58] = 0.15
+    draws = np.stack([o64.draw_vessel(rt, gid, ep) for gid in (0, 1, 2**33 + 5) for ep in range(400)])
+    nz = rt[:26] != 0
+    ratio = draws[:, :26][:, nz] / rt[:26][nz]
+    assert ratio.min() >= 0.85 and ratio.max() < 1.15 and abs(ratio.mean() - 1) < 2e-3 and abs(ratio.std() - 0.15 / np.sqrt(3)) < 2e-3
+    assert np.all(draws[:, 26:] == 0) and np.all(draws[:, :26][:, ~nz] == 0)
+    u = (ratio - 1) / 0.15                                    # 16-bit uniforms: multiples of 2^-15
+    assert np.abs(u * 32768 - np.round(u * 32768)).max() < 1e-6
+    assert np.array_equal(o64.draw_vessel(rt, 5, 9), o64.draw_vessel(rt, 5, 9)) and not np.array_equal(o64.draw_vessel(rt, 5, 9), o64.draw_vessel(rt, 5, 10))
+    assert np.abs(np.corrcoef(ratio.T) - np.eye(ratio.shape[1])).max() < 0.15                                 # parameters are drawn independently
+    a32 = o32.draw_vessel(rt.astype(np.float32), 12345, 3)
+    a64 = o64.draw_vessel(rt.astype(np.float32).astype(np.float64), 12345, 3)
+    assert np.abs(a32 - a64).max() <= 3e-7 * np.abs(a64).max()
+    # a reset with the table re-draws the env's column and advances its episode counter even with an explicit init
+    st64, c64 = o64.new_state(8)
+    tab = np.ascontiguousarray(np.tile(o64.vessel[:, None], (1, 8)))
+    o64.reset(st64, c64, init=np.zeros((6, 8)), vessel_env=tab, rand_tab=rt)
+    assert list(c64[1]) == [1] * 8 and np.array_equal(tab[:, 3], o64.draw_vessel(rt, 3, 0))
+    o64.reset(st64, c64, mask=np.array([0, 1, 0, 0, 0, 0, 0, 0], np.uint8), vessel_env=tab, rand_tab=rt)
+    assert list(c64[1]) == [1, 2, 1, 1, 1, 1, 1, 1] and np.array_equal(tab[:, 1], o64.draw_vessel(rt, 1, 1)) and np.array_equal(tab[:, 3], o64.draw_vessel(rt, 3, 0))

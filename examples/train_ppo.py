@@ -9,6 +9,10 @@ What differs is the rollout: N environments x T steps from ONE dpenv_policy_roll
 env.step, critic, trajectory rows), GAE by one scan kernel, advantage statistics by device reductions.
 
     python examples/train_ppo.py --envs 4096 --epochs 30
+    python examples/train_ppo.py --envs 4096 --epochs 40 --randomise 0.15 --eval      domain randomisation: every episode of every env
+                                                                                      runs on its own hull, +-15 % on all 26 parameters, re-drawn by the reset path
+                                                                                      inside the rollout launch; --eval: the reference's evaluation harness
+                                                                                      (test_policy.py:97-186) and the box test (IAE, energy) on the NOMINAL hull
 """
 import argparse
 import os
@@ -22,6 +26,43 @@ import ml4ca_amd
 from ml4ca_amd import dist as D
 from ml4ca_amd import rollout
 from ml4ca_amd.policy import ActorCritic
+
+
+def evaluate_actor(ac, dev, preset, precision, seed, out=print):
+    """The trained actor on the NOMINAL hull (and on a spread of hulls): the reference's run_RL_policy (spinup/utils/test_policy.py:97-186: six
+    fixed starts, deterministic policy) and the thesis' 4-corner box test with its two metrics - IAE (results/all_plots/common.py:60-74) and
+    the energy-equivalent work of the thruster power model (box_test/plot_act.py:128-135,184-211)."""
+    from ml4ca_amd import evaluate as EV
+    from ml4ca_amd.policy import policy_rollout
+    nominal = ml4ca_amd.default_vessel(preset)
+    env6 = ml4ca_amd.BatchedRevoltEnv(6, device=dev, auto_reset=False, testing=True, vessel_params=nominal)
+    ac.upload(env6, precision=precision)
+    r = EV.run_RL_policy(env6, ac)
+    out('eval  run_RL_policy on the nominal hull (six fixed starts, deterministic actor): EpRet %s  EpLen %s' % (
+        [round(float(x), 1) for x in r['EpRet']], [int(x) for x in r['EpLen']]))
+    res = {'EpRet_mean': float(r['EpRet'].mean()), 'EpLen_mean': float(r['EpLen'].float().mean())}
+    T, nb = 1250, 1024
+    for tag, spread in (('nominal hull', 0.0), ('hulls +-15 %', 0.15), ('hulls +-30 %', 0.30)):
+        env = ml4ca_amd.BatchedRevoltEnv(nb, device=dev, terminate=False, time_limit=False, seed=seed + 77, vessel_params=nominal)
+        if spread > 0:
+            env.set_vessel_randomisation(spread, nominal=nominal)          # one draw per env at the reset below; no resets after it
+        ac.upload(env, precision=precision)
+        start = torch.zeros((3, nb), device=dev)
+        env.reset(init=torch.zeros((6, nb), device=dev), new_ref=start.clone())
+        steps, refs = EV.box_schedule(start)
+        o = policy_rollout(env, T, noise=None, switch_steps=steps, refs=refs)
+        iae_tot, _ = EV.iae(o['obs'])
+        w = EV.work(EV.commanded_thrust(o['act']))
+        e = o['obs'][:, :, :3]
+        k = [max(t - 1, 0) for t in list(steps)[1:] + [T - 1]]             # just before each switch: how close to the corner
+        pos = torch.sqrt(e[k, :, 0] ** 2 + e[k, :, 1] ** 2)
+        out('eval  box test (1250 steps, %d envs), %-13s: IAE %.2f (worst env %.2f)  work bow/port/star %s  corner error %.2f m / %.1f deg (worst %.2f m)  reward/step %.3f' % (
+            nb, tag, float(iae_tot.mean()), float(iae_tot.max()), [round(float(x), 1) for x in w.mean(0)], float(pos.mean()),
+            float(torch.rad2deg(e[k, :, 2].abs().mean())), float(pos.max()), float(o['rew'].mean())))
+        res[tag] = {'IAE': float(iae_tot.mean()), 'IAE_worst': float(iae_tot.max()), 'work': [float(x) for x in w.mean(0)],
+                    'corner_error_m': float(pos.mean()), 'reward_per_step': float(o['rew'].mean())}
+        del env
+    return res
 
 
 def main():
@@ -42,6 +83,12 @@ def main():
     ap.add_argument('--chunks', type=int, default=4, help="--exchange rollout: pieces the episode is rolled out and posted in")
     ap.add_argument('--reset-at-end', action='store_true', help='the reference\'s epoch boundary (ppo.py:305-322): every env is cut and re-drawn '
                                                                 'after the last step of an epoch (matters when --steps < max_ep_len)')
+    ap.add_argument('--randomise', type=float, default=0.0, help='R > 0: domain randomisation - every reset (also the ones inside the rollout launch) draws the '
+                                                                  'new episode\'s hull: each of the 26 vessel parameters = nominal x (1 + R u), u ~ U[-1, 1), '
+                                                                  'Philox keyed (seed; global env id, episode): independent of the rank count')
+    ap.add_argument('--preset', default='no_loss', choices=('no_loss', 'thrust_loss'), help='nominal hull (dpenv_default_vessel_ex)')
+    ap.add_argument('--eval', action='store_true', help='after training: run_RL_policy + the box test (IAE, energy) on the nominal hull and on spreads of hulls')
+    ap.add_argument('--save', default='', help='write the trained parameters (reference variable names) to this .npz')
     ap.add_argument('--backend', default='nccl', help="'nccl' (RCCL, one GPU per rank) or 'gloo' (rehearsal)")
     ap.add_argument('--same-device', action='store_true', help='all ranks on cuda:0 (multi-rank rehearsal on a one-GPU box)')
     args = ap.parse_args()
@@ -56,8 +103,10 @@ def main():
         else:
             torch.distributed.init_process_group(args.backend)
     torch.manual_seed(args.seed + 1000 * rank)
-    env = ml4ca_amd.BatchedRevoltEnv(args.envs, auto_reset=True, seed=args.seed, device=dev,
-                                     env_id_base=rank * args.envs)               # final / ext / cont_ang
+    env = ml4ca_amd.BatchedRevoltEnv(args.envs, auto_reset=True, seed=args.seed, device=dev, env_id_base=rank * args.envs,
+                                     vessel_params=ml4ca_amd.default_vessel(args.preset) if args.preset != 'no_loss' else None)   # final / ext / cont_ang
+    if args.randomise > 0:
+        env.set_vessel_randomisation(args.randomise, nominal=ml4ca_amd.default_vessel(args.preset))
     ac = ActorCritic(9, 7, (80, 80, 80), leak=0.2, seed=args.seed, device=dev, activation=args.activation)
     D.sync_params(ac.parameters())                                               # sync_all_params, ppo.py:255
     for p in ac.parameters():
@@ -145,6 +194,17 @@ def main():
                 float(v_loss.detach()), t_roll * 1e3, t_upd))
     if rank == 0:
         print('env-steps collected: %d (%.1f M per epoch, %d rank(s))' % (args.epochs * T * n * world, T * n * world / 1e6, world))
+        if args.randomise > 0:
+            hp = env.get_vessel_params()[:4]
+            print('hulls in force at the end: m11 %.1f .. %.1f (nominal %.1f), episodes per env so far %.1f' % (
+                float(hp[0].min()), float(hp[0].max()), float(ml4ca_amd.default_vessel(args.preset)[0]), float(env.get_state()[1][1].float().mean())))
+        for p in ac.parameters():
+            p.requires_grad_(False)
+        if args.save:
+            import numpy as np
+            np.savez(args.save, **{k.replace('/', '.'): v for k, v in ac.state_dict().items()})
+        if args.eval:
+            evaluate_actor(ac, dev, args.preset, 'f32', args.seed)
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -146,6 +146,13 @@ typedef struct dpenv_step_io {
 int dpenv_default_config(dpenv_config* cfg);
 /* Default ReVolt parameter vector. */
 int dpenv_default_vessel(float params[DPENV_NPARAM]);
+/* The presets of the build-owned plant, one per set of steady full-thrust speeds the reference records (customEnv.py:13-18):
+ * NO_LOSS = dpenv_default_vessel (+2.20 m/s ahead, 0.60 rad/s: "no thrust losses activated"); THRUST_LOSS = the same hull with the stern
+ * thrust gains that give +1.4 / -1.1 m/s ahead / astern ("with thrust losses": the velocity bounds the reference trains with,
+ * customEnv.py:26) through the forward / reverse slots.  Pass the vector to dpenv_create, or as `nominal` to
+ * dpenv_set_vessel_randomisation. */
+enum { DPENV_VESSEL_NO_LOSS = 0, DPENV_VESSEL_THRUST_LOSS = 1 };
+int dpenv_default_vessel_ex(int32_t kind, float params[DPENV_NPARAM]);
 /* Derived sizes for a config. */
 int dpenv_act_dim(const dpenv_config* cfg);
 int dpenv_obs_dim(const dpenv_config* cfg);

@@ -78,6 +78,7 @@ SYMBOLS = {
     'dpenv_abi_version': (C.c_int, []),
     'dpenv_default_config': (C.c_int, [C.POINTER(Config)]),
     'dpenv_default_vessel': (C.c_int, [C.POINTER(C.c_float)]),
+    'dpenv_default_vessel_ex': (C.c_int, [C.c_int32, C.POINTER(C.c_float)]),
     'dpenv_act_dim': (C.c_int, [C.POINTER(Config)]),
     'dpenv_obs_dim': (C.c_int, [C.POINTER(Config)]),
     'dpenv_create': (C.c_int, [C.POINTER(Config), C.POINTER(C.c_float), _I32, C.POINTER(_VP)]),
@@ -157,8 +158,12 @@ def default_config():
     return cfg
 
 
-def default_vessel():
+VESSEL_NO_LOSS, VESSEL_THRUST_LOSS = 0, 1
+
+
+def default_vessel(kind='no_loss'):
+    """Parameter vector of a preset of the build-owned plant: 'no_loss' (the default hull) or 'thrust_loss' (dpenv.h: DPENV_VESSEL_*)."""
     import numpy as np
     p = (C.c_float * NPARAM)()
-    check(load().dpenv_default_vessel(p))
+    check(load().dpenv_default_vessel_ex({'no_loss': VESSEL_NO_LOSS, 'thrust_loss': VESSEL_THRUST_LOSS}[kind], p))
     return np.array(p[:], dtype=np.float32)

@@ -150,6 +150,23 @@ extern "C" int dpenv_default_vessel(float* p)
     return DPENV_OK;
 }
 
+// The same hull with the thrust gains of the reference's SECOND set of steady full-thrust speeds - "with thrust losses" +1.4 / -1.1 m/s
+// ahead / astern (customEnv.py:17), which are also the velocity bounds it trains with (customEnv.py:26) - derived by
+// tests/calibration/fit_thrust_loss_preset.py: stern gains 0.44 (ahead) / 0.29 (astern) of the no-loss ones through the forward / reverse
+// slots, bow unchanged (sway 0.29 m/s against the recorded 0.30); the hull is untouched, so the free-drift record is reproduced as
+// before.  Yaw comes out at 0.35 rad/s against the recorded 0.52: a constant gain cannot be 0.44 at 1.4 m/s inflow and 0.87 at none
+// (DESIGN.md section 3).  Not the default: the recorded Cybersea manoeuvres (low speed) replay better with the no-loss gains.
+extern "C" int dpenv_default_vessel_ex(int32_t kind, float* p)
+{
+    if (!p || (kind != DPENV_VESSEL_NO_LOSS && kind != DPENV_VESSEL_THRUST_LOSS)) return DPENV_EINVAL;
+    dpenv_default_vessel(p);
+    if (kind == DPENV_VESSEL_THRUST_LOSS) {
+        p[DPENV_P_KF_PORT] = p[DPENV_P_KF_STAR] = 0.0009059f;
+        p[DPENV_P_KR_PORT] = p[DPENV_P_KR_STAR] = 0.0005949f;
+    }
+    return DPENV_OK;
+}
+
 static int mode_of(const dpenv_config* c)
 {
     switch (c->variant) {

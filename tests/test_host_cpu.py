@@ -490,3 +490,38 @@ def test_episode_exchange_single_process_is_a_copy():
             assert torch.equal(ex.flat(k), b.reshape((T * n,) + tuple(b.shape[2:])))
     with pytest.raises(ValueError):
         D.EpisodeExchange(blocks, n_chunks=5)
+
+
+def test_thrust_loss_preset_against_the_second_set_of_recorded_speeds():
+    """dpenv_default_vessel_ex(DPENV_VESSEL_THRUST_LOSS): the calibrated hull with the stern thrust gains that give the reference's steady
+    speeds WITH thrust losses (customEnv.py:17: +1.4 / -1.1 m/s; they are the velocity bounds it trains with, customEnv.py:26), derived by
+    tests/calibration/fit_thrust_loss_preset.py.  BUILD-OWNED like the plant itself: soft pins, no parity claim.  Both presets against
+    every recorded speed; yaw under losses is an outcome (0.35 against 0.52: a constant gain cannot follow an inflow-dependent loss)."""
+    from ml4ca_amd import _lib
+    from tests.calibration import fit_thrust_loss_preset as F
+    base, loss = _lib.default_vessel('no_loss').astype(np.float64), _lib.default_vessel('thrust_loss').astype(np.float64)
+    assert np.array_equal(_lib.default_vessel(), _lib.default_vessel('no_loss'))
+    changed = np.nonzero(base != loss)[0]
+    assert list(changed) == [_lib.P['KF_PORT'], _lib.P['KF_STAR'], _lib.P['KR_PORT'], _lib.P['KR_STAR']]       # thruster gains only: the hull is the same
+    m0, m1 = F.manoeuvres(base), F.manoeuvres(loss)
+    assert abs(m0['surge_ahead'] - 2.20) < 0.02 and abs(m0['yaw'] - 0.60) < 0.02 and abs(m0['sway'] - 0.35) < 0.07
+    assert abs(m1['surge_ahead'] - 1.40) < 0.01 and abs(m1['surge_astern'] + 1.10) < 0.01
+    assert abs(m1['sway'] - 0.30) < 0.02 and abs(m1['sway_to_port'] + 0.30) < 0.02
+    assert 0.30 < m1['yaw'] < 0.40                                                                              # recorded 0.52: documented, not met
+    # a fit from the default reproduces the shipped numbers
+    fit = F.fit(base)
+    assert np.allclose(fit[12:18], loss[12:18], rtol=2e-3)
+    # the free drift (no thrust) is the same trajectory under both presets
+    from oracle import oracle as O
+    d = np.load(os.path.join(G, 'cybersea_free_drift.npz'))
+    traj = []
+    for vec in (base, loss):
+        orc = O.Oracle(O.make_config(terminate=0, current_enabled=1), np.float64, vessel=vec)
+        st, ctr = orc.new_state(1)
+        orc.reset(st, ctr, init=np.zeros((6, 1)))
+        a = np.zeros((1, 7))
+        a[0, 4] = a[0, 6] = 1.0
+        for _ in range(100):
+            orc.step(st, ctr, a, current=d['current'].reshape(2, 1).astype(np.float64))
+        traj.append(st[0:6, 0].copy())
+    assert np.array_equal(traj[0], traj[1])

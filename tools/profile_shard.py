@@ -97,6 +97,42 @@ def main():
 
     closed(env, 'shard', ('f16', 'f32_actor', 'f32'))
     del env
+    # ---- per-env vessel parameter blocks (round 5), same shard size: dpenv_step with the blocks in registers / through the LDS image
+    #      (terminate off: step_kernel<4,true,2|3,false>), and the randomised form on the config-2 workload (reset wave draws the hulls:
+    #      step_kernel<4,true,4,true>; closed loop: the RND instantiation of the 128-env f16 form)
+    import numpy as np
+    base = np.asarray(ml4ca_amd.default_vessel(), np.float32)
+    hulls = torch.from_numpy(np.ascontiguousarray(np.concatenate([
+        base[:26, None] * (1.0 + 0.15 * np.random.RandomState(7).uniform(-1, 1, size=(26, n))), np.zeros((6, n))]).astype(np.float32))).to(dev)
+    so, sr, sd = torch.empty((n, 9), device=dev), torch.empty(n, device=dev), torch.empty(n, dtype=torch.uint8, device=dev)
+
+    def step_graph(e, steps=200):
+        def run():
+            for t in range(steps):
+                e.step(actions[t % CH], out=(so, sr, sd))
+        side2 = torch.cuda.Stream(device=dev)
+        side2.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side2):
+            run()
+        torch.cuda.current_stream(dev).wait_stream(side2)
+        torch.cuda.synchronize(dev)
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            run()
+        return timed(g2.replay, 2 * args.reps) / steps
+
+    for tag, lds in (('registers', False), ('lds_image', True)):
+        e = ml4ca_amd.BatchedRevoltEnv(n, device=dev, terminate=False, time_limit=False, seed=4, per_env_lds=lds)
+        e.set_vessel_params(hulls)
+        e.reset()
+        rec['legs']['step_per_env_' + tag] = {'kernel': 'step_kernel<4,true,%d,false>' % (3 if lds else 2), 'steps_per_launch': 1, 'us_per_step': step_graph(e) * 1e6}
+        del e
+    e = ml4ca_amd.BatchedRevoltEnv(n, device=dev, terminate=True, auto_reset=True, seed=4)
+    e.set_vessel_randomisation(0.15)
+    e.reset()
+    rec['legs']['step_randomised'] = {'kernel': 'step_kernel<4,true,4,true> (reset wave draws the hulls)', 'steps_per_launch': 1, 'us_per_step': step_graph(e) * 1e6}
+    closed(e, 'shard_randomised', ('f16', 'f32_actor'))
+    del e
     if args.big > 0:
         envb = ml4ca_amd.BatchedRevoltEnv(args.big, device=dev, terminate=True, auto_reset=True, seed=4)
         envb.reset()

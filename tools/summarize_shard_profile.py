@@ -31,12 +31,14 @@ def kname(k):
     if m:
         a = [re.sub(r'[^0-9a-z]', '', x) for x in m.group(1).split(',')]     # MODE, EXT, KA, ROLES, PREC, GROUPS
         grp = int(a[5]) if len(a) > 5 else 4
-        name = 'policy_rollout_ws_kernel<roles=%s,%s,%d_envs_per_workgroup>' % (a[3], PREC.get(a[4], a[4]), 64 * grp)
+        rnd = len(a) > 6 and a[6] in ('true', '1')
+        name = 'policy_rollout_ws_kernel<roles=%s,%s,%d_envs_per_workgroup%s>' % (a[3], PREC.get(a[4], a[4]), 64 * grp, ',randomised' if rnd else '')
         return name, T, (N if grp == 2 else (BIG or N))
     m = re.search(r'dpenv::step_kernel<([^>]*)>', k)
     if m:
         a = [x.strip() for x in m.group(1).split(',')]
-        return 'step_kernel<%s>%s' % (','.join(a), ' (reset wave)' if a[-1] == 'true' and len(a) >= 4 else ''), 1, N
+        ves = {'0': 'shared', '1': 'class_lds', '2': 'per_env_registers', '3': 'per_env_lds_image', '4': 'per_env_randomised'}.get(a[2], a[2]) if len(a) >= 4 else ''
+        return 'step_kernel<%s>%s%s' % (','.join(a), ' ' + ves if ves else '', ' (reset wave)' if a[-1] == 'true' and len(a) >= 4 else ''), 1, N
     if 'dpenv::rollout_ws_kernel' in k:
         return 'rollout_ws_kernel', CH, N
     if 'dpenv::rollout_kernel' in k:

@@ -2,7 +2,7 @@
 # Batch-size sweep of the bench legs (one MI355X): bash tools/batch_sweep.sh > gpurun_out/r04_batch_sweep.txt
 # us per env step of ALL N envs; frac = 177 B x N / step time / 8 TB/s.  The named workload is the 65 536 row.
 cd $GRAFT_REPO_ROOT 2>/dev/null || true
-echo "Batch-size sweep with the round-4 kernels (python bench.py --envs N --steps 250 --warmup 50 --no-cpu-baseline)"
+echo "Batch-size sweep with the ${ROUND:-round-5} kernels (python bench.py --envs N --steps 250 --warmup 50 --no-cpu-baseline)"
 for N in ${SIZES:-4096 16384 32768 65536 131072 262144 1048576}; do
   python3 bench.py --envs $N --steps 250 --warmup 50 --no-cpu-baseline 2>/dev/null | python3 -c "
 import json, sys

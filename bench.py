@@ -522,7 +522,7 @@ def config4_record(args, dev, rank, world, dist):
     return rec
 
 
-def classes_record(args, dev, n):
+def classes_record(args, dev, n, with_classes=True):
     """north_star: 'per-env 3x3 mass / Coriolis / damping blocks staged in LDS'; SURVEY section 7 asked for the A/B against plain
     registers.  dpenv_step with K vessel classes (the [class][param] table staged into LDS as [param][class] by every workgroup,
     step_kernel<.., PER_CLASS = true>) against the single-class path (parameters as kernel arguments, SGPRs), same envs, same
@@ -536,7 +536,8 @@ def classes_record(args, dev, n):
     actions = torch.randn((CHUNK, n, 7), generator=g, device=dev) * 0.6065
     base = np.array(ml4ca_amd.default_vessel(), np.float32)
     rec = {'what': classes_record.__doc__.replace('\n    ', ' '), 'envs': n}
-    for K in sorted(set([1, 3, args.classes, 16])):
+    # without --classes (the default run): the single class as the yardstick and the per-env record below
+    for K in (sorted(set([1, 3, args.classes, 16])) if with_classes else [1]):
         vp = None
         if K > 1:
             vp = np.tile(base, (K, 1))
@@ -1182,8 +1183,14 @@ def main():
             cfg4 = {'error': '%s: %s' % (type(e).__name__, e), 'traceback': traceback.format_exc()[-1500:]}
             sys.stderr.write('bench.py: config-4 record failed on rank %d: %s\n' % (rank, cfg4['error']))
     classes = None
-    if args.classes > 0 and rank == 0:
-        classes = classes_record(args, dev, n)
+    if rank == 0 and (args.classes > 0 or side_legs):
+        # --classes K: the class A/B as well; the per-env record (north_star: "per-env 3x3 mass / Coriolis / damping blocks") is part of every
+        # single-GPU run, so that it is in the driver's line
+        try:
+            classes = classes_record(args, dev, n, with_classes=args.classes > 0)
+        except Exception as e:       # pragma: no cover - a side record must not cost the line
+            import traceback
+            classes = {'error': '%s: %s' % (type(e).__name__, e), 'traceback': traceback.format_exc()[-1500:]}
 
     if rank == 0:
         if cfg4:

@@ -116,6 +116,9 @@ def parse():
     ap.add_argument('--classes', type=int, default=0, help='K > 0: also time dpenv_step with K vessel classes (LDS-staged [param][class] blocks) '
                                                            'against the single-class SGPR path, the closed loop with classes on, and per-ENV parameter '
                                                            'blocks (registers vs LDS image, randomised hulls): the `vessel_classes` record')
+    ap.add_argument('--eager-loop', type=int, default=1, help='the eager-loop record (a Python `for` over env.step without a graph); 0 leaves it out - the profile '
+                                                              'round does, because the leg launches the HEADLINE kernel ~14 000 times eagerly and a kernel-trace average '
+                                                              'over all dispatches of that kernel would then be an average over two launch forms')
     ap.add_argument('--init-timeout', type=float, default=180.0, help='seconds a rank waits for its peers in init_process_group / the first barrier '
                                                                        'before it gives up with a message and a non-zero exit code')
     ap.add_argument('--rendezvous-only', action='store_true', help='diagnostic: the ranks join the process group, exchange one all-reduce and rank 0 '
@@ -934,7 +937,7 @@ def main():
 
     # ---- eager loop: what a hand-written Python `for` over env.step pays (no graph) -------------------------------------------
     eager = None
-    if side_legs and rank == 0:
+    if side_legs and rank == 0 and args.eager_loop:
         eager = eager_record(env, actions, dev)
 
     # ---- fused-rollout leg (dpenv_rollout): same workload, CHUNK env steps per launch, state in registers -----

@@ -15,8 +15,8 @@ src = 'gpurun_out/prof_%s' % tag
 dst = sys.argv[2] if len(sys.argv) > 2 else 'profiles'       # on the GPU box: a directory under gpurun_out/, copied to profiles/ afterwards
 os.makedirs(dst, exist_ok=True)
 out = {'tag': tag, 'n_envs': 65536,
-       'commands': {'kernel_trace': 'rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline',
-                    'pmc': 'rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ_*> --output-format csv -- python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline (one pass per counter set)'},
+       'commands': {'kernel_trace': 'rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --eager-loop 0 (the eager-loop record launches the headline kernel eagerly ~14 000 times: its dispatches are profiled on their own, headline_kernel_duration.eager)',
+                    'pmc': 'rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ_*> --output-format csv -- python3 bench.py --steps 250 --warmup 50 --no-cpu-baseline --eager-loop 0 (one pass per counter set)'},
        'correction': 'gfx950: FETCH_SIZE tallies 128-B requests of wide coalesced reads at 64 B -> x2 (MI355X_MICROARCH.md, HBM); '
                      'WRITE_SIZE exact; both in KiB', 'kernels': {}}
 shutil.copy(glob.glob(src + '/kt/*/*_kernel_stats.csv')[0], '%s/%s_kernel_stats.csv' % (dst, tag))
@@ -35,12 +35,22 @@ def kname(k):
         a = [x.strip() for x in m.group(1).split(',')]
         prec = PREC.get(re.sub(r'[^0-9]', '', a[4]) if len(a) > 4 else '0', '?')
         grp = re.sub(r'[^0-9]', '', a[5]) if len(a) > 5 else '4'
-        return 'policy_rollout_ws_kernel/%s/%d_envs_per_workgroup' % (prec, 64 * int(grp or 4))
+        rnd = len(a) > 6 and a[6] in ('true', '1')          # round 5: the instantiation with the randomisation's hull re-draw (a side record launches it)
+        return 'policy_rollout_ws_kernel/%s/%d_envs_per_workgroup%s' % (prec, 64 * int(grp or 4), '/randomised' if rnd else '')
     for n in ('policy_rollout_x_kernel', 'policy_rollout_kernel', 'gae_kernel', 'gae_finalize_kernel',
               'adv_apply_kernel', 'pack_policy_kernel'):
         if n in k:
             return n
-    return 'step_kernel' if 'step_kernel' in k else 'rollout_ws_kernel' if 'dpenv::rollout_ws_kernel' in k else 'rollout_kernel' if 'rollout_kernel' in k else None
+    m = re.search(r'dpenv::step_kernel<([^>]*)>', k)
+    if m:
+        # <MODE, EXT, VES, RESETW>: the headline is the shared-hull kernel without a reset wave; the bench's side records (round 5) also launch
+        # the class / per-env / randomised instantiations and the reset-wave forms - different kernels, kept apart
+        a = [x.strip() for x in m.group(1).split(',')]
+        if len(a) >= 4 and (a[2], a[3]) != ('0', 'false'):
+            ves = {'0': 'shared', '1': 'class_lds', '2': 'per_env_registers', '3': 'per_env_lds_image', '4': 'per_env_randomised'}.get(a[2], a[2])
+            return 'step_kernel/%s%s' % (ves, '/reset_wave' if a[3] == 'true' else '')
+        return 'step_kernel'
+    return 'rollout_ws_kernel' if 'dpenv::rollout_ws_kernel' in k else 'rollout_kernel' if 'rollout_kernel' in k else None
 
 
 ALL = sorted({kname(r['Kernel_Name']) for r in rows} - {None})
@@ -63,8 +73,8 @@ for name in ('pmc_fetch', 'pmc_write', 'pmc_sq', 'pmc_mfma', 'pmc_l2'):
             agg[(kn, r['Counter_Name'])].append(float(r['Counter_Value']))
     for (kn, c), v in agg.items():
         out['kernels'].setdefault(kn, {}).setdefault('pmc_median_per_launch', {})[c] = st.median(v)
-steps_per_launch = {'step_kernel': 1, 'rollout_kernel': 50, 'rollout_ws_kernel': 50, 'policy_rollout_kernel': 50, 'policy_rollout_x_kernel': 50,
-                    'gae_kernel': 400, 'gae_finalize_kernel': 1, 'adv_apply_kernel': 400, 'pack_policy_kernel': 1}
+steps_per_launch = collections.defaultdict(lambda: 1, {'step_kernel': 1, 'rollout_kernel': 50, 'rollout_ws_kernel': 50, 'policy_rollout_kernel': 50, 'policy_rollout_x_kernel': 50,
+                    'gae_kernel': 400, 'gae_finalize_kernel': 1, 'adv_apply_kernel': 400, 'pack_policy_kernel': 1})
 for kn, k in out['kernels'].items():
     if kn.startswith('policy_rollout_ws_kernel'):
         # the bench launches these with T = 50 (closed-loop legs) and T = 400 (config 5): per-step figures use the launch's own T,
@@ -84,7 +94,7 @@ for kn, k in out['kernels'].items():
         # SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the SIMDs that issue MFMAs; SQ_BUSY_CYCLES is per SE (32 on this part):
         # matrix-pipe share of the kernel = MFMA cycles / (4 SIMDs x 256 CUs x kernel cycles)
         k['mfma_cycles_per_wave_per_env_step'] = p['SQ_VALU_MFMA_BUSY_CYCLES'] / p.get('SQ_WAVES', 1) / steps_per_launch[kn]
-    if kn in ('step_kernel', 'rollout_kernel', 'rollout_ws_kernel'):
+    if kn in ('step_kernel', 'rollout_kernel', 'rollout_ws_kernel') or kn.startswith('step_kernel/'):
         k['algorithmic_bytes_per_launch'] = 177 * 65536 * steps_per_launch[kn]
 try:
     out['bench_line'] = json.loads(open(src + '/bench_plain.json').read())
@@ -102,11 +112,11 @@ hd = {'what': 'step_kernel duration (End - Start timestamp of rocprofv3 --kernel
               'gives a fraction 5-6 % lower, by (1) 38 % higher.'}
 for form, sub, cmd in (('eager', 'kt_eager', 'bench.py --no-graph --steps 250 --warmup 50 --no-cpu-baseline --no-fused'),
                        ('graph_50_steps', 'kt_g50', 'bench.py --graph-steps 50 --steps 50 --warmup 50 --no-cpu-baseline --no-fused'),
-                       ('one_long_graph', 'kt', 'bench.py --no-cpu-baseline')):
+                       ('one_long_graph', 'kt', 'bench.py --no-cpu-baseline --eager-loop 0')):
     f = glob.glob(src + '/%s/*/*_kernel_trace.csv' % sub)
     if not f:
         continue
-    d = [int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in csv.DictReader(open(f[0])) if 'step_kernel' in r['Kernel_Name']]
+    d = [int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in csv.DictReader(open(f[0])) if kname(r['Kernel_Name']) == 'step_kernel']
     if not d:
         continue
     rec = {'command': 'rocprofv3 --kernel-trace --stats --output-format csv -- python3 ' + cmd, 'dispatches': len(d), 'avg_ns': st.mean(d),

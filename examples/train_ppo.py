@@ -42,7 +42,7 @@ def evaluate_actor(ac, dev, preset, precision, seed, out=print):
         [round(float(x), 1) for x in r['EpRet']], [int(x) for x in r['EpLen']]))
     res = {'EpRet_mean': float(r['EpRet'].mean()), 'EpLen_mean': float(r['EpLen'].float().mean())}
     T, nb = 1250, 1024
-    for tag, spread in (('nominal hull', 0.0), ('hulls +-15 %', 0.15), ('hulls +-30 %', 0.30)):
+    for tag, spread in (('nominal hull', 0.0), ('hulls +-15 %', 0.15), ('hulls +-30 %', 0.30), ('hulls +-50 %', 0.50)):
         env = ml4ca_amd.BatchedRevoltEnv(nb, device=dev, terminate=False, time_limit=False, seed=seed + 77, vessel_params=nominal)
         if spread > 0:
             env.set_vessel_randomisation(spread, nominal=nominal)          # one draw per env at the reset below; no resets after it

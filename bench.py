@@ -653,15 +653,16 @@ def classes_record(args, dev, n, with_classes=True):
     del env
     # config-2 workload (termination + auto-reset on): shared hull / per-env blocks / per-env blocks re-drawn at every reset
     rnd = {}
-    for tag in ('shared_default', 'per_env', 'per_env_randomised'):
-        env = ml4ca_amd.BatchedRevoltEnv(n, device=dev, terminate=True, auto_reset=True, seed=1)
+    for tag in ('shared_default', 'per_env', 'per_env_randomised', 'thrust_loss_preset'):
+        env = ml4ca_amd.BatchedRevoltEnv(n, device=dev, terminate=True, auto_reset=True, seed=1,
+                                         vessel_params=ml4ca_amd.default_vessel('thrust_loss') if tag == 'thrust_loss_preset' else None)
         if tag == 'per_env':
             env.set_vessel_params(hulls)
         if tag == 'per_env_randomised':
             env.set_vessel_randomisation(0.15)
         env.reset()
         sec = time_steps(env, reps=20)
-        rnd[tag] = {'step_us': sec * 1e6, 'kernel': step_kernel_name(env, {'shared_default': 0, 'per_env': 2, 'per_env_randomised': 4}[tag])}
+        rnd[tag] = {'step_us': sec * 1e6, 'kernel': step_kernel_name(env, {'shared_default': 0, 'per_env': 2, 'per_env_randomised': 4, 'thrust_loss_preset': 4}[tag])}
         for prec in ('f16',):
             ac.upload(env, precision=prec)
             out = policy_rollout(env, CHUNK, sample=True)
@@ -675,7 +676,9 @@ def classes_record(args, dev, n, with_classes=True):
         del env
     per_env['config2_workload'] = dict(rnd, what='terminate + auto_reset on (the training workload): dpenv_step with its reset wave, and the f16 closed loop; '
                                                  'per_env_randomised = dpenv_set_vessel_randomisation(0.15): every reset draws the new episode\'s hull '
-                                                 '(four Philox blocks) - in the reset wave of dpenv_step, in a separate instantiation of the closed-loop kernel')
+                                                 '(four Philox blocks) - in the reset wave of dpenv_step, in a separate instantiation of the closed-loop kernel; '
+                                                 'thrust_loss_preset = dpenv_default_vessel_ex(THRUST_LOSS) as the hull of every env: an inflow thrust loss '
+                                                 'F = K n|n| - Kl |n| u_a, carried by that same general per-env instantiation (32 B more per env-step)')
     rec['per_env'] = per_env
     return rec
 

@@ -82,8 +82,15 @@ enum {
     DPENV_P_LX_BOW, DPENV_P_LX_PORT, DPENV_P_LX_STAR,
     DPENV_P_LY_BOW, DPENV_P_LY_PORT, DPENV_P_LY_STAR,
     DPENV_P_NUV, DPENV_P_YUR, /* speed-proportional cross-flow terms: yaw moment -N_uv u v (adds to the Munk moment -(m22-m11) u v; N_uv < -(m22-m11) would make the hull weathervane-stable), sway force -Y_ur u r */
-    DPENV_NPARAM = 32,   /* slots 26..31 reserved (zero) */
-    DPENV_NPARAM_USED = 26
+    /* BUILD-OWNED inflow thrust loss (the linear open-water characteristic, Fossen 2011 eq. 9.7): F = K n|n| - Kl |n| u_a, u_a = the speed through
+     * the water of the thruster's position along its axis at the start of the env step, never past zero thrust; [N per percent per m/s], >= 0.
+     * 0 (the default hull) is the reference's law F = K n|n| (SupervisedTau.py:42-83) exactly.  Non-zero coefficients are carried by per-env
+     * blocks only - a single class given to dpenv_create is then installed as such, vessel CLASSES (n_classes > 1) may not have them - and select
+     * the general per-env kernels (what it costs: DESIGN.md section 3). */
+    DPENV_P_KLF_BOW, DPENV_P_KLF_PORT, DPENV_P_KLF_STAR, /* n >= 0 */
+    DPENV_P_KLR_BOW, DPENV_P_KLR_PORT, DPENV_P_KLR_STAR, /* n < 0 */
+    DPENV_NPARAM = 32,
+    DPENV_NPARAM_USED = 32
 };
 #define DPENV_MAX_CLASSES 64   /* classes share LDS-staged tables; for more distinct hulls than that - one per env - see dpenv_set_vessel_params */
 
@@ -147,10 +154,11 @@ int dpenv_default_config(dpenv_config* cfg);
 /* Default ReVolt parameter vector. */
 int dpenv_default_vessel(float params[DPENV_NPARAM]);
 /* The presets of the build-owned plant, one per set of steady full-thrust speeds the reference records (customEnv.py:13-18):
- * NO_LOSS = dpenv_default_vessel (+2.20 m/s ahead, 0.60 rad/s: "no thrust losses activated"); THRUST_LOSS = the same hull with the stern
- * thrust gains that give +1.4 / -1.1 m/s ahead / astern ("with thrust losses": the velocity bounds the reference trains with,
- * customEnv.py:26) through the forward / reverse slots.  Pass the vector to dpenv_create, or as `nominal` to
- * dpenv_set_vessel_randomisation. */
+ * NO_LOSS = dpenv_default_vessel (+2.20 m/s ahead, 0.60 rad/s: "no thrust losses activated"); THRUST_LOSS = the same hull with stern
+ * thrusters that meet BOTH sets: their reverse gain from -1.60 m/s astern without losses, their inflow-loss coefficients (DPENV_P_KLF_* /
+ * DPENV_P_KLR_*) from +1.4 / -1.1 m/s ahead / astern "with thrust losses" (the velocity bounds the reference trains with, customEnv.py:26);
+ * yaw then comes out at 0.505 rad/s against the recorded 0.52 (tests/calibration/fit_thrust_loss_preset.py).  Pass the vector to
+ * dpenv_create (one class), in a dpenv_set_vessel_params block, or as `nominal` to dpenv_set_vessel_randomisation. */
 enum { DPENV_VESSEL_NO_LOSS = 0, DPENV_VESSEL_THRUST_LOSS = 1 };
 int dpenv_default_vessel_ex(int32_t kind, float params[DPENV_NPARAM]);
 /* Derived sizes for a config. */
@@ -158,7 +166,9 @@ int dpenv_act_dim(const dpenv_config* cfg);
 int dpenv_obs_dim(const dpenv_config* cfg);
 
 /* Create an environment batch.  vessel_params: host float[n_classes][DPENV_NPARAM], NULL = one
- * default class.  With n_classes > 1 call dpenv_set_vessel_class to assign envs to classes. */
+ * default class.  With n_classes > 1 call dpenv_set_vessel_class to assign envs to classes.
+ * A single class with thrust-loss coefficients is installed as per-env blocks (every env the same block; dpenv_get_vessel_params works,
+ * dpenv_set_vessel_params(h, NULL, s) returns to the class WITHOUT its loss); classes with them are refused. */
 int dpenv_create(const dpenv_config* cfg, const float* vessel_params, int32_t n_classes, dpenv_handle* out);
 int dpenv_destroy(dpenv_handle h);
 /* Message of the last failure on this handle (h == NULL: last failure of dpenv_create in this thread). */
@@ -174,22 +184,25 @@ int dpenv_set_vessel_class(dpenv_handle h, const int32_t* class_id, dpenv_stream
  * Every env gets its OWN hull and thruster parameters - the constants the reference hard-codes once for its one vessel
  * (qp_allocator.py:51-55,69-70 K and lever arms, SupervisedTau.py:35-36,69-71) and the build-owned mass / damping terms of the plant
  * that stands in for customEnv.py:124.  params: DEVICE float[DPENV_NPARAM][n_envs] (structure of arrays: row p = parameter DPENV_P_p of
- * every env; rows 26..31 ignored), copied on the stream: one kernel derives each env's mass-matrix inverse (the same float operations
+ * every env), copied on the stream: one kernel derives each env's mass-matrix inverse (the same float operations
  * as for a class, so an env given its class's numbers reproduces the class path bit for bit) and packs the block as eight float4
- * streams.  dpenv_step then reads 128 B more per env-step (SURVEY 8d accounts 108 B: 285 B per env-step); the T-step kernels
- * (dpenv_rollout, dpenv_policy_rollout) load the block once per launch.  A block that is not a vessel (mass matrix not positive
- * definite, non-finite entry) is not rejected here (no host synchronisation): that env reports DPENV_DONE_FAULT at its first step.
+ * streams (+ two for the thrust-loss coefficients).  dpenv_step then reads 128 B more per env-step (SURVEY 8d accounts 108 B: 285 B per
+ * env-step); the T-step kernels (dpenv_rollout, dpenv_policy_rollout) load the block once per launch.  A block that is not a vessel (mass
+ * matrix not positive definite, non-finite entry, negative loss coefficient) is not rejected here: that env reports DPENV_DONE_FAULT at
+ * its first step.  If ANY env has a thrust-loss coefficient the general per-env kernels run from here on (they read 32 B more per
+ * env-step and apply the loss; envs without a coefficient get the rows of the plain per-env kernels bit for bit) - the one word this
+ * setter reads back: it SYNCHRONISES the stream (do not call it inside a stream capture).
  * params == NULL: back to the vessel classes / the single class of dpenv_create (the shared-default fast path: parameters in SGPRs).
  * Switching between the paths voids HIP graphs captured before (the table's address is a kernel argument). */
 int dpenv_set_vessel_params(dpenv_handle h, const float* params, dpenv_stream s);
-/* The parameter vectors in force: DEVICE float[DPENV_NPARAM][n_envs] (rows 26..31 zero).  Needs per-env blocks in force. */
+/* The parameter vectors in force: DEVICE float[DPENV_NPARAM][n_envs].  Needs per-env blocks in force. */
 int dpenv_get_vessel_params(dpenv_handle h, float* params_out, dpenv_stream s);
 /* Domain randomisation through the reset path: from this call on EVERY reset of an env - dpenv_reset (also with explicit init),
  * auto-reset inside dpenv_step / dpenv_rollout / dpenv_policy_rollout, reset_at_end - starts the new episode on a freshly drawn hull:
  *   parameter p = nominal[p] * (1 + rel_range[p] * u),  u uniform in [-1, 1) (16 bits),
  * Philox4x32-10 keyed by config.seed with counter (global env id, episode counter, tag 0x48000000 | block) - parameter p takes the
  * 16-bit half (q & 1) of word (q & 7) >> 1 of block q >> 3, q = its slot in the order m11 m22 m23 m33 Xu (0..4) | Xuu Yv Yvv Yr Nv Nr Nrr
- * Nuv (8..15) | Yur Kf[3] Kr[3] lx_bow (16..23) | lx_port lx_star ly[3] (24..28); u = h / 32768 - 1: a function of the env and of
+ * Nuv (8..15) | Yur Kf[3] Kr[3] lx_bow (16..23) | lx_port lx_star ly[3] Klf[3] (24..31), Klr[3] (5..7); u = h / 32768 - 1: a function of the env and of
  * its episode like the pose sample, so hulls do not depend on the rank count or on the launch form, and a checkpoint (dpenv_get_state
  * counters + dpenv_get_vessel_params) restores them.  nominal: HOST float[DPENV_NPARAM], NULL = class 0 of dpenv_create; rel_range:
  * HOST float[DPENV_NPARAM], entries in [0, 1), 0 = that parameter is not randomised; every hull of the range must have a positive

@@ -19,7 +19,7 @@ ACT_LEAKY_RELU, ACT_TANH = 0, 1
 POLICY_F16, POLICY_F32, POLICY_F32_ACTOR = 0, 1, 2
 LAUNCH_AUTO, LAUNCH_ONE_WAVE, LAUNCH_TWO_WAVE = 0, 1, 2
 DONE_TERMINAL, DONE_TIMELIMIT, DONE_FAULT = 1, 2, 4
-NSTATE, NPARAM, NPARAM_USED, MAX_CLASSES = 15, 32, 26, 64
+NSTATE, NPARAM, NPARAM_USED, MAX_CLASSES = 15, 32, 32, 64
 ABI_VERSION = 4
 
 # canonical state rows (dpenv.h DPENV_S_*)
@@ -28,7 +28,8 @@ S = dict(N=0, E=1, PSI=2, U=3, V=4, R=5, REF_N=6, REF_E=7, REF_PSI=8,
 # vessel parameter slots (dpenv.h DPENV_P_*)
 P = dict(M11=0, M22=1, M23=2, M33=3, XU=4, XUU=5, YV=6, YVV=7, YR=8, NV=9, NR=10, NRR=11,
          KF_BOW=12, KF_PORT=13, KF_STAR=14, KR_BOW=15, KR_PORT=16, KR_STAR=17,
-         LX_BOW=18, LX_PORT=19, LX_STAR=20, LY_BOW=21, LY_PORT=22, LY_STAR=23, NUV=24, YUR=25)
+         LX_BOW=18, LX_PORT=19, LX_STAR=20, LY_BOW=21, LY_PORT=22, LY_STAR=23, NUV=24, YUR=25,
+         KLF_BOW=26, KLF_PORT=27, KLF_STAR=28, KLR_BOW=29, KLR_PORT=30, KLR_STAR=31)
 
 
 class Config(C.Structure):

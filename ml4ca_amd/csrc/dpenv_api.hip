@@ -31,8 +31,10 @@ struct dpenv_s {
     float* cur_beta0;
     uint32_t* drift_ctr;
     int32_t* class_id;
-    float4* env_tab;        // per-env parameter blocks ET[ENV_GROUPS][env_stride] (dpenv_dev.h), always allocated
+    float4* env_tab;        // per-env parameter blocks + thrust-loss rows ET[DRAW_GROUPS][env_stride] (dpenv_dev.h), always allocated
     int env_stride;
+    uint32_t* loss_flag;    // device word the packing kernel reports "some env has a thrust-loss coefficient" through
+    bool loss_on;           // ... read back: the kernels of the general per-env form apply the loss (StepArgs.loss_on)
     float* rand_tab;        // device float[RAND_TAB_FLOATS]: nominal | relative half-range of the domain randomisation
     float rand_host[RAND_TAB_FLOATS];   // its host image (the source of the stream-ordered upload must outlive the call)
     float raw0[DPENV_NPARAM];           // public parameter vector of class 0 (the randomisation's default nominal hull)
@@ -152,17 +154,21 @@ extern "C" int dpenv_default_vessel(float* p)
 
 // The same hull with the thrust gains of the reference's SECOND set of steady full-thrust speeds - "with thrust losses" +1.4 / -1.1 m/s
 // ahead / astern (customEnv.py:17), which are also the velocity bounds it trains with (customEnv.py:26) - derived by
-// tests/calibration/fit_thrust_loss_preset.py: stern gains 0.44 (ahead) / 0.29 (astern) of the no-loss ones through the forward / reverse
-// slots, bow unchanged (sway 0.29 m/s against the recorded 0.30); the hull is untouched, so the free-drift record is reproduced as
-// before.  Yaw comes out at 0.35 rad/s against the recorded 0.52: a constant gain cannot be 0.44 at 1.4 m/s inflow and 0.87 at none
-// (DESIGN.md section 3).  Not the default: the recorded Cybersea manoeuvres (low speed) replay better with the no-loss gains.
+// tests/calibration/fit_thrust_loss_preset.py as an INFLOW loss of the stern thrusters, F = K n|n| - Kl |n| u_a (u_a: the water's speed
+// along the thruster axis; never past zero thrust), their reverse gain from the no-loss astern speed (-1.60 m/s, customEnv.py:14); bow
+// unchanged (sway 0.29 m/s against the recorded 0.30); the hull is untouched, so the free-drift record is reproduced as before.  Yaw comes
+// out at 0.505 rad/s against the recorded 0.52 (a constant gain reduced to meet +1.4 m/s - round 5's first form of this preset - gave 0.35).
+// Not the default: the loss code lives in the general per-env kernels only (DESIGN.md section 3 for what it costs and what it changes).
 extern "C" int dpenv_default_vessel_ex(int32_t kind, float* p)
 {
     if (!p || (kind != DPENV_VESSEL_NO_LOSS && kind != DPENV_VESSEL_THRUST_LOSS)) return DPENV_EINVAL;
     dpenv_default_vessel(p);
     if (kind == DPENV_VESSEL_THRUST_LOSS) {
-        p[DPENV_P_KF_PORT] = p[DPENV_P_KF_STAR] = 0.0009059f;
-        p[DPENV_P_KR_PORT] = p[DPENV_P_KR_STAR] = 0.0005949f;
+        // tests/calibration/fit_thrust_loss_preset.py: stern reverse gain from -1.60 m/s astern without losses, inflow-loss coefficients from
+        // +1.4 / -1.1 m/s with losses (customEnv.py:14,17); the bow thruster keeps its gain and has no loss
+        p[DPENV_P_KR_PORT] = p[DPENV_P_KR_STAR] = 0.001149f;
+        p[DPENV_P_KLF_PORT] = p[DPENV_P_KLF_STAR] = 0.08173f;
+        p[DPENV_P_KLR_PORT] = p[DPENV_P_KLR_STAR] = 0.05039f;
     }
     return DPENV_OK;
 }
@@ -197,7 +203,8 @@ extern "C" int dpenv_obs_dim(const dpenv_config* c)
     return c->extended_state ? 9 : 6;   // customEnv.py:44
 }
 
-static int derive_vessel(const float* p, VesselDev* d, std::string* why)
+// allow_loss: the caller deals with the inflow thrust-loss coefficients (parameters 26-31), which are not part of a VesselDev
+static int derive_vessel(const float* p, VesselDev* d, std::string* why, bool allow_loss = false)
 {
     const double m11 = p[DPENV_P_M11], m22 = p[DPENV_P_M22], m23 = p[DPENV_P_M23], m33 = p[DPENV_P_M33];
     const double det = m22 * m33 - m23 * m23;
@@ -220,6 +227,11 @@ static int derive_vessel(const float* p, VesselDev* d, std::string* why)
     for (int i = 0; i < 3; ++i) {
         d->p[VD_KF + i] = p[DPENV_P_KF_BOW + i]; d->p[VD_KR + i] = p[DPENV_P_KR_BOW + i];
         d->p[VD_LX + i] = p[DPENV_P_LX_BOW + i]; d->p[VD_LY + i] = p[DPENV_P_LY_BOW + i];
+        if (!(p[DPENV_P_KLF_BOW + i] >= 0.0f) || !(p[DPENV_P_KLR_BOW + i] >= 0.0f)) { *why = "thrust-loss coefficients must be >= 0"; return DPENV_EINVAL; }
+        if (!allow_loss && (p[DPENV_P_KLF_BOW + i] != 0.0f || p[DPENV_P_KLR_BOW + i] != 0.0f)) {
+            *why = "thrust-loss coefficients (parameters 26-31) are not available to vessel CLASSES: one class, per-env blocks (dpenv_set_vessel_params) or the nominal hull of dpenv_set_vessel_randomisation";
+            return DPENV_EINVAL;
+        }
     }
     return DPENV_OK;
 }
@@ -275,6 +287,7 @@ extern "C" int dpenv_create(const dpenv_config* cfg, const float* vessel_params,
     h->classes_assigned = false;
     h->per_env = false;
     h->randomise = false;
+    h->loss_on = false;
     h->current_set = false;
     h->pol_buf = nullptr; h->pol_buf_bytes = 0;
     h->pol_slot = 0;
@@ -299,7 +312,7 @@ extern "C" int dpenv_create(const dpenv_config* cfg, const float* vessel_params,
     for (int c = 0; c < n_classes; ++c) {
         std::string why;
         const float* p = vessel_params ? vessel_params + (size_t)c * DPENV_NPARAM : defp;
-        if (derive_vessel(p, &tab[c], &why) != DPENV_OK) {
+        if (derive_vessel(p, &tab[c], &why, n_classes == 1) != DPENV_OK) {
             delete h;
             return fail(nullptr, DPENV_EINVAL, "vessel class %d: %s", c, why.c_str());
         }
@@ -324,7 +337,8 @@ extern "C" int dpenv_create(const dpenv_config* cfg, const float* vessel_params,
     const size_t o_s3 = off; off += npad * 16;
     const size_t o_ct = off; off += align_up(sizeof(VesselDev) * MAX_CLASSES, 256);
     const size_t o_rt = off; off += align_up(sizeof(float) * RAND_TAB_FLOATS, 256);
-    const size_t o_et = off; off += npad * 16 * ENV_GROUPS;
+    const size_t o_lf = off; off += 256;
+    const size_t o_et = off; off += npad * 16 * DRAW_GROUPS;
     h->blob_bytes = off;
     void* blob = nullptr;
     e = hipMalloc(&blob, off);
@@ -354,6 +368,7 @@ extern "C" int dpenv_create(const dpenv_config* cfg, const float* vessel_params,
     h->env_tab = (float4*)(b + o_et);
     h->env_stride = (int)npad;
     h->rand_tab = (float*)(b + o_rt);
+    h->loss_flag = (uint32_t*)(b + o_lf);
     a.class_tab = (const float*)(b + o_ct);
     a.n_classes = n_classes;
     a.v0 = tab[0];
@@ -383,6 +398,24 @@ extern "C" int dpenv_create(const dpenv_config* cfg, const float* vessel_params,
     a.reset_acts = cfg->reset_acts ? 1 : 0;
     a.noise_ctr = h->noise_ctr;
     a.S3 = (float4*)(b + o_s3);
+    {
+        // a single class WITH thrust-loss coefficients: only the general per-env kernels carry the loss code (dpenv_dev.h), so the hull is
+        // installed as per-env blocks, every env the same one (dpenv_set_vessel_params(h, NULL) would return to the class without its loss)
+        bool any = false;
+        for (int p = DPENV_P_KLF_BOW; p <= DPENV_P_KLR_STAR; ++p) any = any || h->raw0[p] != 0.0f;
+        if (any) {
+            e = hipMemcpy(h->rand_tab, h->raw0, sizeof h->raw0, hipMemcpyHostToDevice);     // (the nominal half of the randomisation's table: its default)
+            if (e == hipSuccess) e = dpenv_dev_launch_pack_env_vessels(h->rand_tab, 1, 0, h->env_tab, nullptr, h->env_stride, cfg->n_envs, nullptr);
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+            if (e != hipSuccess) {
+                (void)hipFree(blob);
+                delete h;
+                return fail(nullptr, DPENV_EHIP, "per-env blocks of the thrust-loss hull: %s", hipGetErrorString(e));
+            }
+            h->per_env = true;
+            h->loss_on = true;
+        }
+    }
     *out = h;
     return DPENV_OK;
 }
@@ -467,13 +500,14 @@ static void bind_optional(dpenv_handle h, StepArgs& a)
     a.class_id = h->class_id;
     a.env_tab = h->per_env ? h->env_tab : nullptr;
     a.env_stride = h->env_stride;
+    a.loss_on = (h->per_env && h->loss_on) ? 1 : 0;
     a.rand_tab = (h->per_env && h->randomise) ? h->rand_tab : nullptr;
 }
 
 // where the kernels take a lane's vessel from (dpenv_dev.h VES_*)
 static int vessel_source(dpenv_handle h)
 {
-    if (h->per_env) return h->randomise ? VES_ENV_RND : (h->cfg.per_env_lds ? VES_ENV_LDS : VES_ENV_VGPR);
+    if (h->per_env) return (h->randomise || h->loss_on) ? VES_ENV_RND : (h->cfg.per_env_lds ? VES_ENV_LDS : VES_ENV_VGPR);
     return h->n_classes > 1 ? VES_CLASS_LDS : VES_ARGS;
 }
 
@@ -485,9 +519,21 @@ extern "C" int dpenv_set_vessel_params(dpenv_handle h, const float* params, dpen
     if (!h) return DPENV_EINVAL;
     DeviceGuard dev_guard(h->device);
     h->randomise = false;
-    if (!params) { h->per_env = false; return DPENV_OK; }              // back to the classes / the single class
-    HIP_TRY(h, dpenv_dev_launch_pack_env_vessels(params, (int64_t)h->cfg.n_envs, 1, h->env_tab, h->env_stride, h->cfg.n_envs, (hipStream_t)s));
+    h->loss_on = false;
+    if (!params) {
+        h->per_env = false;               // back to the classes / the single class (which carry no thrust loss)
+        h->loss_on = false;
+        return DPENV_OK;
+    }
+    HIP_TRY(h, hipMemsetAsync(h->loss_flag, 0, sizeof(uint32_t), (hipStream_t)s));          // the packing kernel sets it if any env has a coefficient
+    HIP_TRY(h, dpenv_dev_launch_pack_env_vessels(params, (int64_t)h->cfg.n_envs, 1, h->env_tab, h->loss_flag, h->env_stride, h->cfg.n_envs, (hipStream_t)s));
+    // which kernels run from here on depends on whether any env has a thrust-loss coefficient (the general per-env form applies it, the
+    // plain one does not carry the code): the one word the host has to wait for - this setter synchronises the stream
+    uint32_t flag = 0;
+    HIP_TRY(h, hipMemcpyAsync(&flag, h->loss_flag, sizeof flag, hipMemcpyDeviceToHost, (hipStream_t)s));
+    HIP_TRY(h, hipStreamSynchronize((hipStream_t)s));
     h->per_env = true;
+    h->loss_on = flag != 0u;
     return DPENV_OK;
 }
 
@@ -508,8 +554,8 @@ extern "C" int dpenv_set_vessel_randomisation(dpenv_handle h, const float* nomin
     const float* nom = nominal ? nominal : h->raw0;
     for (int p = 0; p < DPENV_NPARAM; ++p) {
         const float r = p < RAND_NPARAM ? rel_range[p] : 0.0f;
-        if (!std::isfinite(nom[p]) || !(r >= 0.0f && r < 1.0f))
-            return fail(h, DPENV_EINVAL, "parameter %d: nominal must be finite and the relative half-range in [0, 1)", p);
+        if (!std::isfinite(nom[p]) || !(r >= 0.0f && r < 1.0f) || (p >= DPENV_P_KLF_BOW && nom[p] < 0.0f))
+            return fail(h, DPENV_EINVAL, "parameter %d: nominal must be finite (thrust-loss coefficients >= 0) and the relative half-range in [0, 1)", p);
         h->rand_host[p] = nom[p];
         h->rand_host[32 + p] = r;
     }
@@ -524,9 +570,11 @@ extern "C" int dpenv_set_vessel_randomisation(dpenv_handle h, const float* nomin
     }
     HIP_TRY(h, hipMemcpyAsync(h->rand_tab, h->rand_host, sizeof h->rand_host, hipMemcpyHostToDevice, (hipStream_t)s));
     // until its first reset every env runs on the nominal hull
-    HIP_TRY(h, dpenv_dev_launch_pack_env_vessels(h->rand_tab, 1, 0, h->env_tab, h->env_stride, h->cfg.n_envs, (hipStream_t)s));
+    HIP_TRY(h, dpenv_dev_launch_pack_env_vessels(h->rand_tab, 1, 0, h->env_tab, nullptr, h->env_stride, h->cfg.n_envs, (hipStream_t)s));
     h->per_env = true;
     h->randomise = true;
+    h->loss_on = false;                                 // a draw scales the nominal value: no coefficient there, none in any hull
+    for (int p = DPENV_P_KLF_BOW; p <= DPENV_P_KLR_STAR; ++p) h->loss_on = h->loss_on || nom[p] != 0.0f;
     return DPENV_OK;
 }
 
@@ -930,7 +978,7 @@ extern "C" int dpenv_policy_rollout(dpenv_handle h, const dpenv_policy_rollout_i
     // the two-wave kernels carry the randomisation's hull re-draw in an instantiation of their own, built for the shipped training configuration
     // (final / continuous angles / extended state, leaky-relu or relu networks); everything else runs the one-wave kernels while the
     // randomisation is on - the same rows bit for bit, the draw a run-time switch there
-    if (a.rand_tab && pa.ws && !(h->mode == MODE_FINAL_CONT && h->cfg.extended_state && pa.act == DPENV_ACT_LEAKY_RELU)) pa.ws = 0;
+    if ((a.rand_tab || a.loss_on) && pa.ws && !(h->mode == MODE_FINAL_CONT && h->cfg.extended_state && pa.act == DPENV_ACT_LEAKY_RELU)) pa.ws = 0;
     if (pa.split) HIP_TRY(h, dpenv_dev_launch_policy_rollout_x(&a, &pa, h->mode, h->cfg.extended_state, (hipStream_t)s));
     else HIP_TRY(h, dpenv_dev_launch_policy_rollout(&a, &pa, h->mode, h->cfg.extended_state, (hipStream_t)s));
     h->lag_valid = true;
@@ -1002,7 +1050,7 @@ extern "C" int dpenv_thrust_map(const float* params, const float* n_pct, const f
     if (!params) { dpenv_default_vessel(defp); params = defp; }
     VesselDev vd;
     std::string why;
-    if (derive_vessel(params, &vd, &why) != DPENV_OK) return fail(nullptr, DPENV_EINVAL, "%s", why.c_str());
+    if (derive_vessel(params, &vd, &why, true) != DPENV_OK) return fail(nullptr, DPENV_EINVAL, "%s", why.c_str());
     HIP_TRY(nullptr, dpenv_dev_launch_thrust_map(&vd, n_pct, alpha, tau_out, n, (hipStream_t)s));
     return DPENV_OK;
 }

@@ -44,7 +44,16 @@ constexpr int VD_M33 = VD_COUNT;          // slot of the raw m33 in a per-env bl
 constexpr int ENV_GROUPS = 8;
 constexpr int ENV_BLOCK_FLOATS = 4 * ENV_GROUPS;
 static_assert(VD_COUNT + 1 <= ENV_BLOCK_FLOATS, "per-env block: derived parameters + m33 must fit eight float4");
-constexpr int RAND_NPARAM = 26;           // public parameters DPENV_P_M11 .. DPENV_P_YUR (include/dpenv.h); slots 26..31 of the vector are reserved
+constexpr int RAND_NPARAM = 32;           // public parameters DPENV_P_M11 .. DPENV_P_KLR_STAR (include/dpenv.h): the whole vector
+// The six inflow thrust-loss coefficients (DPENV_P_KLF_* / DPENV_P_KLR_*) are NOT part of the Vessel the kernels carry in registers: they
+// are two more rows of the per-env table, ET[ENV_GROUPS] = (Klf bow, port, star, Klr bow) and ET[ENV_GROUPS + 1] = (Klr port, star, -, -),
+// read at the force map of an env step ONLY by the GENERAL per-env kernels (VES_ENV_RND below; the closed loop's RND instantiations and its
+// one-wave forms) and only while StepArgs.loss_on says some env has one.  Every other kernel passes a compile-time "no table" and is, to
+// the instruction, what it was before the loss existed: built both ways (round 5) - with the coefficients inside the Vessel the 256-env f16
+// closed loop went from 76 to 100 B of scratch, behind a run-time flag in every kernel from 76 to 92 B and the headline step kernel from
+// 63 to 66 VGPRs (one wave per SIMD less).  In the randomisation's draw they are groups 8 and 9.
+constexpr int LOSS_GROUPS = 2;
+constexpr int DRAW_GROUPS = ENV_GROUPS + LOSS_GROUPS;
 constexpr int RAND_TAB_FLOATS = 64;       // device table of the randomisation: [0..31] nominal public parameters, [32..63] relative half-ranges
 
 // where step_kernel takes a lane's vessel from (template argument VES)
@@ -52,8 +61,9 @@ enum { VES_ARGS = 0,      // one class: kernel arguments (SGPRs)
        VES_CLASS_LDS = 1, // vessel classes: [class][param] table staged into LDS as [param][class]
        VES_ENV_VGPR = 2,  // per-env blocks: eight coalesced float4 loads per lane straight into registers
        VES_ENV_LDS = 3,   // per-env blocks: LDS-DMA (global_load_lds_dwordx4) into a [group][lane] image, read back when needed (the A/B of SURVEY 7)
-       VES_ENV_RND = 4 }; // VES_ENV_VGPR + the domain randomisation's hull re-draw compiled into the reset paths (its own instantiation: the draw's
-                          //   four Philox blocks cost the register allocation of the other forms 15-70 VGPRs when they share the code)
+       VES_ENV_RND = 4 }; // the GENERAL per-env form: VES_ENV_VGPR + the domain randomisation's hull re-draw in the reset paths (while StepArgs.rand_tab)
+                          //   + the inflow thrust loss (while StepArgs.loss_on).  Its own instantiation: the draw's four Philox blocks cost the register
+                          //   allocation of the other forms 15-70 VGPRs when they share the code, the loss 10-16
 
 struct StepArgs {
     // library-owned state streams (see dpenv_kernels.hip header)
@@ -105,6 +115,7 @@ struct StepArgs {
     float4* env_tab;          // per-env parameter blocks ET[ENV_GROUPS][env_stride], NULL = classes / the single class (written by the kernels only
                               //   when the randomisation re-draws a hull)
     int32_t env_stride;
+    int32_t loss_on;          // some env has a non-zero inflow thrust-loss coefficient (rows ENV_GROUPS.. of env_tab): the general per-env kernels apply it
     const float* rand_tab;    // domain randomisation on: device float[RAND_TAB_FLOATS] (nominal | relative half-range); every reset - explicit,
                               //   auto, reset_at_end - re-draws the env's hull for the new episode, Philox keyed (seed; global env id, episode)
 };
@@ -204,7 +215,10 @@ hipError_t dpenv_dev_launch_rollout(const dpenv::StepArgs* a, const dpenv::Rollo
 hipError_t dpenv_dev_launch_step(const dpenv::StepArgs* a, int mode, int ext, int ves, int reset_wave, hipStream_t s);
 // raw public parameters -> per-env blocks: raw[p * p_stride + i * i_stride] (SoA block: p_stride = n, i_stride = 1; one vector for every env:
 // p_stride = 1, i_stride = 0); and back (out[p * n + i])
-hipError_t dpenv_dev_launch_pack_env_vessels(const float* raw, int64_t p_stride, int64_t i_stride, float4* tab, int stride, int n, hipStream_t s);
+// tab: ET[DRAW_GROUPS][stride] (vessel block + thrust-loss rows); loss_flag (device word, may be NULL) is OR-ed with 1 if any env's
+// thrust-loss coefficient is non-zero
+hipError_t dpenv_dev_launch_pack_env_vessels(const float* raw, int64_t p_stride, int64_t i_stride, float4* tab, uint32_t* loss_flag,
+                                             int stride, int n, hipStream_t s);
 hipError_t dpenv_dev_launch_unpack_env_vessels(const float4* tab, int stride, float* out, int n, hipStream_t s);
 hipError_t dpenv_dev_launch_reset(const dpenv::StepArgs* a, int mode, int ext, const uint8_t* mask, const float* init,
                                   const float* ref, hipStream_t s);

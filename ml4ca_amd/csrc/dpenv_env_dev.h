@@ -244,7 +244,9 @@ __device__ __forceinline__ void derive_env_block(const float raw[RAND_NPARAM], f
     float chk = 0.0f;
 #pragma unroll
     for (int k = 0; k < RAND_NPARAM; ++k) chk += raw[k];
-    const bool ok = (m11 > 0.0f) && (m22 > 0.0f) && (fdet > 0.0f) && (fabsf(chk) <= 3.0e38f);
+    bool ok = (m11 > 0.0f) && (m22 > 0.0f) && (fdet > 0.0f) && (fabsf(chk) <= 3.0e38f);
+#pragma unroll
+    for (int k = 26; k < RAND_NPARAM; ++k) ok = ok && (raw[k] >= 0.0f);      // thrust-loss coefficients (kept in the loss table, not in d)
     if (!ok) {
 #pragma unroll
         for (int k = 0; k < ENV_BLOCK_FLOATS; ++k) d[k] = __builtin_nanf("");
@@ -262,9 +264,10 @@ __device__ __forceinline__ void store_env_block(float4* tab, int stride, int i, 
 // Philox4x32-10 blocks keyed by the seed with counter (global env id, episode, tag 0x48000000 | block): a pure function of the env and
 // of its episode, like the pose sample (tags 0, 1) and the reset thrust (tag 2) - so a sharded run draws the hulls of a single-process run.
 // A parameter's 16 bits are half (q & 1) of word (q & 7) >> 1 of block q >> 3, q = its SLOT: the parameters are numbered in the order
-// of the packed block (m11 m22 m23 m33 Xu | Xuu Yv Yvv Yr Nv Nr Nrr Nuv | Yur Kf Kr lx_bow | lx_port lx_star ly), so that Philox block b
-// yields exactly float4 groups 2b and 2b + 1 of the block: the draw is STREAMED - one Philox block, eight parameters, two groups handed
-// to `emit(g, float4)` - and never holds more than a dozen values (a reset sits inside kernels that have no registers to spare).
+// of the packed block (m11 m22 m23 m33 Xu Klr[3] | Xuu Yv Yvv Yr Nv Nr Nrr Nuv | Yur Kf Kr lx_bow | lx_port lx_star ly Klf[3]), so that
+// Philox block b yields exactly float4 groups 2b and 2b + 1 of the block: the draw is STREAMED - one Philox block, eight parameters, two
+// groups handed to `emit(g, float4)` - and never holds more than a dozen values (a reset sits inside kernels that have no registers to
+// spare).  Groups 8 and 9 (emitted last, from values of blocks 0 and 3) are the thrust-loss table's (dpenv_dev.h LOSS_GROUPS).
 // The slot table is part of the definition of the draw (include/dpenv.h, dpenv_set_vessel_randomisation).
 struct HullKey {            // what the draw needs of the kernel arguments
     const float* rand_tab;
@@ -286,13 +289,14 @@ __device__ __forceinline__ void draw_env_groups(const HullKey& a, int64_t gid, u
     const uint32_t g0 = (uint32_t)((uint64_t)gid & 0xffffffffu), g1 = (uint32_t)((uint64_t)gid >> 32);
     const float nan = __builtin_nanf("");
     uint32_t w[4];
-    float m33;
+    float m33, klr0, klr1, klr2, klf0, klf1, klf2;
     bool ok;
     {
         philox4x32_10(g0, g1, episode, 0x48000000u, a.seed_lo, a.seed_hi, w);
         const float m11 = rand_param(a, w, 0, 0), m22 = rand_param(a, w, 1, 1), m23 = rand_param(a, w, 2, 2);
         m33 = rand_param(a, w, 3, 3);
         const float Xu = rand_param(a, w, 4, 4);
+        klr0 = rand_param(a, w, 29, 5); klr1 = rand_param(a, w, 30, 6); klr2 = rand_param(a, w, 31, 7);
         // the mass-matrix inverse with derive_env_block's operations (the range was checked on the host: every hull is a vessel;
         // a non-finite nominal entry set behind the library's back still ends as NaN blocks, i.e. as DPENV_DONE_FAULT)
         const float fdet = m22 * m33 - m23 * m23;
@@ -314,7 +318,16 @@ __device__ __forceinline__ void draw_env_groups(const HullKey& a, int64_t gid, u
         philox4x32_10(g0, g1, episode, 0x48000003u, a.seed_lo, a.seed_hi, w);
         emit(6, make_float4(rand_param(a, w, 19, 24), rand_param(a, w, 20, 25), rand_param(a, w, 21, 26), rand_param(a, w, 22, 27)));  // lx_port lx_star ly_bow ly_port
         emit(7, make_float4(rand_param(a, w, 23, 28), ok ? m33 : nan, 0.0f, 0.0f));                                                     // ly_star | raw m33
+        klf0 = rand_param(a, w, 26, 29); klf1 = rand_param(a, w, 27, 30); klf2 = rand_param(a, w, 28, 31);
     }
+    emit(8, make_float4(klf0, klf1, klf2, klr0));                                                                                       // the loss table's two groups
+    emit(9, make_float4(klr1, klr2, 0.0f, 0.0f));
+}
+
+// where group g of a draw goes: the env's vessel block (g < ENV_GROUPS) or its thrust-loss coefficients behind it (ET has DRAW_GROUPS rows)
+__device__ __forceinline__ void store_draw_group(float4* env_tab, int stride, int i, int g, const float4& q)
+{
+    env_tab[(int64_t)g * stride + i] = q;
 }
 
 // group g of a packed block -> the fields of a Vessel (VD order, dpenv_dev.h)
@@ -328,20 +341,21 @@ __device__ __forceinline__ void vessel_set_group(Vessel& v, int g, const float4&
     case 4: v.Yur = q.x; v.Kf[0] = q.y; v.Kf[1] = q.z; v.Kf[2] = q.w; break;
     case 5: v.Kr[0] = q.x; v.Kr[1] = q.y; v.Kr[2] = q.z; v.lx[0] = q.w; break;
     case 6: v.lx[1] = q.x; v.lx[2] = q.y; v.ly[0] = q.z; v.ly[1] = q.w; break;
-    default: v.ly[2] = q.x; break;
+    case 7: v.ly[2] = q.x; break;
+    default: break;                                          // groups 8, 9: the thrust-loss table's, not the vessel's
     }
 }
 
 // a reset with the randomisation on: draw the new episode's hull group by group, into the table ...
 __device__ __forceinline__ void redraw_vessel_table(const StepArgs& a, int i, uint32_t episode)
 {
-    draw_env_groups(hull_key(a), a.env_id_base + i, episode, [&](int g, const float4& q) { a.env_tab[(int64_t)g * a.env_stride + i] = q; });
+    draw_env_groups(hull_key(a), a.env_id_base + i, episode, [&](int g, const float4& q) { store_draw_group(a.env_tab, a.env_stride, i, g, q); });
 }
 // ... and into the registers the launch runs on with
 __device__ __forceinline__ void redraw_vessel(const StepArgs& a, int i, uint32_t episode, Vessel& ve)
 {
     draw_env_groups(hull_key(a), a.env_id_base + i, episode, [&](int g, const float4& q) {
-        a.env_tab[(int64_t)g * a.env_stride + i] = q;
+        store_draw_group(a.env_tab, a.env_stride, i, g, q);
         vessel_set_group(ve, g, q);
     });
 }
@@ -354,7 +368,7 @@ __device__ __forceinline__ void redraw_vessel(const StepArgs& a, int i, uint32_t
 static __device__ __attribute__((noinline)) void redraw_vessel_table_call(const float* rand_tab, uint32_t seed_lo, uint32_t seed_hi, float4* env_tab,
                                                                           int env_stride, int64_t gid, int i, uint32_t episode)
 {
-    draw_env_groups(HullKey{rand_tab, seed_lo, seed_hi}, gid, episode, [&](int g, const float4& q) { env_tab[(int64_t)g * env_stride + i] = q; });
+    draw_env_groups(HullKey{rand_tab, seed_lo, seed_hi}, gid, episode, [&](int g, const float4& q) { store_draw_group(env_tab, env_stride, i, g, q); });
 }
 __device__ __forceinline__ void redraw_vessel_cold(const StepArgs& a, int i, uint32_t episode, Vessel& ve)
 {
@@ -363,16 +377,25 @@ __device__ __forceinline__ void redraw_vessel_cold(const StepArgs& a, int i, uin
     for (int g = 0; g < ENV_GROUPS; ++g) vessel_set_group(ve, g, a.env_tab[(int64_t)g * a.env_stride + i]);
 }
 
+// BUILD-OWNED inflow thrust loss (round 5): F_i = K_i n_i|n_i| - Kl_i |n_i| u_a,i, u_a,i = the inflow along thruster i's
+// axis at its position, (u, v, r) = the velocity through the water at the start of the env step - the linear open-water characteristic
+// K_T(J) = K_T0 (1 - J / J0) (Fossen 2011, eq. 9.7) - never past zero thrust.  Coefficients forward / reverse like the gains.
+struct ThrustLoss {
+    float klf[3], klr[3];
+    float u, v, r;
+};
+
 // SupervisedTau.py:42-83: tau = B(alpha) F, F_i = K_i n_i |n_i|
 // sc != nullptr: sin/cos of the port and starboard azimuths are already known (sc = {sin_p, cos_p, sin_s, cos_s})
+// tl != nullptr (wave-uniform): the inflow thrust loss above is applied; nullptr - the default hull - is the reference's law, untouched
 __device__ __forceinline__ void thrust_map(const Vessel& ve, const float n[3], const float al[3], float& tx, float& ty,
-                                           float& tn, const float* sc = nullptr)
+                                           float& tn, const float* sc = nullptr, const ThrustLoss* tl = nullptr)
 {
     tx = 0.0f; ty = 0.0f; tn = 0.0f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const float K = (n[i] >= 0.0f) ? ve.Kf[i] : ve.Kr[i];
-        const float F = K * fabsf(n[i]) * n[i];
+        float F = K * fabsf(n[i]) * n[i];
         float sa, ca;
         if (i > 0 && sc != nullptr) {
             sa = sc[2 * (i - 1)]; ca = sc[2 * (i - 1) + 1];
@@ -382,6 +405,12 @@ __device__ __forceinline__ void thrust_map(const Vessel& ve, const float n[3], c
             sa = 1.0f; ca = -4.371139e-08f;
         } else {
             sincos_lean(al[i], sa, ca);
+        }
+        if (tl != nullptr) {
+            const bool ahead = n[i] >= 0.0f;
+            const float ua = fmaf(fmaf(-ve.ly[i], tl->r, tl->u), ca, fmaf(ve.lx[i], tl->r, tl->v) * sa);
+            F = fmaf(-((ahead ? tl->klf[i] : tl->klr[i]) * fabsf(n[i])), ua, F);
+            F = ahead ? fmaxf(F, 0.0f) : fminf(F, 0.0f);
         }
         tx = fmaf(ca, F, tx);
         ty = fmaf(sa, F, ty);
@@ -658,7 +687,7 @@ __device__ __forceinline__ void env_decode_cmd(float ang[3], const float* act, f
 }
 
 template <int MODE, bool DEFER_ANG = false>
-__device__ __forceinline__ void env_decode(const Vessel& ve, float ang[3], const float* act, Wrench& w)
+__device__ __forceinline__ void env_decode(const Vessel& ve, float ang[3], const float* act, Wrench& w, const ThrustLoss* tl = nullptr)
 {
     env_decode_cmd<MODE, DEFER_ANG>(ang, act, w.thr);
     if (MODE == MODE_FINAL_CONT) {
@@ -669,9 +698,9 @@ __device__ __forceinline__ void env_decode(const Vessel& ve, float ang[3], const
         const float ip = __builtin_amdgcn_rsqf(np2), is = __builtin_amdgcn_rsqf(ns2);
         sc[0] = (np2 > 0.0f) ? act[3] * ip : 0.0f; sc[1] = (np2 > 0.0f) ? act[4] * ip : 1.0f;
         sc[2] = (ns2 > 0.0f) ? act[5] * is : 0.0f; sc[3] = (ns2 > 0.0f) ? act[6] * is : 1.0f;
-        thrust_map(ve, w.thr, ang, w.tx, w.ty, w.tn, sc);
+        thrust_map(ve, w.thr, ang, w.tx, w.ty, w.tn, sc, tl);
     } else {
-        thrust_map(ve, w.thr, ang, w.tx, w.ty, w.tn);
+        thrust_map(ve, w.thr, ang, w.tx, w.ty, w.tn, nullptr, tl);
     }
 }
 
@@ -808,14 +837,29 @@ struct StepRest {
 // ENV:104-133 up to and including the observation and the termination bits - everything the NEXT policy input depends on.
 // DEFER: leave the reward (and, for the continuous-angle variant, the two atan2 behind the azimuth bookkeeping) to env_step_finish,
 // so that a kernel can hand the observation over first.  cur = constant current (vcN, vcE in NED) present.
+// il: the env's (clamped) index, for the thrust-loss table; < 0 (a compile-time constant in every kernel but the general per-env ones, VES_ENV_RND /
+// the closed loop's RND and one-wave forms) = no table: the loss code is not even compiled in, those kernels are what they were without it.
 template <int MODE, bool EXT, bool DEFER>
 __device__ __forceinline__ void env_step_chain(const StepArgs& a, const Vessel& ve, Env& s, const float* act, bool has_ref,
-                                               float nrN, float nrE, float nrP, bool cur, float vcN, float vcE, StepOut& out, StepRest& rest)
+                                               float nrN, float nrE, float nrP, bool cur, float vcN, float vcE, StepOut& out, StepRest& rest,
+                                               int il = -1)
 {
 #pragma unroll
     for (int k = 0; k < 3; ++k) { rest.ang_prev[k] = s.ang[k]; rest.pt_old[k] = s.pt[k]; }   // ENV:102
     Wrench w;
-    env_decode<MODE, DEFER>(ve, s.ang, act, w);
+    if (il >= 0 && a.loss_on) {                          // launch-uniform (a kernel argument): some env of this handle has a thrust-loss coefficient
+        const float4 q0 = a.env_tab[(int64_t)ENV_GROUPS * a.env_stride + il], q1 = a.env_tab[(int64_t)(ENV_GROUPS + 1) * a.env_stride + il];
+        ThrustLoss tl;
+        tl.klf[0] = q0.x; tl.klf[1] = q0.y; tl.klf[2] = q0.z; tl.klr[0] = q0.w; tl.klr[1] = q1.x; tl.klr[2] = q1.y;
+        tl.u = s.u; tl.v = s.v; tl.r = s.r;
+        if (cur) {                                       // through the water: nu_r = nu - R(psi)^T v_c (env_plant forms the same difference)
+            tl.u -= fmaf(s.cs, vcN, s.sn * vcE);
+            tl.v -= fmaf(s.cs, vcE, -(s.sn * vcN));
+        }
+        env_decode<MODE, DEFER>(ve, s.ang, act, w, &tl);
+    } else {
+        env_decode<MODE, DEFER>(ve, s.ang, act, w);
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) { rest.thr[k] = w.thr[k]; rest.ang_new[k] = s.ang[k]; }      // ang_new[1..2] still the old ones if deferred
     float N = s.N, E = s.E, psi = s.psi, u = s.u, v = s.v, r = s.r;
@@ -854,10 +898,10 @@ __device__ __forceinline__ void env_step_finish(const StepArgs& a, Env& s, const
 // ENV:104-133 for one env: decode, command map, plant, observation, reward, termination, late new_ref.
 template <int MODE, bool EXT>
 __device__ __forceinline__ void env_step(const StepArgs& a, const Vessel& ve, Env& s, const float* act, bool has_ref,
-                                         float nrN, float nrE, float nrP, bool cur, float vcN, float vcE, StepOut& out)
+                                         float nrN, float nrE, float nrP, bool cur, float vcN, float vcE, StepOut& out, int il = -1)
 {
     StepRest rest;
-    env_step_chain<MODE, EXT, false>(a, ve, s, act, has_ref, nrN, nrE, nrP, cur, vcN, vcE, out, rest);
+    env_step_chain<MODE, EXT, false>(a, ve, s, act, has_ref, nrN, nrE, nrP, cur, vcN, vcE, out, rest, il);
     env_step_finish<MODE, EXT, false>(a, s, act, rest, true, out);
 }
 

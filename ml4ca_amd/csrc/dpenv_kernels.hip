@@ -110,14 +110,15 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(const 
         reset_wave<MODE>(a, lds_rst, lane, blockIdx.x);
         // domain randomisation: the hull of the episode that would start now, drawn beside the plant loop as well; the env wave says
         // which envs finished, and this wave - whose registers hold the block - puts it into the table, off the env wave's way
-        float4 hull[ENV_GROUPS];
+        float4 hull[DRAW_GROUPS];                       // the vessel block's groups and the thrust-loss table's two
         const int i = blockIdx.x * 64 + lane;
-        if (RND)
+        const bool rnd = RND && a.rand_tab != nullptr;  // (the general per-env kernel also serves fixed hulls with a thrust loss)
+        if (rnd)
             draw_env_groups(hull_key(a), a.env_id_base + i, __float_as_uint(lds_rst[17 * 64 + lane]), [&](int g, const float4& q) { hull[g] = q; });
         __syncthreads();
-        if (RND && lds_fin[lane] != 0u) {
+        if (rnd && lds_fin[lane] != 0u) {
 #pragma unroll
-            for (int g = 0; g < ENV_GROUPS; ++g) a.env_tab[(int64_t)g * a.env_stride + i] = hull[g];
+            for (int g = 0; g < DRAW_GROUPS; ++g) store_draw_group(a.env_tab, a.env_stride, i, g, hull[g]);
         }
         return;
     }
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(const 
                     : PER_CLASS ? vessel_from_lds(lds_cls, a.n_classes, cls) : vessel_from_args(a.v0);
 
     StepOut out;
-    env_step<MODE, EXT>(a, ve, s, act, a.new_ref != nullptr, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out);
+    env_step<MODE, EXT>(a, ve, s, act, a.new_ref != nullptr, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out, RND ? il : -1);
     if (a.current_drift) {
         current_drift_step(a, cur, vc0, beta0, a.env_id_base + i);
         if (live) { a.cur_vc[i] = cur.vc; a.cur_beta[i] = cur.beta; a.drift_ctr[i] = cur.ctr; }
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(const 
         if (RESETW) reset_from_lds<MODE>(lds_rst, tid, s, o_next);
         else {
             env_auto_reset<MODE>(a, s, a.env_id_base + i, ep, o_next);
-            if (RND) redraw_vessel_table(a, i, ep);            // domain randomisation: the new episode's hull (the reset wave does this in the two-wave form)
+            if (RND && a.rand_tab) redraw_vessel_table(a, i, ep);   // domain randomisation: the new episode's hull (the reset wave does this in the two-wave form)
         }
         rf_dirty = true;
     }
@@ -342,14 +343,14 @@ __global__ __launch_bounds__(RBLOCK) void rollout_kernel(const StepArgs a, const
             ++next_switch;
         }
         StepOut out;
-        env_step<MODE, EXT>(a, ve, s, act, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out);
+        env_step<MODE, EXT>(a, ve, s, act, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out, RND ? il : -1);
         if (a.current_drift) current_drift_step(a, cur, vc0, beta0, a.env_id_base + i);
         float o_next[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) o_next[k] = out.o[k];
         if (a.auto_reset && out.d != 0u && live) {
             env_auto_reset<MODE>(a, s, a.env_id_base + i, episode, o_next);
-            if (RND) redraw_vessel(a, i, episode, ve);            // domain randomisation: the new episode runs on a new hull
+            if (RND && a.rand_tab) redraw_vessel(a, i, episode, ve);   // domain randomisation: the new episode runs on a new hull
             ++episode; ep_dirty = true; rf_dirty = true;
         }
         lag[0] = o_next[6]; lag[1] = o_next[7]; lag[2] = o_next[8];
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(128) void rollout_ws_kernel(const StepArgs a, const
     __shared__ float post_mb[2][64 * 9];         // o_t+1 rows (pre-reset) by step parity, [lane * OD + k]: also the staged image of the row store
     __shared__ uint32_t done_mb[2][64];
     __shared__ float rec_mb[RW_REC * 64];        // the prepared re-draw, [field][lane]
-    __shared__ float hull_mb[RND ? ENV_BLOCK_FLOATS * 64 : 1]; // the prepared re-draw's hull (domain randomisation), [field][lane]; part of the record
+    __shared__ float hull_mb[RND ? 4 * DRAW_GROUPS * 64 : 1]; // the prepared re-draw's hull (domain randomisation), [field][lane]; part of the record
     __shared__ float ang_mb[2 * 64];             // stern azimuths in force after the last step (MODE_FINAL_CONT: the row wave keeps them)
     __shared__ int seq[8];                       // [0] actions posted, [1] steps posted, [2] re-draw record version, [3] final
     __shared__ float lds_cls[PER_CLASS ? VD_COUNT * MAX_CLASSES : 1];
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(128) void rollout_ws_kernel(const StepArgs a, const
         bool ep_dirty = false;
         int next_switch = 0, version = 0;
         float rec_o[9], rec_pt[3];
-        constexpr bool rnd = RND;               // domain randomisation: the record carries the hull of the episode that would start now
+        const bool rnd = RND && a.rand_tab != nullptr;   // domain randomisation: the record carries the hull of the episode that would start now
         // the re-draw an env would get if it finished NOW: (seed, global env id, episode) and the setpoint in force
         auto prepare = [&]() __attribute__((always_inline)) {
             Env s;
@@ -579,9 +580,10 @@ __global__ __launch_bounds__(128) void rollout_ws_kernel(const StepArgs a, const
                 if (do_reset) {
                     if (rnd) {                                               // the hull the env wave took from the record goes into the table
 #pragma unroll
-                        for (int g = 0; g < ENV_GROUPS; ++g)
-                            a.env_tab[(int64_t)g * a.env_stride + i] = make_float4(hull_mb[(4 * g + 0) * 64 + lane], hull_mb[(4 * g + 1) * 64 + lane],
-                                                                                   hull_mb[(4 * g + 2) * 64 + lane], hull_mb[(4 * g + 3) * 64 + lane]);
+                        for (int g = 0; g < ENV_GROUPS; ++g)              // (the two thrust-loss rows: the ENV wave writes them, it reads them back)
+                            store_draw_group(a.env_tab, a.env_stride, i, g,
+                                             make_float4(hull_mb[(4 * g + 0) * 64 + lane], hull_mb[(4 * g + 1) * 64 + lane],
+                                                         hull_mb[(4 * g + 2) * 64 + lane], hull_mb[(4 * g + 3) * 64 + lane]));
                     }
                     ++episode; ep_dirty = true;
                 }
@@ -633,7 +635,7 @@ __global__ __launch_bounds__(128) void rollout_ws_kernel(const StepArgs a, const
         }
         StepOut out;
         StepRest rest;
-        env_step_chain<MODE, EXT, true>(a, ve, s, act, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out, rest);
+        env_step_chain<MODE, EXT, true>(a, ve, s, act, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out, rest, RND ? il : -1);
         if (a.current_drift) current_drift_step(a, cur, vc0, beta0, a.env_id_base + i);
         const bool do_reset = resets && out.d != 0u && live;
         float* pm = post_mb[t & 1];
@@ -645,11 +647,18 @@ __global__ __launch_bounds__(128) void rollout_ws_kernel(const StepArgs a, const
             if (do_reset) {
                 float o_new[9];
                 reset_from_lds<MODE>(rec_mb, lane, s, o_new);
-                if (RND) {                                                   // the record's hull (the row wave keeps the table)
+                if (RND && a.rand_tab) {                                     // the record's hull (the row wave keeps the table)
                     VesselDev hd;
 #pragma unroll
                     for (int k = 0; k < VD_COUNT; ++k) hd.p[k] = hull_mb[k * 64 + lane];
                     ve = vessel_from_args(hd);
+                    // the thrust-loss coefficients of the new episode: this wave reads them from the table at its next force map, so it
+                    // is this wave that puts them there (a wave's own store is ahead of its own later load; the row wave runs a step behind)
+#pragma unroll
+                    for (int g = ENV_GROUPS; g < DRAW_GROUPS; ++g)
+                        store_draw_group(a.env_tab, a.env_stride, i, g,
+                                         make_float4(hull_mb[(4 * g + 0) * 64 + lane], hull_mb[(4 * g + 1) * 64 + lane],
+                                                     hull_mb[(4 * g + 2) * 64 + lane], hull_mb[(4 * g + 3) * 64 + lane]));
                 }
                 rf_dirty = true;
             }
@@ -757,7 +766,8 @@ __global__ __launch_bounds__(BLOCK) void set_state_kernel(const StepArgs a, cons
 }
 
 // ---- per-env parameter blocks: public parameter vectors <-> the packed float4 streams (dpenv_set / get_vessel_params) -------------
-__global__ __launch_bounds__(BLOCK) void pack_env_vessels_kernel(const float* raw, int64_t p_stride, int64_t i_stride, float4* tab, int stride, int n)
+__global__ __launch_bounds__(BLOCK) void pack_env_vessels_kernel(const float* raw, int64_t p_stride, int64_t i_stride, float4* tab, uint32_t* loss_flag,
+                                                                 int stride, int n)
 {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -766,6 +776,16 @@ __global__ __launch_bounds__(BLOCK) void pack_env_vessels_kernel(const float* ra
     for (int p = 0; p < RAND_NPARAM; ++p) r[p] = raw[p * p_stride + i * i_stride];
     derive_env_block(r, d);
     store_env_block(tab, stride, i, d);
+    // the six thrust-loss coefficients: two rows behind the vessel block; the device flag tells the host whether any env has one (the
+    // general per-env kernels then load and apply them: dpenv_env_dev.h).  A block that is not a vessel carries NaN coefficients too.
+    const bool bad = !(d[0] == d[0]);
+    const float nanv = __builtin_nanf("");
+    tab[(int64_t)ENV_GROUPS * stride + i] = bad ? make_float4(nanv, nanv, nanv, nanv) : make_float4(r[26], r[27], r[28], r[29]);
+    tab[(int64_t)(ENV_GROUPS + 1) * stride + i] = bad ? make_float4(nanv, nanv, 0.0f, 0.0f) : make_float4(r[30], r[31], 0.0f, 0.0f);
+    bool any = false;
+#pragma unroll
+    for (int p = 26; p < RAND_NPARAM; ++p) any = any || (r[p] != 0.0f);
+    if (loss_flag && __ballot(any) != 0ull && (threadIdx.x & 63) == __builtin_ctzll(__ballot(true))) atomicOr(loss_flag, 1u);
 }
 
 __global__ __launch_bounds__(BLOCK) void unpack_env_vessels_kernel(const float4* tab, int stride, float* out, int n)
@@ -785,8 +805,10 @@ __global__ __launch_bounds__(BLOCK) void unpack_env_vessels_kernel(const float4*
 #pragma unroll
     for (int k = 0; k < 3; ++k) { r[12 + k] = d[VD_KF + k]; r[15 + k] = d[VD_KR + k]; r[18 + k] = d[VD_LX + k]; r[21 + k] = d[VD_LY + k]; }
     r[24] = d[VD_NUV]; r[25] = d[VD_YUR];
-#pragma unroll
-    for (int p = RAND_NPARAM; p < 32; ++p) r[p] = 0.0f;
+    {
+        const float4 q0 = tab[(int64_t)ENV_GROUPS * stride + i], q1 = tab[(int64_t)(ENV_GROUPS + 1) * stride + i];
+        r[26] = q0.x; r[27] = q0.y; r[28] = q0.z; r[29] = q0.w; r[30] = q1.x; r[31] = q1.y;
+    }
 #pragma unroll
     for (int p = 0; p < 32; ++p) out[(int64_t)p * n + i] = r[p];
 }
@@ -1053,7 +1075,6 @@ extern "C" int dpenv_debug_set_step_trace(void* p)      // device buffer of STEP
 extern "C" hipError_t dpenv_dev_launch_step(const StepArgs* a, int mode, int ext, int ves, int reset_wave, hipStream_t s)
 {
     if (ves >= VES_ENV_VGPR && !a->env_tab) return hipErrorInvalidValue;
-    if (ves == VES_ENV_RND && !a->rand_tab) return hipErrorInvalidValue;
     switch (mode) {
     case MODE_FULL: return launch_step_mode<MODE_FULL>(*a, ext, ves, reset_wave != 0, s);
     case MODE_SIMPLE: return launch_step_mode<MODE_SIMPLE>(*a, ext, ves, reset_wave != 0, s);
@@ -1064,10 +1085,10 @@ extern "C" hipError_t dpenv_dev_launch_step(const StepArgs* a, int mode, int ext
     return hipErrorInvalidValue;
 }
 
-extern "C" hipError_t dpenv_dev_launch_pack_env_vessels(const float* raw, int64_t p_stride, int64_t i_stride, float4* tab, int stride, int n,
-                                                        hipStream_t s)
+extern "C" hipError_t dpenv_dev_launch_pack_env_vessels(const float* raw, int64_t p_stride, int64_t i_stride, float4* tab, uint32_t* loss_flag,
+                                                        int stride, int n, hipStream_t s)
 {
-    hipLaunchKernelGGL(pack_env_vessels_kernel, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, raw, p_stride, i_stride, tab, stride, n);
+    hipLaunchKernelGGL(pack_env_vessels_kernel, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, raw, p_stride, i_stride, tab, loss_flag, stride, n);
     return hipGetLastError();
 }
 
@@ -1108,7 +1129,6 @@ extern "C" hipError_t dpenv_dev_launch_rollout(const StepArgs* a, const RolloutA
                                                hipStream_t s)
 {
     if (ves >= VES_ENV_VGPR && !a->env_tab) return hipErrorInvalidValue;
-    if (ves == VES_ENV_RND && !a->rand_tab) return hipErrorInvalidValue;
     switch (mode) {
     case MODE_FULL: return launch_rollout_mode<MODE_FULL>(*a, *ra, ext, ves, two_wave != 0, s);
     case MODE_SIMPLE: return launch_rollout_mode<MODE_SIMPLE>(*a, *ra, ext, ves, two_wave != 0, s);

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
             ++next_switch;
         }
         StepOut out;
-        env_step<MODE, EXT>(a, ve, s, act, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out);
+        env_step<MODE, EXT>(a, ve, s, act, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out, il);
         if (a.current_drift) current_drift_step(a, cur, vc0, beta0, a.env_id_base + i);
 
 #pragma unroll

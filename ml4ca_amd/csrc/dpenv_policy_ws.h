@@ -469,7 +469,7 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
 #endif
         constexpr bool DEFER = DPENV_WS_DEFER_REWARD != 0;
         StepRest rest;
-        env_step_chain<MODE, EXT, DEFER>(a, ve, s, act, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out, rest);
+        env_step_chain<MODE, EXT, DEFER>(a, ve, s, act, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out, rest, RND ? il : -1);
         if constexpr (!DEFER) env_step_finish<MODE, EXT, false>(a, s, act, rest, true, out);
         WS_TOC(t_env, te_);
         WS_TIC(tq_);
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
         {
             ws_wait(&seq[2], t + 1);                                         // critic(o_t) done: the partner is idle from here
                 StepOut outB;
-            env_step<MODE, EXT>(a, ve, sB, actB, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, outB);
+            env_step<MODE, EXT>(a, ve, sB, actB, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, outB, RND ? il : -1);
             const float fa[20] = {s.N, s.E, s.psi, s.u, s.v, s.r, s.sn, s.cs, out.reward, out.o[0], out.o[1], out.o[2], out.o[3],
                                   out.o[4], out.o[5], out.o[6], out.o[7], out.o[8], __uint_as_float(out.d), s.ang[1]};
             const float fb[20] = {sB.N, sB.E, sB.psi, sB.u, sB.v, sB.r, sB.sn, sB.cs, outB.reward, outB.o[0], outB.o[1], outB.o[2],
@@ -521,8 +521,9 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
             if (do_reset) {
                 if constexpr (PREDRAW) { reset_apply<MODE>(a, s, rdraw, o); need_draw = true; }
                 else env_auto_reset<MODE>(a, s, a.env_id_base + i, episode, o);
-                if constexpr (VE_RELOAD) redraw_vessel_table_call(a.rand_tab, a.seed_lo, a.seed_hi, a.env_tab, a.env_stride, a.env_id_base + i, i, episode);
-                else if constexpr (RND) redraw_vessel_cold(a, i, episode, ve);   // domain randomisation: the new episode runs on a new hull
+                // domain randomisation: the new episode runs on a new hull (the RND instantiation also serves fixed hulls with a thrust loss)
+                if constexpr (VE_RELOAD) { if (a.rand_tab) redraw_vessel_table_call(a.rand_tab, a.seed_lo, a.seed_hi, a.env_tab, a.env_stride, a.env_id_base + i, i, episode); }
+                else if constexpr (RND) { if (a.rand_tab) redraw_vessel_cold(a, i, episode, ve); }
                 ++episode; ep_dirty = true; rf_dirty = true;
             }
         }
@@ -627,7 +628,7 @@ static hipError_t go(const StepArgs& a, const PolicyArgs& pa, hipStream_t s)
 template <int MODE, bool EXT, int KA, int PREC, int GROUPS>
 static hipError_t pick(const StepArgs& a, const PolicyArgs& pa, hipStream_t s)
 {
-    if (a.rand_tab) {
+    if (a.rand_tab || a.loss_on) {
         if constexpr (MODE == MODE_FINAL_CONT && EXT && KA < 16) return go<MODE, EXT, KA, PREC, GROUPS, true>(a, pa, s);
         else return hipErrorNotSupported;
     }

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_x_kernel(const StepArgs
             ++next_switch;
         }
         StepOut out;
-        env_step<MODE, EXT>(a, ve, s, act, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out);
+        env_step<MODE, EXT>(a, ve, s, act, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out, il);
         if (a.current_drift) current_drift_step(a, cur, vc0, beta0, a.env_id_base + i);
 #pragma unroll
         for (int k = 0; k < 9; ++k) o[k] = out.o[k];

@@ -395,10 +395,14 @@ class BatchedRevoltEnv(object):
 
     def set_vessel_params(self, params):
         """Per-env hull / thruster parameters (dpenv_set_vessel_params): float32 [NPARAM, n] device tensor, row p = parameter
-        _lib.P[...] of every env (rows 26..31 ignored) - the constants the reference hard-codes for its one vessel
-        (qp_allocator.py:51-55,69-70; SupervisedTau.py:35-36,69-71) and the build-owned plant's mass / damping terms.  None returns to
-        the vessel classes / the single class given to the constructor."""
+        _lib.P[...] of every env - the constants the reference hard-codes for its one vessel (qp_allocator.py:51-55,69-70;
+        SupervisedTau.py:35-36,69-71), the build-owned plant's mass / damping terms and (rows 26..31) the thrusters' inflow-loss
+        coefficients.  A single length-NPARAM vector is given to every env.  None returns to the vessel classes / the single class given
+        to the constructor.  Synchronises the stream (the library reads back whether any env has a thrust loss: dpenv.h)."""
         torch = _torch()
+        if params is not None and not (hasattr(params, 'dim') and params.dim() == 2):
+            one = torch.as_tensor(np.asarray(params.cpu() if hasattr(params, 'cpu') else params, np.float32).reshape(_lib.NPARAM), device=self.device)
+            params = one[:, None].expand(_lib.NPARAM, self.n_envs).contiguous()
         self._chk(params, (_lib.NPARAM, self.n_envs), torch.float32, 'params')
         _lib.check(self.lib.dpenv_set_vessel_params(self._h, self._ptr(params), self._stream()), self._h)
 
@@ -412,7 +416,7 @@ class BatchedRevoltEnv(object):
     def set_vessel_randomisation(self, rel_range, nominal=None):
         """Domain randomisation through the reset path (dpenv_set_vessel_randomisation): every reset starts its episode on a hull with
         parameter p = nominal[p] * (1 + rel_range[p] * u), u ~ U[-1, 1), keyed (seed; global env id, episode).  rel_range: a float (the
-        same relative half-range for all 26 parameters), a length-NPARAM sequence, or None to stop re-drawing; nominal: a parameter
+        same relative half-range for every parameter), a length-NPARAM sequence, or None to stop re-drawing; nominal: a parameter
         vector, default class 0."""
         if rel_range is None:
             _lib.check(self.lib.dpenv_set_vessel_randomisation(self._h, None, None, self._stream()), self._h)

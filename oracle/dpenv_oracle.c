@@ -43,6 +43,12 @@ void dpo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+/* the thrust-loss preset's numbers (tests/calibration/fit_thrust_loss_preset.py; the library holds the same: dpenv_default_vessel_ex) */
+#define THRUST_LOSS_KR_STERN 0.001149
+#define THRUST_LOSS_KLF_STERN 0.08173
+#define THRUST_LOSS_KLR_STERN 0.05039
+#define THRUST_LOSS_KL_BOW 0.0
+
 #define REAL double
 #define SFX f64
 #define M_FMOD fmod

@@ -63,6 +63,8 @@ enum {
     DPO_P_LX_BOW, DPO_P_LX_PORT, DPO_P_LX_STAR,
     DPO_P_LY_BOW, DPO_P_LY_PORT, DPO_P_LY_STAR,
     DPO_P_NUV, DPO_P_YUR,                          /* lift-type cross-flow terms N_uv u v, Y_ur u r */
+    DPO_P_KLF_BOW, DPO_P_KLF_PORT, DPO_P_KLF_STAR, /* inflow thrust loss, n >= 0: F = K n|n| - Kl |n| u_a (build-owned) */
+    DPO_P_KLR_BOW, DPO_P_KLR_PORT, DPO_P_KLR_STAR, /* n < 0 */
     DPO_NPARAM = 32
 };
 
@@ -91,6 +93,7 @@ typedef struct dpo_config {
     int  dpo_act_dim_##suffix(const dpo_config* c);                                                    \
     int  dpo_obs_dim_##suffix(const dpo_config* c);                                                    \
     void dpo_default_vessel_##suffix(REAL* p);                                                         \
+    void dpo_thrust_loss_vessel_##suffix(REAL* p);                                                     \
     void dpo_decode_##suffix(const dpo_config* c, const REAL* action, const REAL ang_in[3],            \
                              REAL thrust_out[3], REAL ang_out[3]);                                     \
     void dpo_thrust_map_##suffix(const REAL* vessel, const REAL n_pct[3], const REAL alpha[3],         \

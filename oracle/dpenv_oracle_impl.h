@@ -76,6 +76,17 @@ void FN(dpo_default_vessel)(REAL* p)
     p[DPO_P_LY_BOW] = R(0.0);  p[DPO_P_LY_PORT] = R(-0.15); p[DPO_P_LY_STAR] = R(0.15);
 }
 
+/* BUILD-OWNED second preset (the steady speeds "with thrust losses", ENV:17; tests/calibration/fit_thrust_loss_preset.py): the same hull,
+ * reverse gain of the stern thrusters from the no-loss astern speed (ENV:14: -1.60 m/s), inflow-loss coefficients from +1.4 / -1.1 m/s */
+void FN(dpo_thrust_loss_vessel)(REAL* p)
+{
+    FN(dpo_default_vessel)(p);
+    p[DPO_P_KR_PORT] = p[DPO_P_KR_STAR] = R(THRUST_LOSS_KR_STERN);
+    p[DPO_P_KLF_PORT] = p[DPO_P_KLF_STAR] = R(THRUST_LOSS_KLF_STERN);
+    p[DPO_P_KLR_PORT] = p[DPO_P_KLR_STAR] = R(THRUST_LOSS_KLR_STERN);
+    p[DPO_P_KLF_BOW] = p[DPO_P_KLR_BOW] = R(THRUST_LOSS_KL_BOW);
+}
+
 /* per-variant action bounds ENV:63,339,362,390 */
 static void FN(action_bounds)(const dpo_config* c, REAL bnd[6], int* n)
 {
@@ -168,7 +179,6 @@ void FN(dpo_plant)(const dpo_config* c, const REAL* p, REAL eta[3], REAL nu[3], 
     const REAL det = m22 * m33 - m23 * m23;
     const REAL i22 = m33 / det, i23 = -m23 / det, i33 = m22 / det;
     REAL tau[3];
-    FN(dpo_thrust_map)(p, n_pct, alpha, tau);
 
     REAL N = eta[0], E = eta[1], psi = eta[2];
     REAL u = nu[0], v = nu[1], r = nu[2];
@@ -180,6 +190,28 @@ void FN(dpo_plant)(const dpo_config* c, const REAL* p, REAL eta[3], REAL nu[3], 
         /* relative velocity nu_r = nu - R(psi)^T v_c */
         u -= cs * vcN + sn * vcE;
         v -= -sn * vcN + cs * vcE;
+    }
+    /* tau = B(alpha) F with the BUILD-OWNED inflow thrust loss: F_i = K_i n_i|n_i| - Kl_i |n_i| u_a,i, u_a,i the velocity through the water
+     * of thruster i's position along its axis at the start of the env step (the linear open-water characteristic, Fossen 2011 eq. 9.7),
+     * never past zero thrust; Kl = 0 (default hull) is the reference's law (STAU:42-83) exactly */
+    {
+        REAL tx = R(0), ty = R(0), tn = R(0);
+        for (int i = 0; i < 3; ++i) {
+            const int ahead = n_pct[i] >= R(0);
+            REAL K = ahead ? p[DPO_P_KF_BOW + i] : p[DPO_P_KR_BOW + i];
+            REAL Kl = ahead ? p[DPO_P_KLF_BOW + i] : p[DPO_P_KLR_BOW + i];
+            REAL F = K * M_FABS(n_pct[i]) * n_pct[i];
+            REAL ca = M_COS(alpha[i]), sa = M_SIN(alpha[i]);
+            if (Kl != R(0)) {
+                REAL ua = (u - p[DPO_P_LY_BOW + i] * r) * ca + (v + p[DPO_P_LX_BOW + i] * r) * sa;
+                F -= Kl * M_FABS(n_pct[i]) * ua;
+                if (ahead ? (F < R(0)) : (F > R(0))) F = R(0);
+            }
+            tx += ca * F;
+            ty += sa * F;
+            tn += (p[DPO_P_LX_BOW + i] * sa - p[DPO_P_LY_BOW + i] * ca) * F;
+        }
+        tau[0] = tx; tau[1] = ty; tau[2] = tn;
     }
     for (int k = 0; k < c->n_substeps; ++k) {
         REAL c13 = -(m22 * v + m23 * r);
@@ -377,11 +409,12 @@ void FN(dpo_policy_noise)(const dpo_config* c, int64_t gid, uint32_t draw, int32
  * `gid`.  rand_tab = { nominal[32] | relative half-range[32] } in the public parameter order; parameter p = nominal[p] * (1 + range[p] * u),
  * u uniform in [-1, 1) with 16 bits, taken from four Philox4x32-10 blocks keyed by the seed with counter (global env id, episode,
  * tag 0x48000000 | block).  The 16 bits of a parameter are half (q & 1) of word (q & 7) >> 1 of block q >> 3 for its slot q: the
- * parameters numbered in the order the kernels pack a per-env block (m11 m22 m23 m33 Xu | Xuu Yv Yvv Yr Nv Nr Nrr Nuv | Yur Kf Kr lx_bow |
- * lx_port lx_star ly), so that one Philox block fills two float4 groups there.  The parameters it randomises are the constants the
+ * parameters numbered in the order the kernels pack a per-env block (m11 m22 m23 m33 Xu Klr[3] | Xuu Yv Yvv Yr Nv Nr Nrr Nuv | Yur Kf Kr lx_bow |
+ * lx_port lx_star ly Klf[3]), so that one Philox block fills two float4 groups there.  The parameters it randomises are the constants the
  * reference hard-codes once for its one vessel (QPROS:51-55,69-70, STAU:35-36,69-71) and the build-owned hull terms.
  */
-static const int FN(RAND_SLOT)[26] = {0, 1, 2, 3, 4, 8, 9, 10, 11, 12, 13, 14, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 15, 16};
+static const int FN(RAND_SLOT)[32] = {0, 1, 2, 3, 4, 8, 9, 10, 11, 12, 13, 14, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 15, 16,
+                                      29, 30, 31, 5, 6, 7};      /* ... Klf[3] (slots 29-31), Klr[3] (5-7) */
 
 void FN(dpo_draw_vessel)(const dpo_config* c, const REAL* rand_tab, int64_t gid, uint32_t episode, REAL* p)
 {
@@ -392,7 +425,7 @@ void FN(dpo_draw_vessel)(const dpo_config* c, const REAL* rand_tab, int64_t gid,
         dpo_philox4x32_10(ctr, key, w[b]);
     }
     for (int k = 0; k < DPO_NPARAM; ++k) p[k] = R(0);
-    for (int k = 0; k < 26; ++k) {
+    for (int k = 0; k < 32; ++k) {
         const int q = FN(RAND_SLOT)[k];
         const uint32_t h16 = (w[q >> 3][(q & 7) >> 1] >> (16 * (q & 1))) & 0xffffu;
         const REAL u = R(h16) * R(1.0 / 32768.0) - R(1);

@@ -4,16 +4,18 @@
 The reference records TWO sets of steady full-thrust speeds of its plant (customEnv.py:13-18): without thrust losses surge +2.20 / -1.60 m/s,
 sway +-0.35 m/s, yaw +-0.60 rad/s - the default hull is fitted to those (calibrate_plant.py) - and WITH thrust losses +1.4 / -1.1 m/s,
 +-0.30 m/s, +-0.52 rad/s, which are also the velocity bounds it trains with (customEnv.py:26: "these are its REAL limits").  This script
-derives a second parameter vector for the second set.  What it may touch: the thrust gains K (forward and reverse slots, DPENV_P_KF_* /
-DPENV_P_KR_*: a thrust LOSS is a property of the thrusters) - the hull (mass, damping) stays the calibrated one, so the free-drift record,
-which involves no thrust, is reproduced exactly as before.  Manoeuvres (float64 oracle plant, steady state after 120 s):
+derives the second parameter vector.  What it may touch: the THRUSTERS - a thrust loss is theirs - i.e. the reverse gain of the stern
+thrusters (DPENV_P_KR_*: from the no-loss astern speed, -1.60 m/s, which the default hull with its symmetric gains does not meet) and the
+inflow-loss coefficients (DPENV_P_KLF_* / DPENV_P_KLR_*: F = K n|n| - Kl |n| u_a, the linear open-water characteristic, Fossen 2011 eq. 9.7).
+The hull (mass, damping) stays the calibrated one, so the free-drift record, which involves no thrust, is reproduced exactly as before.
+Manoeuvres (float64 oracle plant, steady state after 120 s):
     surge ahead / astern   stern thrusters +-100 % at azimuth 0, bow off
     sway                   bow +100 % at its fixed 90 deg, stern azimuths at 90 deg with the thrust that keeps the heading (r = 0)
     yaw                    bow +100 % at 90 deg, stern +100 % at -90 deg ("rotating stern azimuths only", customEnv.py:13)
-Three gains (stern forward, stern reverse, bow) are determined by surge ahead, surge astern and sway.  The yaw pin is then an OUTCOME: one
-constant gain per thruster and direction cannot also meet it - at 1.4 m/s ahead the stern thrusters must deliver 44 % of their bollard
-thrust, in the yaw manoeuvre (no inflow) the record wants 87 % - i.e. Cybersea's loss depends on the inflow speed, which nothing in the
-reference tree describes.
+Three numbers are determined by three pins: stern reverse gain by -1.60 m/s (no loss), stern Kl forward by +1.4 m/s, stern Kl reverse by
+-1.1 m/s.  Sway and yaw are then OUTCOMES: an inflow-type loss that explains the surge speeds leaves the stern thrusters ~77 % of their bollard
+thrust in the yaw manoeuvre - a constant gain reduced to fit +1.4 m/s would leave 44 % (yaw 0.35 rad/s; round 5's first form of this preset).
+The bow thruster keeps its gain and gets no loss coefficient: the recorded sway needs all of its thrust.
 
     python tests/calibration/fit_thrust_loss_preset.py        prints the vector and the table of DESIGN.md section 3
 """
@@ -26,7 +28,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from oracle import oracle as O          # noqa: E402
 
-P = dict(KF_BOW=12, KF_PORT=13, KF_STAR=14, KR_BOW=15, KR_PORT=16, KR_STAR=17)
+P = dict(KF_BOW=12, KF_PORT=13, KF_STAR=14, KR_BOW=15, KR_PORT=16, KR_STAR=17, KLF_BOW=26, KLF_PORT=27, KLF_STAR=28, KLR_BOW=29, KLR_PORT=30, KLR_STAR=31)
 PINS_NO_LOSS = dict(surge_ahead=2.20, surge_astern=-1.60, sway=0.35, yaw=0.60)          # customEnv.py:14
 PINS_LOSS = dict(surge_ahead=1.4, surge_astern=-1.1, sway=0.30, yaw=0.52)               # customEnv.py:17
 
@@ -65,48 +67,55 @@ def manoeuvres(vessel):
                 yaw=steady(vessel, [100, 100, 100], [np.pi / 2, -np.pi / 2, -np.pi / 2])[2])
 
 
+def no_loss_of(vessel):
+    """the same thrusters with the loss switched off (what the reference measured 'with no thrust losses activated')"""
+    w = np.array(vessel, np.float64)
+    w[26:32] = 0.0
+    return w
+
+
 def fit(base):
     v = np.array(base, np.float64)
 
-    def with_gains(kf_s=None, kr_s=None, k_b=None):
+    def with_(**kw):
         w = v.copy()
-        if kf_s is not None:
-            w[P['KF_PORT']] = w[P['KF_STAR']] = kf_s
-        if kr_s is not None:
-            w[P['KR_PORT']] = w[P['KR_STAR']] = kr_s
-        if k_b is not None:
-            w[P['KF_BOW']] = w[P['KR_BOW']] = k_b
+        for k, x in kw.items():
+            for name in (k + '_PORT', k + '_STAR'):
+                w[P[name]] = x
         return w
 
-    kf_s = bisect(lambda k: steady(with_gains(kf_s=k), [0, 100, 100], [np.pi / 2, 0, 0])[0] - PINS_LOSS['surge_ahead'], 1e-5, v[P['KF_PORT']])
-    v = with_gains(kf_s=kf_s)
-    kr_s = bisect(lambda k: -steady(with_gains(kr_s=k), [0, -100, -100], [np.pi / 2, 0, 0])[0] + PINS_LOSS['surge_astern'], 1e-5, v[P['KR_PORT']])
-    v = with_gains(kr_s=kr_s)
-    k_b = bisect(lambda k: sway_speed(with_gains(k_b=k))[0] - PINS_LOSS['sway'], 1e-5, v[P['KF_BOW']], it=30)
-    return with_gains(k_b=k_b)
+    # stern reverse gain: -1.60 m/s astern without losses (customEnv.py:14)
+    kr = bisect(lambda k: -steady(with_(KR=k), [0, -100, -100], [np.pi / 2, 0, 0])[0] + PINS_NO_LOSS['surge_astern'], 1e-5, v[P['KF_PORT']])
+    v = with_(KR=kr)
+    # inflow-loss coefficients of the stern thrusters: +1.4 ahead, -1.1 astern with losses (customEnv.py:17)
+    klf = bisect(lambda k: PINS_LOSS['surge_ahead'] - steady(with_(KLF=k), [0, 100, 100], [np.pi / 2, 0, 0])[0], 0.0, 0.5)
+    v = with_(KLF=klf)
+    klr = bisect(lambda k: steady(with_(KLR=k), [0, -100, -100], [np.pi / 2, 0, 0])[0] - PINS_LOSS['surge_astern'], 0.0, 0.5)
+    return with_(KLR=klr)
 
 
 if __name__ == '__main__':
     base = O.Oracle(O.make_config(), np.float64).vessel.copy()
     loss = fit(base)
-    # four significant digits are what goes into dpenv_default_vessel_ex / dpo (the speeds below are those of the ROUNDED vector)
-    for k in P.values():
+    # four significant digits are what goes into dpenv_default_vessel_ex / the oracle (the speeds below are those of the ROUNDED vector)
+    for k in (P['KR_PORT'], P['KR_STAR'], P['KLF_PORT'], P['KLF_STAR'], P['KLR_PORT'], P['KLR_STAR']):
         loss[k] = float('%.4g' % loss[k])
-    print('thrust-loss preset: K forward (bow, port, star) = %s   K reverse = %s   [N per percent squared]' % (
-        ', '.join('%.4g' % loss[k] for k in (12, 13, 14)), ', '.join('%.4g' % loss[k] for k in (15, 16, 17))))
-    print('share of the bollard thrust of the no-loss preset: stern ahead %.2f, stern astern %.2f, bow %.2f' % (
-        loss[13] / base[13], loss[16] / base[16], loss[12] / base[12]))
-    print('%-14s %10s %10s   %10s %10s' % ('manoeuvre', 'no-loss', 'recorded', 'loss', 'recorded'))
-    m0, m1 = manoeuvres(base), manoeuvres(loss)
+    print('thrust-loss preset: stern K forward %.4g, K reverse %.4g [N per percent^2]; Kl forward %.4g, Kl reverse %.4g [N per percent per m/s]; bow unchanged' % (
+        loss[13], loss[16], loss[27], loss[30]))
+    print('%-14s %10s %10s   %12s %10s   %12s %10s' % ('manoeuvre', 'default', 'recorded', 'loss preset,', 'recorded', 'loss preset', 'recorded'))
+    print('%-14s %10s %10s   %12s %10s   %12s %10s' % ('', '(no loss)', 'no loss', 'loss OFF', 'no loss', '', 'with loss'))
+    m0, m1, m2 = manoeuvres(base), manoeuvres(no_loss_of(loss)), manoeuvres(loss)
     for key in ('surge_ahead', 'surge_astern', 'sway', 'sway_to_port', 'yaw'):
         pin = 'sway' if key == 'sway_to_port' else key
         sgn = -1.0 if key == 'sway_to_port' else 1.0
-        print('%-14s %10.3f %10.2f   %10.3f %10.2f' % (key, m0[key], sgn * PINS_NO_LOSS[pin], m1[key], sgn * PINS_LOSS[pin]))
+        print('%-14s %10.3f %10.2f   %12.3f %10.2f   %12.3f %10.2f' % (key, m0[key], sgn * PINS_NO_LOSS[pin], m1[key], sgn * PINS_NO_LOSS[pin], m2[key], sgn * PINS_LOSS[pin]))
+    stern = steady(loss, [100, 100, 100], [np.pi / 2, -np.pi / 2, -np.pi / 2])
+    print('stern thrust in the yaw manoeuvre: %.0f %% of the bollard thrust (inflow %.2f m/s)' % (100 * (1 - loss[27] * 100 * 1.12 * stern[2] / (loss[13] * 1e4)), 1.12 * stern[2]))
     try:
         from tests.calibration import replay_cybersea as RC
         W = RC.load_windows()
-        for name, vec in (('no-loss (default)', base), ('thrust-loss', loss)):
+        for name, vec in (('default (no loss)', base), ('loss preset, loss off', no_loss_of(loss)), ('loss preset', loss)):
             e = RC.errors(RC.replay_oracle(W, vessel=vec), W)
-            print('open-loop replay of the recorded Cybersea commands, %-18s %s' % (name + ':', '  '.join('%4.1f s: %.2f m %5.1f deg' % (h * 0.2, e[h][0], e[h][1]) for h in RC.HORIZONS)))
+            print('open-loop replay of the recorded Cybersea commands, %-22s %s' % (name + ':', '  '.join('%4.1f s: %.2f m %5.1f deg' % (h * 0.2, e[h][0], e[h][1]) for h in RC.HORIZONS)))
     except Exception as ex:      # pragma: no cover
         print('replay skipped:', ex)

@@ -67,14 +67,18 @@ def to_dev(x, device='cuda:0'):
     return torch.from_numpy(np.ascontiguousarray(x)).to(device)
 
 
-def random_hulls(rng, n, rel=0.15, base=None):
+def random_hulls(rng, n, rel=0.15, base=None, loss=0.0):
     """[NPARAM, n] float32: every env its own parameter vector, each of the 26 parameters of the default hull scaled by an
     independent factor in [1 - rel, 1 + rel] (the constants the reference fixes once for its one vessel: qp_allocator.py:51-55,69-70,
-    SupervisedTau.py:35-36,69-71, and the build-owned mass / damping terms)."""
+    SupervisedTau.py:35-36,69-71, and the build-owned mass / damping terms).  loss > 0: the six inflow thrust-loss coefficients
+    (rows 26..31) uniform in [0, loss) as well - every fourth env keeps none."""
     import ml4ca_amd
     base = np.asarray(ml4ca_amd.default_vessel() if base is None else base, np.float32)
     tab = np.zeros((O.NPARAM, n), np.float32)
     tab[:26] = base[:26, None] * (1.0 + rel * rng.uniform(-1, 1, size=(26, n))).astype(np.float32)
+    if loss > 0:
+        tab[26:32] = (loss * rng.uniform(0, 1, size=(6, n))).astype(np.float32)
+        tab[26:32, ::4] = 0.0
     return tab
 
 
@@ -83,5 +87,5 @@ def rand_table(rel, nominal=None):
     import ml4ca_amd
     rt = np.zeros(2 * O.NPARAM, np.float32)
     rt[:O.NPARAM] = np.asarray(ml4ca_amd.default_vessel() if nominal is None else nominal, np.float32)
-    rt[O.NPARAM:O.NPARAM + 26] = np.float32(rel)
+    rt[O.NPARAM:2 * O.NPARAM] = np.float32(rel)
     return rt

@@ -398,3 +398,59 @@ def test_per_env_vessels_and_the_randomisation_draw_in_the_oracle():
     assert list(c64[1]) == [1] * 8 and np.array_equal(tab[:, 3], o64.draw_vessel(rt, 3, 0))
     o64.reset(st64, c64, mask=np.array([0, 1, 0, 0, 0, 0, 0, 0], np.uint8), vessel_env=tab, rand_tab=rt)
     assert list(c64[1]) == [1, 2, 1, 1, 1, 1, 1, 1] and np.array_equal(tab[:, 1], o64.draw_vessel(rt, 1, 1)) and np.array_equal(tab[:, 3], o64.draw_vessel(rt, 3, 0))
+
+
+def test_inflow_thrust_loss_in_the_oracle():
+    """Round 5, BUILD-OWNED (the reference's plant is closed; it only records steady speeds with and without 'thrust losses', customEnv.py:13-18):
+    F = K n|n| - Kl |n| u_a with u_a the speed through the water of the thruster's position along its axis at the start of the env step, never
+    past zero thrust.  The oracle's plant against a numpy restatement of that sentence (the body dynamics taken from the oracle itself through
+    the wrench it is equivalent to), the coefficients' draw, and Kl = 0 as the exact reference law."""
+    from tests import helpers as H
+    cfg = O.make_config(terminate=0, current_enabled=1)
+    o = O.Oracle(cfg, np.float64)
+    p = o.vessel.copy()
+    P = dict(KF=12, KR=15, LX=18, LY=21, KLF=26, KLR=29)
+    rng = np.random.RandomState(4)
+    for trial in range(200):
+        q = p.copy()
+        q[26:32] = rng.uniform(0, 0.12, 6) * (rng.uniform(size=6) < 0.8)
+        eta = np.array([rng.uniform(-3, 3), rng.uniform(-3, 3), rng.uniform(-3, 3)])
+        nu = np.array([rng.uniform(-1.4, 1.4), rng.uniform(-0.3, 0.3), rng.uniform(-0.5, 0.5)])
+        n_pct = rng.uniform(-100, 100, 3) * (rng.uniform(size=3) < 0.9)
+        al = rng.uniform(-np.pi, np.pi, 3)
+        cur = np.array([rng.uniform(0, 0.3), rng.uniform(-3, 3)]) if trial % 2 else np.zeros(2)
+        # the wrench the sentence above gives ...
+        vcN, vcE = cur[0] * np.cos(cur[1]), cur[0] * np.sin(cur[1])
+        cs, sn = np.cos(eta[2]), np.sin(eta[2])
+        ur, vr = nu[0] - (cs * vcN + sn * vcE), nu[1] - (-sn * vcN + cs * vcE)
+        F = np.zeros(3)
+        for i in range(3):
+            ahead = n_pct[i] >= 0
+            K, Kl = (q[P['KF'] + i], q[P['KLF'] + i]) if ahead else (q[P['KR'] + i], q[P['KLR'] + i])
+            ua = (ur - q[P['LY'] + i] * nu[2]) * np.cos(al[i]) + (vr + q[P['LX'] + i] * nu[2]) * np.sin(al[i])
+            f = K * abs(n_pct[i]) * n_pct[i] - Kl * abs(n_pct[i]) * ua
+            F[i] = max(f, 0.0) if ahead else min(f, 0.0)
+        # ... is the wrench of LOSS-FREE thrusters commanded n' with K n'|n'| = F at the same azimuths: the oracle's own plant, Kl = 0
+        q0 = q.copy()
+        q0[26:32] = 0.0
+        n_eq = np.array([np.sign(F[i]) * np.sqrt(abs(F[i]) / (q[P['KF'] + i] if F[i] >= 0 else q[P['KR'] + i])) for i in range(3)])
+        a = O.Oracle(cfg, np.float64, vessel=q).plant(eta, nu, n_pct, al, current=cur)
+        b = O.Oracle(cfg, np.float64, vessel=q0).plant(eta, nu, n_eq, al, current=cur)
+        assert np.allclose(a[0], b[0], rtol=0, atol=1e-12) and np.allclose(a[1], b[1], rtol=0, atol=1e-12), trial
+        if np.any(q[26:32] != 0) and np.any(n_pct != 0) and not np.allclose(n_eq, n_pct, atol=1e-3):
+            c = O.Oracle(cfg, np.float64, vessel=q0).plant(eta, nu, n_pct, al, current=cur)
+            assert not np.allclose(a[1], c[1], atol=1e-9)
+    # the draw covers the six coefficients with words of their own
+    rt = np.zeros(64)
+    rt[:32] = p
+    rt[26:32] = [0.02, 0.08, 0.08, 0.01, 0.05, 0.05]
+    rt[32:64] = 0.2
+    draws = np.stack([o.draw_vessel(rt, gid, ep) for gid in (0, 7) for ep in range(600)])
+    ratio = draws[:, 26:32] / rt[26:32]
+    assert ratio.min() >= 0.8 and ratio.max() < 1.2 and abs(ratio.mean() - 1) < 4e-3 and abs(ratio.std() - 0.2 / np.sqrt(3)) < 4e-3
+    both = np.concatenate([draws[:, :26][:, rt[:26] != 0] / rt[:26][rt[:26] != 0], ratio], axis=1)
+    assert np.abs(np.corrcoef(both.T) - np.eye(both.shape[1])).max() < 0.15
+    # and the hull part of a draw does not depend on whether the coefficients are randomised (the round-5 tables of hulls stay what they were)
+    rt0 = rt.copy()
+    rt0[26:32] = 0.0
+    assert np.array_equal(o.draw_vessel(rt0, 3, 4)[:26], o.draw_vessel(rt, 3, 4)[:26]) and np.all(o.draw_vessel(rt0, 3, 4)[26:] == 0)

@@ -3,7 +3,8 @@
 box test of the RL allocator (results/all_plots/box_test/bagfile__RL_*.csv).  The trained actor (fixture
 final_policy.npz) is driven with the RECORDED filtered setpoint series (reference_filter/state_desired, the signal the
 ROS node fed the policy, rl_allocator.py:160) and the resulting pose is compared with the recorded pose.
-Input: tests/golden/cybersea_box_rl.npz (tools/gen_golden.py cybersea).  Prints per-axis RMS and max deviations."""
+Input: tests/golden/cybersea_box_rl.npz (tools/gen_golden.py cybersea).  Prints per-axis RMS and max deviations.
+Usage: python tools/compare_cybersea_box.py [no_loss|thrust_loss]   (plant preset, dpenv_default_vessel_ex; default no_loss)"""
 import os
 import sys
 
@@ -22,7 +23,10 @@ refs = np.ascontiguousarray(rec['setpoint'].T.astype(np.float32))        # [3, T
 cy_full = rec['pose']
 
 d = np.load(os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden', 'final_policy.npz'))
-env = ml4ca_amd.BatchedRevoltEnv(1, terminate=False, time_limit=False, wrap_mode='radians')   # the ROS node wraps in radians
+preset = sys.argv[1] if len(sys.argv) > 1 else 'no_loss'
+print('plant preset:', preset)
+env = ml4ca_amd.BatchedRevoltEnv(1, terminate=False, time_limit=False, wrap_mode='radians',   # the ROS node wraps in radians
+                                 vessel_params=ml4ca_amd.default_vessel(preset))
 ac = ActorCritic.from_tensors({k.replace('.', '/'): d[k] for k in d.files if '.' in k}, device='cuda:0').upload(env)
 obs = env.reset(init=torch.zeros((6, 1), device=env.device), new_ref=torch.tensor(refs[:, :1], device=env.device).contiguous())
 traj = np.zeros((T, 3))

@@ -29,6 +29,10 @@
 // A/B, by LDS-DMA into a [group][lane] image).  No MFMA: this is batched 3x3 physics.
 #include "dpenv_env_dev.h"
 
+#ifndef DPENV_STEP_HOIST_LOADS
+#define DPENV_STEP_HOIST_LOADS 1
+#endif
+
 namespace dpenv {
 
 #ifdef DPENV_STEP_TRACE
@@ -142,7 +146,9 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(const 
     }
     Env s;
     load_env(a, il, s);
+#if !DPENV_STEP_HOIST_LOADS
     sincos_lean(s.psi, s.sn, s.cs);
+#endif
     float nrN = 0.0f, nrE = 0.0f, nrP = 0.0f;
     if (a.new_ref) { nrN = a.new_ref[il]; nrE = a.new_ref[(int64_t)n + il]; nrP = a.new_ref[2 * (int64_t)n + il]; }
     Current cur = {0.0f, 0.0f, 0.0f, 0.0f, 0u};
@@ -150,16 +156,12 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(const 
     if (a.cur_vc) {
         cur.vc = a.cur_vc[il]; cur.beta = a.cur_beta[il];
         if (a.current_drift) { vc0 = a.cur_vc0[il]; beta0 = a.cur_beta0[il]; cur.ctr = a.drift_ctr[il]; }
+#if !DPENV_STEP_HOIST_LOADS
         current_components(cur);
+#endif
     }
     int cls = 0;
-    if (PER_CLASS) {
-        cls = a.class_id[il];
-        for (int k = tid; k < VD_COUNT * a.n_classes; k += BLOCK) {
-            const int c = k / VD_COUNT, p = k - c * VD_COUNT;   // global table is [class][param]
-            lds_cls[p * a.n_classes + c] = a.class_tab[k];
-        }
-    }
+    if (PER_CLASS) cls = a.class_id[il];
     Vessel ve_env;
     if (ENV_VGPR) ve_env = vessel_from_env(a.env_tab, a.env_stride, il);                 // eight more 16-byte loads in the same burst
     if (VES == VES_ENV_LDS) {
@@ -169,6 +171,21 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(const 
         for (int g = 0; g < ENV_GROUPS; ++g)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.env_tab + ((int64_t)g * a.env_stride + il)),
                                              (__attribute__((address_space(3))) void*)(lds_pe + g * 64), 16, 0, 0);
+    }
+#if DPENV_STEP_HOIST_LOADS
+    // Every load of the step is in flight before the first loaded value is looked at: the sine / cosine of the heading (and of the current's
+    // direction) start with a range test - a branch - and whatever load the compiler leaves behind that branch waits a whole memory round
+    // trip for psi first (round 5: read off the ISA - the fourth state stream, the setpoint / current loads and the per-env block each
+    // started only after an earlier s_waitcnt vmcnt had drained).
+    __builtin_amdgcn_sched_barrier(0);
+    sincos_lean(s.psi, s.sn, s.cs);
+    if (a.cur_vc) current_components(cur);
+#endif
+    if (PER_CLASS) {
+        for (int k = tid; k < VD_COUNT * a.n_classes; k += BLOCK) {
+            const int c = k / VD_COUNT, p = k - c * VD_COUNT;   // global table is [class][param]
+            lds_cls[p * a.n_classes + c] = a.class_tab[k];
+        }
     }
     if (a.action_layout == LAYOUT_AOS) {
 #pragma unroll

@@ -941,14 +941,16 @@ __device__ __forceinline__ void env_auto_reset(const StepArgs& a, Env& s, int64_
     reset_apply<MODE>(a, s, d, o_new);
 }
 
-__device__ __forceinline__ void load_env(const StepArgs& a, int il, Env& s)
+__device__ __forceinline__ void load_env(const float4* S0, const float4* S1, const float4* S2, const float4* RF, int il, Env& s)
 {
-    const float4 s0 = a.S0[il], s1 = a.S1[il], s2 = a.S2[il], rf = a.RF[il];
+    const float4 s0 = S0[il], s1 = S1[il], s2 = S2[il], rf = RF[il];
     s.N = s0.x; s.E = s0.y; s.psi = s0.z; s.u = s0.w; s.v = s1.x; s.r = s1.y;
     s.ang[0] = rf.w; s.ang[1] = s1.z; s.ang[2] = s1.w;
     s.pt[0] = s2.x; s.pt[1] = s2.y; s.pt[2] = s2.z; s.steps = __float_as_int(s2.w);
     s.refN = rf.x; s.refE = rf.y; s.refPsi = rf.z;
 }
+
+__device__ __forceinline__ void load_env(const StepArgs& a, int il, Env& s) { load_env(a.S0, a.S1, a.S2, a.RF, il, s); }
 
 __device__ __forceinline__ void store_env(const StepArgs& a, int i, const Env& s, bool rf_dirty)
 {

@@ -93,8 +93,14 @@ __device__ __forceinline__ void reset_from_lds(const float* lds, int lane, Env& 
 
 // VES (dpenv_dev.h VES_*): where a lane's vessel comes from - kernel arguments, the LDS-staged class table, or its own per-env block
 // (straight into registers, or through an LDS image filled by LDS-DMA: the A/B SURVEY section 7 asks for, bench.py `vessel_classes.per_env`).
+// The first seven arguments repeat fields of `a` (the four state streams, the action block, n, the action layout): scalar arguments at the
+// head of the list are PRELOADED into SGPRs by the command processor (-mllvm -amdgpu-kernarg-preload-count, gfx940+), so the address
+// arithmetic of the first loads does not wait for a scalar load of the argument block, which then runs beside them.
 template <int MODE, bool EXT, int VES, bool RESETW = false>
-__global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(const StepArgs a)
+__global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(const float4* __restrict__ pS0, const float4* __restrict__ pS1,
+                                                                          const float4* __restrict__ pS2, const float4* __restrict__ pRF,
+                                                                          const float* __restrict__ paction, const int pn, const int playout,
+                                                                          const StepArgs a)
 {
     constexpr int A = ModeTraits<MODE>::A;
     constexpr int OD = EXT ? 9 : 6;
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(const 
     }
     const int tid = threadIdx.x;
     const int i = blockIdx.x * BLOCK + tid;
-    const int n = a.n;
+    const int n = pn;
     const bool live = i < n;
     const int il = live ? i : n - 1;   // dead lanes shadow the last env and never store
 #ifdef DPENV_STEP_TRACE
@@ -137,15 +143,15 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(const 
 
     // ---- issue all global loads up front ------------------------------------------------------
     float act[A];
-    if (a.action_layout == LAYOUT_AOS) {
+    if (playout == LAYOUT_AOS) {
         const int64_t base = (int64_t)blockIdx.x * (BLOCK * A);
-        load_rows<A, BLOCK>(a.action + base, (int64_t)n * A - base, tid, act);
+        load_rows<A, BLOCK>(paction + base, (int64_t)n * A - base, tid, act);
     } else {
 #pragma unroll
-        for (int k = 0; k < A; ++k) act[k] = a.action[(int64_t)k * n + il];
+        for (int k = 0; k < A; ++k) act[k] = paction[(int64_t)k * n + il];
     }
     Env s;
-    load_env(a, il, s);
+    load_env(pS0, pS1, pS2, pRF, il, s);
 #if !DPENV_STEP_HOIST_LOADS
     sincos_lean(s.psi, s.sn, s.cs);
 #endif
@@ -187,12 +193,12 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(const 
             lds_cls[p * a.n_classes + c] = a.class_tab[k];
         }
     }
-    if (a.action_layout == LAYOUT_AOS) {
+    if (playout == LAYOUT_AOS) {
 #pragma unroll
         for (int j = 0; j < A; ++j) lds_io[j * BLOCK + tid] = act[j];
     }
-    if (a.action_layout == LAYOUT_AOS || PER_CLASS) lds_order<BLOCK>();
-    if (a.action_layout == LAYOUT_AOS) {
+    if (playout == LAYOUT_AOS || PER_CLASS) lds_order<BLOCK>();
+    if (playout == LAYOUT_AOS) {
 #pragma unroll
         for (int k = 0; k < A; ++k) act[k] = lds_io[tid * A + k];
     }
@@ -1060,12 +1066,12 @@ static hipError_t launch_step_ves(const StepArgs& a, bool ext, bool reset_wave, 
     if (a.auto_reset && BLOCK == 64 && reset_wave) {
         // auto-reset on: a second wave per workgroup prepares the re-draws beside the plant loop (RESETW above)
         const dim3 block2(2 * BLOCK);
-        if (ext) hipLaunchKernelGGL((step_kernel<MODE, true, VES, BLOCK == 64>), grid, block2, 0, s, a);
-        else hipLaunchKernelGGL((step_kernel<MODE, false, VES, BLOCK == 64>), grid, block2, 0, s, a);
+        if (ext) hipLaunchKernelGGL((step_kernel<MODE, true, VES, BLOCK == 64>), grid, block2, 0, s, a.S0, a.S1, a.S2, a.RF, a.action, a.n, a.action_layout, a);
+        else hipLaunchKernelGGL((step_kernel<MODE, false, VES, BLOCK == 64>), grid, block2, 0, s, a.S0, a.S1, a.S2, a.RF, a.action, a.n, a.action_layout, a);
         return hipGetLastError();
     }
-    if (ext) hipLaunchKernelGGL((step_kernel<MODE, true, VES>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((step_kernel<MODE, false, VES>), grid, block, 0, s, a);
+    if (ext) hipLaunchKernelGGL((step_kernel<MODE, true, VES>), grid, block, 0, s, a.S0, a.S1, a.S2, a.RF, a.action, a.n, a.action_layout, a);
+    else hipLaunchKernelGGL((step_kernel<MODE, false, VES>), grid, block, 0, s, a.S0, a.S1, a.S2, a.RF, a.action, a.n, a.action_layout, a);
     return hipGetLastError();
 }
 

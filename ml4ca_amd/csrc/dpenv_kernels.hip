@@ -32,6 +32,9 @@
 #ifndef DPENV_STEP_HOIST_LOADS
 #define DPENV_STEP_HOIST_LOADS 1
 #endif
+#ifndef DPENV_STEP_PRELOAD_ARGS
+#define DPENV_STEP_PRELOAD_ARGS 0
+#endif
 
 namespace dpenv {
 
@@ -93,15 +96,27 @@ __device__ __forceinline__ void reset_from_lds(const float* lds, int lane, Env& 
 
 // VES (dpenv_dev.h VES_*): where a lane's vessel comes from - kernel arguments, the LDS-staged class table, or its own per-env block
 // (straight into registers, or through an LDS image filled by LDS-DMA: the A/B SURVEY section 7 asks for, bench.py `vessel_classes.per_env`).
-// The first seven arguments repeat fields of `a` (the four state streams, the action block, n, the action layout): scalar arguments at the
-// head of the list are PRELOADED into SGPRs by the command processor (-mllvm -amdgpu-kernarg-preload-count, gfx940+), so the address
-// arithmetic of the first loads does not wait for a scalar load of the argument block, which then runs beside them.
+// DPENV_STEP_PRELOAD_ARGS (make PRELOAD=1; off by default): seven leading arguments repeat fields of `a` (the four state streams, the action
+// block, n, the action layout) - scalar arguments at the head of the list are PRELOADED into SGPRs by the command processor (-mllvm
+// -amdgpu-kernarg-preload-count, gfx940+), so the address arithmetic of the first loads does not wait for a scalar load of the argument block.
+// Measured (round 5): back-to-back launches 4.96 -> 4.88 us per step, ONE launch from dispatch to completion (rocprofv3's clock) 5.42 -> 5.65 us;
+// the same argument list WITHOUT the compiler flag costs 5.14 us.  DESIGN.md section 4.
+#if DPENV_STEP_PRELOAD_ARGS
+#define DPENV_STEP_PARAMS const float4* __restrict__ pS0, const float4* __restrict__ pS1, const float4* __restrict__ pS2, const float4* __restrict__ pRF, \
+                          const float* __restrict__ paction, const int pn, const int playout, const StepArgs a
+#define DPENV_STEP_LAUNCH_ARGS(a) (a).S0, (a).S1, (a).S2, (a).RF, (a).action, (a).n, (a).action_layout, (a)
+#else
+#define DPENV_STEP_PARAMS const StepArgs a
+#define DPENV_STEP_LAUNCH_ARGS(a) (a)
+#endif
 template <int MODE, bool EXT, int VES, bool RESETW = false>
-__global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(const float4* __restrict__ pS0, const float4* __restrict__ pS1,
-                                                                          const float4* __restrict__ pS2, const float4* __restrict__ pRF,
-                                                                          const float* __restrict__ paction, const int pn, const int playout,
-                                                                          const StepArgs a)
+__global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(DPENV_STEP_PARAMS)
 {
+#if !DPENV_STEP_PRELOAD_ARGS
+    const float4 *pS0 = a.S0, *pS1 = a.S1, *pS2 = a.S2, *pRF = a.RF;
+    const float* paction = a.action;
+    const int pn = a.n, playout = a.action_layout;
+#endif
     constexpr int A = ModeTraits<MODE>::A;
     constexpr int OD = EXT ? 9 : 6;
     constexpr bool PER_CLASS = VES == VES_CLASS_LDS;
@@ -1066,12 +1081,12 @@ static hipError_t launch_step_ves(const StepArgs& a, bool ext, bool reset_wave, 
     if (a.auto_reset && BLOCK == 64 && reset_wave) {
         // auto-reset on: a second wave per workgroup prepares the re-draws beside the plant loop (RESETW above)
         const dim3 block2(2 * BLOCK);
-        if (ext) hipLaunchKernelGGL((step_kernel<MODE, true, VES, BLOCK == 64>), grid, block2, 0, s, a.S0, a.S1, a.S2, a.RF, a.action, a.n, a.action_layout, a);
-        else hipLaunchKernelGGL((step_kernel<MODE, false, VES, BLOCK == 64>), grid, block2, 0, s, a.S0, a.S1, a.S2, a.RF, a.action, a.n, a.action_layout, a);
+        if (ext) hipLaunchKernelGGL((step_kernel<MODE, true, VES, BLOCK == 64>), grid, block2, 0, s, DPENV_STEP_LAUNCH_ARGS(a));
+        else hipLaunchKernelGGL((step_kernel<MODE, false, VES, BLOCK == 64>), grid, block2, 0, s, DPENV_STEP_LAUNCH_ARGS(a));
         return hipGetLastError();
     }
-    if (ext) hipLaunchKernelGGL((step_kernel<MODE, true, VES>), grid, block, 0, s, a.S0, a.S1, a.S2, a.RF, a.action, a.n, a.action_layout, a);
-    else hipLaunchKernelGGL((step_kernel<MODE, false, VES>), grid, block, 0, s, a.S0, a.S1, a.S2, a.RF, a.action, a.n, a.action_layout, a);
+    if (ext) hipLaunchKernelGGL((step_kernel<MODE, true, VES>), grid, block, 0, s, DPENV_STEP_LAUNCH_ARGS(a));
+    else hipLaunchKernelGGL((step_kernel<MODE, false, VES>), grid, block, 0, s, DPENV_STEP_LAUNCH_ARGS(a));
     return hipGetLastError();
 }
 

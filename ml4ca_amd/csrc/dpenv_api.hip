@@ -525,6 +525,12 @@ extern "C" int dpenv_set_vessel_params(dpenv_handle h, const float* params, dpen
         h->loss_on = false;
         return DPENV_OK;
     }
+    {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing((hipStream_t)s, &cap);
+        if (cap != hipStreamCaptureStatusNone)      // this setter reads one word back (below): it cannot be recorded into a graph
+            return fail(h, DPENV_EINVAL, "dpenv_set_vessel_params synchronises its stream and cannot be called while the stream is being captured");
+    }
     HIP_TRY(h, hipMemsetAsync(h->loss_flag, 0, sizeof(uint32_t), (hipStream_t)s));          // the packing kernel sets it if any env has a coefficient
     HIP_TRY(h, dpenv_dev_launch_pack_env_vessels(params, (int64_t)h->cfg.n_envs, 1, h->env_tab, h->loss_flag, h->env_stride, h->cfg.n_envs, (hipStream_t)s));
     // which kernels run from here on depends on whether any env has a thrust-loss coefficient (the general per-env form applies it, the

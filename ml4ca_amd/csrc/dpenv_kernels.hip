@@ -32,6 +32,16 @@
 #ifndef DPENV_STEP_HOIST_LOADS
 #define DPENV_STEP_HOIST_LOADS 1
 #endif
+#ifndef DPENV_STEP_STATE_STORES_FIRST
+#define DPENV_STEP_STATE_STORES_FIRST 1
+#endif
+#ifndef DPENV_STEP_EARLY_STORES
+#ifdef DPENV_STEP_TRACE
+#define DPENV_STEP_EARLY_STORES 0      // (the diagnostic build takes its end-of-wave time stamp on the common path)
+#else
+#define DPENV_STEP_EARLY_STORES 1
+#endif
+#endif
 #ifndef DPENV_STEP_PRELOAD_ARGS
 #define DPENV_STEP_PRELOAD_ARGS 0
 #endif
@@ -166,7 +176,7 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(DPENV_
         for (int k = 0; k < A; ++k) act[k] = paction[(int64_t)k * n + il];
     }
     Env s;
-    load_env(pS0, pS1, pS2, pRF, il, s);
+    load_env(pS0, pS1, pS2, pRF, il, s);          // (the state streams BEFORE the action rows, so that the heading arrives first: measured, 0.4 % slower)
 #if !DPENV_STEP_HOIST_LOADS
     sincos_lean(s.psi, s.sn, s.cs);
 #endif
@@ -225,13 +235,42 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(DPENV_
                     : PER_CLASS ? vessel_from_lds(lds_cls, a.n_classes, cls) : vessel_from_args(a.v0);
 
     StepOut out;
-    env_step<MODE, EXT>(a, ve, s, act, a.new_ref != nullptr, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out, RND ? il : -1);
+    StepRest rest;
+    env_step_chain<MODE, EXT, false>(a, ve, s, act, a.new_ref != nullptr, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out, rest, RND ? il : -1);
+    bool rf_dirty = (a.new_ref != nullptr) || (MODE == MODE_FULL);
+    // Without auto-reset the state, the observation and the termination bits are final HERE, ~100 instructions (exp, three square roots, the
+    // penalties) before the reward: their stores - 85 of the 89 bytes an env-step writes - go out now and travel while the reward is computed;
+    // the launch ends when its last store has landed, not when it was issued (round 5: 4.930 -> 4.897 us, four interleaved runs).  Storing the
+    // third state stream (commands and step counter: functions of the action alone) BEFORE the plant as well makes it 5.06 us: vmcnt counts
+    // in order, so every later wait for a load then waits for that store too.  With auto-reset a finished env's state and row are the new
+    // episode's: everything is stored after the re-draw, below.
+    const bool early = DPENV_STEP_EARLY_STORES && !RESETW && !a.auto_reset;      // launch-uniform
+    if (early) {
+        if (live) {
+            if (EXT && a.S3) a.S3[i] = make_float4(out.o[6], out.o[7], out.o[8], 0.0f);      // (see the stores below)
+            store_env(a, i, s, rf_dirty);
+            a.done[i] = (uint8_t)out.d;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        store_obs<OD>(a, a.obs, out.o, i, live, lds_io);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    env_step_finish<MODE, EXT, false>(a, s, act, rest, true, out);
     if (a.current_drift) {
         current_drift_step(a, cur, vc0, beta0, a.env_id_base + i);
         if (live) { a.cur_vc[i] = cur.vc; a.cur_beta[i] = cur.beta; a.drift_ctr[i] = cur.ctr; }
     }
+    if (early) {
+        if (live) {
+            a.rew[i] = out.reward;
+            if (a.parts) {
+                a.parts[i] = out.parts[0]; a.parts[(int64_t)n + i] = out.parts[1];
+                a.parts[2 * (int64_t)n + i] = out.parts[2]; a.parts[3 * (int64_t)n + i] = out.parts[3];
+            }
+        }
+        return;
+    }
 
-    bool rf_dirty = (a.new_ref != nullptr) || (MODE == MODE_FULL);
     float o_next[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) o_next[k] = out.o[k];
@@ -261,7 +300,9 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(DPENV_
     }
 
     // ---- stores ---------------------------------------------------------------------------------
+#if !DPENV_STEP_STATE_STORES_FIRST
     store_obs<OD>(a, a.obs, o_next, i, live, lds_io);
+#endif
     if (live) {
         // the thrust columns of the observation just returned: a closed-loop launch that follows continues from THIS observation, not
         // from one rebuilt from the state block (which holds the command of this step, not of the one before: customEnv.py:196-205,126).
@@ -275,6 +316,13 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(DPENV_
             a.parts[2 * (int64_t)n + i] = out.parts[2]; a.parts[3 * (int64_t)n + i] = out.parts[3];
         }
     }
+#if DPENV_STEP_STATE_STORES_FIRST
+    // the state / reward / done stores go out BEFORE the observation rows take their turn through the LDS transposition: they are in flight
+    // a few dozen instructions and two LDS round trips earlier and the launch ends that much sooner (round 5: 4.950 -> 4.927 us, four interleaved runs; with the row image
+    // written to LDS first and the state stores issued while it lands: 4.941)
+    __builtin_amdgcn_sched_barrier(0);
+    store_obs<OD>(a, a.obs, o_next, i, live, lds_io);
+#endif
 #ifdef DPENV_STEP_TRACE
     if (tid == 0 && g_step_trace) {
         const uint64_t t1 = wall_clock64();

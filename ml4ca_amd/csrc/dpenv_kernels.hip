@@ -176,7 +176,8 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(DPENV_
         for (int k = 0; k < A; ++k) act[k] = paction[(int64_t)k * n + il];
     }
     Env s;
-    load_env(pS0, pS1, pS2, pRF, il, s);          // (the state streams BEFORE the action rows, so that the heading arrives first: measured, 0.4 % slower)
+    load_env(pS0, pS1, pS2, pRF, il, s);          // (the state streams BEFORE the action rows, so that the heading arrives first: measured, 0.4 % slower;
+                                                  //  the third stream - not needed before the observation - issued LAST, outside the first wait: no change)
 #if !DPENV_STEP_HOIST_LOADS
     sincos_lean(s.psi, s.sn, s.cs);
 #endif

@@ -2,8 +2,9 @@
  * resets 65 536 environments, steps them 2 000 times with a fixed action block, and prints throughput and a
  * checksum.  Then the FUSED entry points from the same C program (round 5): dpenv_rollout (50 env steps in one launch, one setpoint
  * switch inside it) and, on the rows it wrote, dpenv_gae_stats + dpenv_adv_apply_stats (TrajectoryBuffer.finish_path / get of
- * spinup/algos/tf1/ppo/ppo.py:65-105) - with checksums that tests/test_gpu_c_abi.py compares with the same calls made through
- * the Python binding.  Build (see tests/test_gpu_c_abi.py):
+ * spinup/algos/tf1/ppo/ppo.py:65-105), and the per-env vessel entry points (the thrust-loss preset through dpenv_create, explicit per-env
+ * blocks with dpenv_set_vessel_params / dpenv_get_vessel_params, dpenv_set_vessel_randomisation) - with checksums that
+ * tests/test_gpu_c_abi.py compares with the same calls made through the Python binding.  Build (see tests/test_gpu_c_abi.py):
  *   gcc -std=c11 -O2 -I include -I /opt/rocm/include examples/c_abi_demo.c -L ml4ca_amd/lib -ldpenv -L /opt/rocm/lib -lamdhip64 \
  *       -Wl,-rpath,$PWD/ml4ca_amd/lib -Wl,-rpath,/opt/rocm/lib -o build/c_abi_demo
  */
@@ -154,5 +155,78 @@ int main(int argc, char** argv)
            "gae_stats %.17g %.17g adv_norm_sum %.17g adv_norm_sq %.17g ret %.17g\n", n2, T, SW, obs_sum, rew_sum, done_count, hstats[0], hstats[1], adv_sum,
            adv_sq, ret_sum);
     CHECK(dpenv_destroy(h));
-    return 0;
+
+    /* ---- per-env vessels from plain C: a preset through dpenv_create, explicit per-env blocks, the randomisation ------------------ */
+    const int n3 = 2048, S3 = 20;
+    float preset[DPENV_NPARAM], range[DPENV_NPARAM];
+    CHECK(dpenv_default_vessel_ex(DPENV_VESSEL_THRUST_LOSS, preset));          /* the hull with the inflow thrust loss (customEnv.py:13-18, second set of speeds) */
+    dpenv_default_config(&cfg);
+    cfg.n_envs = n3;
+    cfg.auto_reset = 1;
+    cfg.max_ep_len = 8;
+    cfg.seed = 11;
+    h = NULL;
+    CHECK(dpenv_create(&cfg, preset, 1, &h));                                  /* one class WITH loss coefficients: installed as per-env blocks */
+    float *tab, *act3, *obs3, *rew3;
+    uint8_t* done3;
+    const size_t nt = (size_t)DPENV_NPARAM * n3;
+    if (hipMalloc((void**)&tab, 4 * nt) != hipSuccess || hipMalloc((void**)&act3, 4 * (size_t)n3 * ad) != hipSuccess ||
+        hipMalloc((void**)&obs3, 4 * (size_t)n3 * od) != hipSuccess || hipMalloc((void**)&rew3, 4 * (size_t)n3) != hipSuccess ||
+        hipMalloc((void**)&done3, n3) != hipSuccess) {
+        fprintf(stderr, "hipMalloc failed\n");
+        return 1;
+    }
+    float* htab = (float*)malloc(4 * nt);
+    CHECK(dpenv_get_vessel_params(h, tab, stream));
+    hipStreamSynchronize(stream);
+    hipMemcpy(htab, tab, 4 * nt, hipMemcpyDeviceToHost);
+    int same = 1;
+    for (int p = 0; p < DPENV_NPARAM; ++p)
+        for (int i = 0; i < n3; ++i) same = same && htab[(size_t)p * n3 + i] == preset[p];
+    /* every env its own hull AND its own loss coefficients: +-10 % around the preset, [param][env] */
+    s = 4711u;
+    for (int p = 0; p < DPENV_NPARAM; ++p)
+        for (int i = 0; i < n3; ++i) {
+            s = s * 1664525u + 1013904223u;
+            htab[(size_t)p * n3 + i] = preset[p] * (1.0f + 0.2f * ((float)(s >> 8) / 16777216.0f - 0.5f));
+        }
+    hipMemcpy(tab, htab, 4 * nt, hipMemcpyHostToDevice);
+    CHECK(dpenv_set_vessel_params(h, tab, stream));                             /* (synchronises: it learns whether any env carries a loss coefficient) */
+    float* hact3 = (float*)malloc(4 * (size_t)n3 * ad);
+    float* hobs3 = (float*)malloc(4 * (size_t)n3 * od);
+    float* hrew3 = (float*)malloc(4 * (size_t)n3);
+    double sums[2][3];
+    for (int phase = 0; phase < 2; ++phase) {
+        if (phase == 1) {                                                       /* hulls re-drawn by every reset, +-15 % around the preset, coefficients included */
+            for (int p = 0; p < DPENV_NPARAM; ++p) range[p] = 0.15f;
+            CHECK(dpenv_set_vessel_randomisation(h, preset, range, stream));
+        }
+        CHECK(dpenv_reset(h, NULL, NULL, NULL, NULL, stream));
+        double osum = 0.0, rsum = 0.0;
+        s = 99u + (unsigned)phase;
+        for (int t = 0; t < S3; ++t) {
+            for (size_t i = 0; i < (size_t)n3 * ad; ++i) {
+                s = s * 1664525u + 1013904223u;
+                hact3[i] = ((float)(s >> 8) / 16777216.0f - 0.5f) * 1.6f;
+            }
+            hipMemcpy(act3, hact3, 4 * (size_t)n3 * ad, hipMemcpyHostToDevice);
+            CHECK(dpenv_step(h, act3, NULL, obs3, rew3, done3, stream));
+            hipStreamSynchronize(stream);
+            hipMemcpy(hobs3, obs3, 4 * (size_t)n3 * od, hipMemcpyDeviceToHost);
+            hipMemcpy(hrew3, rew3, 4 * (size_t)n3, hipMemcpyDeviceToHost);
+            for (size_t i = 0; i < (size_t)n3 * od; ++i) osum += hobs3[i];
+            for (int i = 0; i < n3; ++i) rsum += hrew3[i];
+        }
+        CHECK(dpenv_get_vessel_params(h, tab, stream));
+        hipStreamSynchronize(stream);
+        hipMemcpy(htab, tab, 4 * nt, hipMemcpyDeviceToHost);
+        double tsum = 0.0;
+        for (size_t i = 0; i < nt; ++i) tsum += htab[i];
+        sums[phase][0] = osum; sums[phase][1] = rsum; sums[phase][2] = tsum;
+    }
+    printf("c_abi_demo vessels: %d envs x %d steps on the thrust-loss preset; preset read back %s; per-env blocks: checksums obs %.17g rew %.17g table %.17g; "
+           "randomised: obs %.17g rew %.17g table %.17g\n", n3, S3, same ? "exactly" : "DIFFERENT", sums[0][0], sums[0][1], sums[0][2], sums[1][0], sums[1][1],
+           sums[1][2]);
+    CHECK(dpenv_destroy(h));
+    return same ? 0 : 3;
 }

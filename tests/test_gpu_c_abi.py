@@ -52,3 +52,35 @@ def test_plain_c_program_steps_the_env(tmp_path):
     for g_, w_ in zip(got, want):                                               # host sums of float32 rows in double (order of summation differs)
         assert abs(g_ - w_) <= 1e-9 * max(1.0, abs(w_)), (got, want)
     assert abs(got[5]) < 1e-2 * n * T and abs(got[6] / (n * T) - 1.0) < 1e-3   # normalised: mean 0, variance 1
+    # per-env vessels from the same C program: the thrust-loss preset through dpenv_create (read back exactly), explicit per-env blocks with
+    # their own loss coefficients, then the randomisation around the preset - checksums against the same calls through the Python binding
+    v = re.search(r'vessels: (\d+) envs x (\d+) steps .* preset read back (\w+); per-env blocks: checksums obs (\S+) rew (\S+) table (\S+); '
+                  r'randomised: obs (\S+) rew (\S+) table (\S+)', out)
+    assert v and v.group(3) == 'exactly', out
+    n3, S3 = int(v.group(1)), int(v.group(2))
+
+    def lcg(seed, count):
+        x, vals = seed, np.empty(count, np.float32)
+        for i in range(count):
+            x = (x * 1664525 + 1013904223) & 0xffffffff
+            vals[i] = np.float32(x >> 8) / np.float32(16777216.0) - np.float32(0.5)
+        return vals
+
+    preset = ml4ca_amd.default_vessel('thrust_loss')
+    env = ml4ca_amd.BatchedRevoltEnv(n3, auto_reset=True, max_ep_len=16, seed=11, vessel_params=preset)     # customEnv.py:83: 16 -> 8 env steps, the demo's cfg.max_ep_len
+    assert np.array_equal(env.get_vessel_params().cpu().numpy(), np.tile(preset[:, None], (1, n3)))
+    tab = (preset[:, None] * (np.float32(1.0) + np.float32(0.2) * lcg(4711, 32 * n3).reshape(32, n3))).astype(np.float32)
+    env.set_vessel_params(torch.from_numpy(tab).to(env.device))
+    for phase in range(2):
+        if phase == 1:
+            env.set_vessel_randomisation(0.15, nominal=preset)
+        env.reset()
+        acts = (lcg(99 + phase, S3 * n3 * 7) * np.float32(1.6)).reshape(S3, n3, 7)
+        osum = rsum = 0.0
+        for t in range(S3):
+            o, r, _, _ = env.step(torch.from_numpy(acts[t]).to(env.device))
+            osum += float(o.double().sum())
+            rsum += float(r.double().sum())
+        tsum = float(env.get_vessel_params().double().sum())
+        for g_, w_ in zip((osum, rsum, tsum), (float(v.group(4 + 3 * phase)), float(v.group(5 + 3 * phase)), float(v.group(6 + 3 * phase)))):
+            assert abs(g_ - w_) <= 1e-9 * max(1.0, abs(w_)), (phase, g_, w_)

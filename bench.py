@@ -683,6 +683,55 @@ def classes_record(args, dev, n, with_classes=True):
     return rec
 
 
+def multi_handle_record(dev, n):
+    """Twice the headline's envs on ONE GPU, as one handle and as two handles stepped as independent chains on separate streams
+    (tools/multi_handle_step.py): the phases of one launch - kernel boundary, load burst, lone-wave arithmetic, store
+    burst - cannot overlap, those of independent chains do.  Envs never interact: a trainer may shard a GPU's envs this way.
+    Wall clock over 20 replays of 50-step graphs, all handles' envs counted."""
+    import torch
+    import ml4ca_amd
+
+    def run(parts):
+        streams = [torch.cuda.Stream(device=dev) for _ in parts]
+        built, base = [], 0
+        for k, (m, st) in enumerate(zip(parts, streams)):
+            env = ml4ca_amd.BatchedRevoltEnv(m, device=dev, terminate=False, time_limit=False, seed=1, env_id_base=base)
+            base += m
+            g = torch.Generator(device=dev)
+            g.manual_seed(5 + k)
+            acts = torch.randn((CHUNK, m, 7), generator=g, device=dev) * 0.6065
+            io = (torch.empty((m, 9), device=dev), torch.empty(m, device=dev), torch.empty(m, dtype=torch.uint8, device=dev))
+            with torch.cuda.stream(st):
+                env.reset()
+                for t in range(CHUNK):
+                    env.step(acts[t], out=io)
+                torch.cuda.synchronize(dev)
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, stream=st):
+                    for t in range(CHUNK):
+                        env.step(acts[t], out=io)
+            built.append((env, gr, acts, io))
+        torch.cuda.synchronize(dev)
+
+        def replays(k):
+            for _ in range(k):
+                for (_, gr, _, _), st in zip(built, streams):
+                    with torch.cuda.stream(st):
+                        gr.replay()
+        replays(3)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        replays(20)
+        torch.cuda.synchronize(dev)
+        sec = (time.perf_counter() - t0) / (20 * CHUNK)
+        tot = sum(parts)
+        return {'us_per_step_of_all_envs': sec * 1e6, 'env_steps_per_s': tot / sec, 'frac_of_hbm_at_177B': ALGO_BYTES_PER_ENV_STEP * tot / sec / 1e9 / HBM_PEAK_GBPS}
+
+    one, two = run([2 * n]), run([n, n])
+    return {'what': multi_handle_record.__doc__.replace('\n    ', ' '), 'envs_total': 2 * n, 'one_handle': one, 'two_handles_two_streams': two,
+            'gain': two['env_steps_per_s'] / one['env_steps_per_s']}
+
+
 def eager_record(env, actions, dev):
     """What a user's own Python loop pays per call of BatchedRevoltEnv.step - the call pattern of spinup/algos/tf1/ppo/ppo.py:291-293
     (`o2, r, d, _ = env.step(a)` inside a `for`), no HIP graph: (a) the steady loop (wall and HIP events; the GPU is the bound if the host
@@ -1198,11 +1247,20 @@ def main():
             import traceback
             classes = {'error': '%s: %s' % (type(e).__name__, e), 'traceback': traceback.format_exc()[-1500:]}
 
+    multi = None
+    if rank == 0 and side_legs and world == 1:
+        try:
+            multi = multi_handle_record(dev, n)
+        except Exception as e:       # pragma: no cover - a side record must not cost the line
+            multi = {'error': '%s: %s' % (type(e).__name__, e)}
+
     if rank == 0:
         if cfg4:
             res['config4'] = cfg4
         if classes:
             res['vessel_classes'] = classes
+        if multi:
+            res['multi_handle'] = multi
         if eager:
             res['eager_loop'] = eager
         if fused:

@@ -88,6 +88,8 @@ def main():
                                                                   'Philox keyed (seed; global env id, episode): independent of the rank count')
     ap.add_argument('--preset', default='no_loss', choices=('no_loss', 'thrust_loss'), help='nominal hull (dpenv_default_vessel_ex)')
     ap.add_argument('--eval', action='store_true', help='after training: run_RL_policy + the box test (IAE, energy) on the nominal hull and on spreads of hulls')
+    ap.add_argument('--eval-presets', default='', help="comma-separated presets to run --eval on (default: the training preset), e.g. 'no_loss,thrust_loss': "
+                                                      'how an actor trained on one thrust regime fares on the other')
     ap.add_argument('--save', default='', help='write the trained parameters (reference variable names) to this .npz')
     ap.add_argument('--backend', default='nccl', help="'nccl' (RCCL, one GPU per rank) or 'gloo' (rehearsal)")
     ap.add_argument('--same-device', action='store_true', help='all ranks on cuda:0 (multi-rank rehearsal on a one-GPU box)')
@@ -204,7 +206,9 @@ def main():
             import numpy as np
             np.savez(args.save, **{k.replace('/', '.'): v for k, v in ac.state_dict().items()})
         if args.eval:
-            evaluate_actor(ac, dev, args.preset, 'f32', args.seed)
+            for pz in (args.eval_presets.split(',') if args.eval_presets else [args.preset]):
+                print('eval on the %s preset (trained on %s%s)' % (pz, args.preset, ', hulls re-drawn +-%g %%' % (100 * args.randomise) if args.randomise > 0 else ''))
+                evaluate_actor(ac, dev, pz, 'f32', args.seed)
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -234,43 +234,57 @@ def test_two_wave_policy_rollout_full_size_soak():
 
 
 def test_bench_line_with_every_record_at_reduced_size():
-    """bench.py end to end on one GPU at reduced size: the contract keys, roofline, cpu_baseline with its legs and the per-quantity error
-    ledger, the side legs, the config-4 record (every leg present, no error) and the vessel-class record.  The N > 1 runs of the driver
+    """bench.py end to end on one GPU at reduced size: the ONE stdout line (contract keys, roofline, compact cpu_baseline; under 4 KB, and
+    stdout + stderr together under the 8 KB tail the driver keeps) and the side records in bench_side.json: cpu_baseline with its legs and the
+    per-quantity error ledger, the side legs, the config-4 record (every leg present, no error) and the vessel-class record.  The N > 1 runs of the driver
     execute exactly this code plus the collectives (rehearsed over gloo in tests/test_host_cpu.py and profiles/r03c_rehearsal_*)."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    side_path = os.path.join(root, 'gpurun_out', 'bench_side_test.json') if os.path.isdir(os.path.join(root, 'gpurun_out')) else '/tmp/bench_side_test.json'
     p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--envs', '8192', '--steps', '100', '--warmup', '50', '--cpu-seconds', '1.5',
-                        '--config4', '1', '--config4-envs', '4096', '--classes', '3'], capture_output=True, text=True, timeout=600)
+                        '--config4', '1', '--config4-envs', '4096', '--classes', '3', '--side-json', side_path], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1
+    # the driver keeps an 8 KB tail of stdout + stderr: the line is built for <= 4 KB (bench.py asserts < 8 KB itself), stderr stays short
+    assert len(lines[0]) < 4096, len(lines[0])
+    assert len(p.stdout) + len(p.stderr) < 8192, (len(p.stdout), len(p.stderr), p.stderr[-2000:])
     r = json.loads(lines[0])
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config'):
         assert k in r, k
+    assert set(r) <= {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'repeats', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                      'dtype', 'data', 'config', 'roofline', 'roofline_valu', 'cpu_baseline', 'side_records'}, set(r)
     assert r['n_gpus'] == 1 and r['steps'] == 100 and r['warmup'] == 50 and r['dtype'] == 'f32' and r['vs_baseline'] is None
-    assert abs(r['value'] - 8192 / (r['ms_per_step'] * 1e-3)) < 1e-6 * r['value'] and 'math' in r['config']
+    assert abs(r['value'] - 8192 / (r['ms_per_step'] * 1e-3)) < 1e-6 * r['value'] and 'workload' in r['config']
     rf = r['roofline']
     assert rf['bound'] == 'hbm' and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-12 and rf['achieved'] < rf['peak']
     cb = r['cpu_baseline']
-    assert cb['kind'] == 'port' and cb['value'] == max(l['env_steps_per_s'] for l in cb['legs']) and cb['cores'] >= 1
+    assert cb['kind'] == 'port' and cb['cores'] >= 1 and cb['value'] >= cb['value_1thread'] > 0 and 'sample' in cb
     led = cb['gpu_vs_cpu']
     assert led['done_mismatches_elsewhere'] == 0 and led['max_rel_err_obs'] < 1e-5 and led['max_rel_err_reward'] < 1e-5
-    assert set(led['per_quantity']) >= {'obs.x~', 'obs.u', 'reward', 'reward.pos'}
-    assert r['group']['world_size'] == 1 and len(r['per_rank']['wall_s']) == 1
-    for leg in ('fused_rollout', 'policy_rollout', 'config5_ppo_rollout'):
-        assert leg in r, leg
-    assert 'two_wave' in r['policy_rollout']['policy_dtype_f32']['launch_form']
-    c4 = r['config4']
+    assert any(l.startswith('bench.py: headline: {') for l in p.stderr.splitlines())
+    # everything else: the side records
+    s = json.load(open(side_path))
+    full = s['cpu_baseline_full']
+    assert full['value'] == cb['value'] == max(l['env_steps_per_s'] for l in full['legs'])
+    assert set(full['gpu_vs_cpu']['per_quantity']) >= {'obs.x~', 'obs.u', 'reward', 'reward.pos'}
+    assert s['group']['world_size'] == 1 and len(s['per_rank']['wall_s']) == 1 and 'math' in s['headline_notes']
+    assert 'side_legs_error' not in s, s.get('side_legs_error')
+    for leg in ('eager_loop', 'fused_rollout', 'policy_rollout', 'config5_ppo_rollout', 'multi_handle'):
+        assert leg in s, leg
+    assert 'two_wave' in s['policy_rollout']['policy_dtype_f32']['launch_form']
+    assert 'error' not in s['multi_handle'] and s['multi_handle']['at_metric_size']['envs_total'] == 8192
+    c4 = s['config4']
     assert 'error' not in c4, c4
     for leg in ('step_only', 'fused_rollout', 'closed_loop', 'exchange_76B', 'episode_plus_sync_exchange_76B',
                 'episode_with_previous_exchange_in_flight_76B', 'exchange_compact', 'summary'):
         assert leg in c4, leg
     assert c4['envs_per_rank'] == 4096 and c4['exchange_compact']['alone']['bytes_per_env_step'] == 58
     assert set(c4['closed_loop']) >= {'policy_dtype_f16', 'policy_dtype_f32_actor', 'policy_dtype_f32'}
-    vc = r['vessel_classes']
+    vc = s['vessel_classes']
     assert {'classes_1', 'classes_3', 'classes_16'} <= set(vc) and vc['classes_3']['step_us'] > 0
 
 
@@ -287,18 +301,22 @@ def test_bench_two_ranks_started_by_bench_itself_on_one_gpu():
     env = dict(os.environ)
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
         env.pop(k, None)
+    side_path = os.path.join(root, 'gpurun_out', 'bench_side_test2.json') if os.path.isdir(os.path.join(root, 'gpurun_out')) else '/tmp/bench_side_test2.json'
     p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--same-device', '--envs', '4096',
-                        '--steps', '20', '--warmup', '5', '--config4-envs', '1024'], capture_output=True, text=True, timeout=900, env=env)
+                        '--steps', '20', '--warmup', '5', '--config4-envs', '1024', '--side-json', side_path], capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, p.stdout[-2000:]
+    assert len(lines[0]) < 4096, len(lines[0])
     r = json.loads(lines[0])
     assert r['n_gpus'] == 2 and r['config']['total_envs'] == 8192 and r['scaling'] == 'weak' and r['cpu_baseline'] is None
-    assert r['group']['world_size'] == 2 and r['group']['backend'] == 'gloo' and len({x['pid'] for x in r['group']['ranks']}) == 2
-    assert len(r['per_rank']['wall_s']) == 2 and r['per_rank']['ms_per_step_max'] >= r['per_rank']['ms_per_step_min'] > 0
+    assert r['config']['backend'] == 'gloo' and 'roofline' in r
     assert abs(r['value'] - 8192 / (r['ms_per_step'] * 1e-3)) < 1e-6 * r['value']
-    assert 'fused_rollout' not in r                               # the single-GPU side legs stay home when there is more than one rank
-    c4 = r['config4']
+    s = json.load(open(side_path))
+    assert s['group']['world_size'] == 2 and s['group']['backend'] == 'gloo' and len({x['pid'] for x in s['group']['ranks']}) == 2
+    assert len(s['per_rank']['wall_s']) == 2 and s['per_rank']['ms_per_step_max'] >= s['per_rank']['ms_per_step_min'] > 0
+    assert 'fused_rollout' not in s                               # the single-GPU side legs stay home when there is more than one rank
+    c4 = s['config4']
     assert 'error' not in c4, c4
     assert c4['ranks'] == 2 and c4['total_envs'] == 2048
     for leg in ('step_only', 'fused_rollout', 'closed_loop', 'exchange_76B', 'episode_plus_sync_exchange_76B',

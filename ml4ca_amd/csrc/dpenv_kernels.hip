@@ -29,23 +29,6 @@
 // A/B, by LDS-DMA into a [group][lane] image).  No MFMA: this is batched 3x3 physics.
 #include "dpenv_env_dev.h"
 
-#ifndef DPENV_STEP_HOIST_LOADS
-#define DPENV_STEP_HOIST_LOADS 1
-#endif
-#ifndef DPENV_STEP_STATE_STORES_FIRST
-#define DPENV_STEP_STATE_STORES_FIRST 1
-#endif
-#ifndef DPENV_STEP_EARLY_STORES
-#ifdef DPENV_STEP_TRACE
-#define DPENV_STEP_EARLY_STORES 0      // (the diagnostic build takes its end-of-wave time stamp on the common path)
-#else
-#define DPENV_STEP_EARLY_STORES 1
-#endif
-#endif
-#ifndef DPENV_STEP_PRELOAD_ARGS
-#define DPENV_STEP_PRELOAD_ARGS 0
-#endif
-
 namespace dpenv {
 
 #ifdef DPENV_STEP_TRACE
@@ -106,27 +89,14 @@ __device__ __forceinline__ void reset_from_lds(const float* lds, int lane, Env& 
 
 // VES (dpenv_dev.h VES_*): where a lane's vessel comes from - kernel arguments, the LDS-staged class table, or its own per-env block
 // (straight into registers, or through an LDS image filled by LDS-DMA: the A/B SURVEY section 7 asks for, bench.py `vessel_classes.per_env`).
-// DPENV_STEP_PRELOAD_ARGS (make PRELOAD=1; off by default): seven leading arguments repeat fields of `a` (the four state streams, the action
-// block, n, the action layout) - scalar arguments at the head of the list are PRELOADED into SGPRs by the command processor (-mllvm
-// -amdgpu-kernarg-preload-count, gfx940+), so the address arithmetic of the first loads does not wait for a scalar load of the argument block.
-// Measured (round 5): back-to-back launches 4.96 -> 4.88 us per step, ONE launch from dispatch to completion (rocprofv3's clock) 5.42 -> 5.65 us;
-// the same argument list WITHOUT the compiler flag costs 5.14 us.  DESIGN.md section 4.
-#if DPENV_STEP_PRELOAD_ARGS
-#define DPENV_STEP_PARAMS const float4* __restrict__ pS0, const float4* __restrict__ pS1, const float4* __restrict__ pS2, const float4* __restrict__ pRF, \
-                          const float* __restrict__ paction, const int pn, const int playout, const StepArgs a
-#define DPENV_STEP_LAUNCH_ARGS(a) (a).S0, (a).S1, (a).S2, (a).RF, (a).action, (a).n, (a).action_layout, (a)
-#else
-#define DPENV_STEP_PARAMS const StepArgs a
-#define DPENV_STEP_LAUNCH_ARGS(a) (a)
-#endif
+// (Rejected forms of this kernel - loads not hoisted above the first branch, observation rows before the state stores, no early stores,
+// the state streams repeated as preloaded scalar arguments - were A/B switches until round 6: tools/ab/README.md, profiles/LAB_NOTES.md.)
 template <int MODE, bool EXT, int VES, bool RESETW = false>
-__global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(DPENV_STEP_PARAMS)
+__global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(const StepArgs a)
 {
-#if !DPENV_STEP_PRELOAD_ARGS
     const float4 *pS0 = a.S0, *pS1 = a.S1, *pS2 = a.S2, *pRF = a.RF;
     const float* paction = a.action;
     const int pn = a.n, playout = a.action_layout;
-#endif
     constexpr int A = ModeTraits<MODE>::A;
     constexpr int OD = EXT ? 9 : 6;
     constexpr bool PER_CLASS = VES == VES_CLASS_LDS;
@@ -178,9 +148,6 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(DPENV_
     Env s;
     load_env(pS0, pS1, pS2, pRF, il, s);          // (the state streams BEFORE the action rows, so that the heading arrives first: measured, 0.4 % slower;
                                                   //  the third stream - not needed before the observation - issued LAST, outside the first wait: no change)
-#if !DPENV_STEP_HOIST_LOADS
-    sincos_lean(s.psi, s.sn, s.cs);
-#endif
     float nrN = 0.0f, nrE = 0.0f, nrP = 0.0f;
     if (a.new_ref) { nrN = a.new_ref[il]; nrE = a.new_ref[(int64_t)n + il]; nrP = a.new_ref[2 * (int64_t)n + il]; }
     Current cur = {0.0f, 0.0f, 0.0f, 0.0f, 0u};
@@ -188,9 +155,6 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(DPENV_
     if (a.cur_vc) {
         cur.vc = a.cur_vc[il]; cur.beta = a.cur_beta[il];
         if (a.current_drift) { vc0 = a.cur_vc0[il]; beta0 = a.cur_beta0[il]; cur.ctr = a.drift_ctr[il]; }
-#if !DPENV_STEP_HOIST_LOADS
-        current_components(cur);
-#endif
     }
     int cls = 0;
     if (PER_CLASS) cls = a.class_id[il];
@@ -204,7 +168,6 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(DPENV_
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.env_tab + ((int64_t)g * a.env_stride + il)),
                                              (__attribute__((address_space(3))) void*)(lds_pe + g * 64), 16, 0, 0);
     }
-#if DPENV_STEP_HOIST_LOADS
     // Every load of the step is in flight before the first loaded value is looked at: the sine / cosine of the heading (and of the current's
     // direction) start with a range test - a branch - and whatever load the compiler leaves behind that branch waits a whole memory round
     // trip for psi first (round 5: read off the ISA - the fourth state stream, the setpoint / current loads and the per-env block each
@@ -212,7 +175,6 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(DPENV_
     __builtin_amdgcn_sched_barrier(0);
     sincos_lean(s.psi, s.sn, s.cs);
     if (a.cur_vc) current_components(cur);
-#endif
     if (PER_CLASS) {
         for (int k = tid; k < VD_COUNT * a.n_classes; k += BLOCK) {
             const int c = k / VD_COUNT, p = k - c * VD_COUNT;   // global table is [class][param]
@@ -245,7 +207,11 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(DPENV_
     // third state stream (commands and step counter: functions of the action alone) BEFORE the plant as well makes it 5.06 us: vmcnt counts
     // in order, so every later wait for a load then waits for that store too.  With auto-reset a finished env's state and row are the new
     // episode's: everything is stored after the re-draw, below.
-    const bool early = DPENV_STEP_EARLY_STORES && !RESETW && !a.auto_reset;      // launch-uniform
+#ifdef DPENV_STEP_TRACE
+    const bool early = false;                              // (the diagnostic build takes its end-of-wave time stamp on the common path)
+#else
+    const bool early = !RESETW && !a.auto_reset;           // launch-uniform
+#endif
     if (early) {
         if (live) {
             if (EXT && a.S3) a.S3[i] = make_float4(out.o[6], out.o[7], out.o[8], 0.0f);      // (see the stores below)
@@ -301,9 +267,6 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(DPENV_
     }
 
     // ---- stores ---------------------------------------------------------------------------------
-#if !DPENV_STEP_STATE_STORES_FIRST
-    store_obs<OD>(a, a.obs, o_next, i, live, lds_io);
-#endif
     if (live) {
         // the thrust columns of the observation just returned: a closed-loop launch that follows continues from THIS observation, not
         // from one rebuilt from the state block (which holds the command of this step, not of the one before: customEnv.py:196-205,126).
@@ -317,13 +280,11 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(DPENV_
             a.parts[2 * (int64_t)n + i] = out.parts[2]; a.parts[3 * (int64_t)n + i] = out.parts[3];
         }
     }
-#if DPENV_STEP_STATE_STORES_FIRST
     // the state / reward / done stores go out BEFORE the observation rows take their turn through the LDS transposition: they are in flight
     // a few dozen instructions and two LDS round trips earlier and the launch ends that much sooner (round 5: 4.950 -> 4.927 us, four interleaved runs; with the row image
     // written to LDS first and the state stores issued while it lands: 4.941)
     __builtin_amdgcn_sched_barrier(0);
     store_obs<OD>(a, a.obs, o_next, i, live, lds_io);
-#endif
 #ifdef DPENV_STEP_TRACE
     if (tid == 0 && g_step_trace) {
         const uint64_t t1 = wall_clock64();
@@ -1130,12 +1091,12 @@ static hipError_t launch_step_ves(const StepArgs& a, bool ext, bool reset_wave, 
     if (a.auto_reset && BLOCK == 64 && reset_wave) {
         // auto-reset on: a second wave per workgroup prepares the re-draws beside the plant loop (RESETW above)
         const dim3 block2(2 * BLOCK);
-        if (ext) hipLaunchKernelGGL((step_kernel<MODE, true, VES, BLOCK == 64>), grid, block2, 0, s, DPENV_STEP_LAUNCH_ARGS(a));
-        else hipLaunchKernelGGL((step_kernel<MODE, false, VES, BLOCK == 64>), grid, block2, 0, s, DPENV_STEP_LAUNCH_ARGS(a));
+        if (ext) hipLaunchKernelGGL((step_kernel<MODE, true, VES, BLOCK == 64>), grid, block2, 0, s, a);
+        else hipLaunchKernelGGL((step_kernel<MODE, false, VES, BLOCK == 64>), grid, block2, 0, s, a);
         return hipGetLastError();
     }
-    if (ext) hipLaunchKernelGGL((step_kernel<MODE, true, VES>), grid, block, 0, s, DPENV_STEP_LAUNCH_ARGS(a));
-    else hipLaunchKernelGGL((step_kernel<MODE, false, VES>), grid, block, 0, s, DPENV_STEP_LAUNCH_ARGS(a));
+    if (ext) hipLaunchKernelGGL((step_kernel<MODE, true, VES>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((step_kernel<MODE, false, VES>), grid, block, 0, s, a);
     return hipGetLastError();
 }
 

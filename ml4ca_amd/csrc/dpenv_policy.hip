@@ -49,12 +49,7 @@ __global__ __launch_bounds__(PBLOCK) void policy_forward_kernel(const PolicyArgs
     half8 in0, in1;
     obs_to_frags<OD>(o, in0, in1);
     float mu[8], vv[8];
-#if DPENV_JOINT_EVAL
     mlp_eval2<KA>(lds_w, lds_w + pa.nent, lds_b, lds_b + pa.nblk * 32, pa.n_hidden, in0, in1, (_Float16)pa.leak, mu, vv);
-#else
-    mlp_eval<KA>(lds_w, lds_b, pa.n_hidden, in0, in1, (_Float16)pa.leak, mu);
-    mlp_eval<KA>(lds_w + pa.nent, lds_b + pa.nblk * 32, pa.n_hidden, in0, in1, (_Float16)pa.leak, vv);
-#endif
     wave_store_rows<A>(lds_io, mu_out, (int64_t)wave0 * A, (int64_t)(n - wave0) * A, mu, lane);
     if (live) v_out[i] = vv[0];
 }
@@ -123,11 +118,7 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
     half8 in0, in1;
     obs_to_frags<OD>(o, in0, in1);
     float vout[8], mu[8];
-#if DPENV_JOINT_EVAL
     mlp_eval2<KA>(Wpi, Wv, Bpi, Bv, pa.n_hidden, in0, in1, leak, mu, vout);     // actor and critic of o_0
-#else
-    mlp_eval<KA>(Wv, Bv, pa.n_hidden, in0, in1, leak, vout);
-#endif
     float v_t = vout[0];
 
     float pre[A];
@@ -136,9 +127,6 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
     for (int t = 0; t < pa.T; ++t) {
         // ---- store the policy input row; the actor's mean for it is already there (joint evaluation) -------------
         wave_store_rows<OD>(lds_io, pa.obs_out, (int64_t)t * stride_o + w_o, rem_o, o, lane, a.obs_bf16 != 0);
-#if !DPENV_JOINT_EVAL
-        mlp_eval<KA>(Wpi, Bpi, pa.n_hidden, in0, in1, leak, mu);
-#endif
         // ---- sample: a = mu + std * xi (core.py:85), log-likelihood (core.py:42-46) -----------
         float act[A];
         float logp;
@@ -174,7 +162,6 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
         for (int k = 0; k < 9; ++k) o[k] = out.o[k];
         // ppo.py:305-322 with reset_at_end: after the LAST step of the block every env is cut and re-drawn, ended or not
         const bool do_reset = ((a.auto_reset && out.d != 0u) || (pa.reset_at_end && t == pa.T - 1)) && live;
-#if DPENV_JOINT_EVAL
         // ---- value of the observation this step produced, and the next policy input ------------------------------
         // No env of the wave finished (the common case): the next policy input IS that observation, so one joint
         // evaluation gives V(o') for the bootstrap and the actor's mean for the next step.  Otherwise the critic is
@@ -197,23 +184,6 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
         mlp_eval2<KA>(Wpi, Wv, Bpi, Bv, pa.n_hidden, in0, in1, leak, mu, vout);
         const float v_next = do_reset ? v_pre : vout[0];
         const float v_new = vout[0];
-#else
-        // ---- critic on the observation this step produced (pre-reset) --------------------------
-        obs_to_frags<OD>(out.o, in0, in1);
-        mlp_eval<KA>(Wv, Bv, pa.n_hidden, in0, in1, leak, vout);
-        const float v_next = vout[0];
-        float v_new = v_next;
-        if (__ballot(do_reset) != 0ull) {                       // wave-uniform: rare
-            if (do_reset) {
-                env_auto_reset<MODE>(a, s, a.env_id_base + i, episode, o);
-                if (a.rand_tab) redraw_vessel_cold(a, i, episode, ve);    // domain randomisation: the new episode runs on a new hull
-                ++episode; ep_dirty = true; rf_dirty = true;
-            }
-            obs_to_frags<OD>(o, in0, in1);
-            mlp_eval<KA>(Wv, Bv, pa.n_hidden, in0, in1, leak, vout);
-            v_new = do_reset ? vout[0] : v_new;
-        }
-#endif
         // bootstrap value at a path end (ppo.py:311): 0 if the env terminated, V(o) if only the time limit or the
         // end of this launch cut the path
         const bool terminal = (out.d & DONE_TERMINAL) != 0u;

@@ -13,9 +13,6 @@ typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 
-#ifndef DPENV_JOINT_EVAL
-#define DPENV_JOINT_EVAL 1          // actor + critic of one observation as one interleaved routine (mlp_eval2)
-#endif
 
 constexpr int PBLOCK = 256;          // 4 waves share one LDS image of the weights
 constexpr int PWAVES = PBLOCK / 64;

@@ -53,11 +53,8 @@ __device__ __forceinline__ void ws_post(int* p, int v, int lane)
 }
 __device__ __forceinline__ void ws_wait(int* p, int v)
 {
-#ifndef DPENV_WS_POLL_SLEEP
-#define DPENV_WS_POLL_SLEEP 2      // x 64 cycles between polls (A/B'd in round 3: 0 / 1 / 2 / 4 within noise in both geometries)
-#endif
     while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < v)
-        __builtin_amdgcn_s_sleep(DPENV_WS_POLL_SLEEP);
+        __builtin_amdgcn_s_sleep(2);       // x 64 cycles between polls (A/B'd in round 3: 0 / 1 / 2 / 4 within noise in both geometries)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 #ifdef DPENV_WS_PROFILE
@@ -70,15 +67,7 @@ __device__ __forceinline__ void ws_wait(int* p, int v)
 #define WS_TOC(acc, t_)
 #endif
 
-#ifdef DPENV_WS_DEBUG_NOMFMA
-#define WS_EVAL(W_, B_, f0_, f1_)                                                   \
-    do {                                                                           \
-        _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) outv[k_] = 0.01f * (float)(f0_[k_ & 7] + f1_[k_ & 7]); \
-        for (int it_ = 0; it_ < 600; ++it_) { _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) outv[k_] = fmaf(outv[k_], 0.999f, 1e-4f); } \
-    } while (0)
-#else
 #define WS_EVAL(W_, B_, f0_, f1_) mlp_eval<KA>(W_, B_, pa.n_hidden, f0_, f1_, leak, outv)
-#endif
 //  RND: the domain randomisation's hull re-draw compiled into the reset branch (instantiated for the shipped training configuration only -
 //  final variant, continuous angles, extended state, leaky-relu - see dpenv_ws_launch::pick and dpenv_env_dev.h redraw_vessel_cold).
 template <int MODE, bool EXT, int KA, int ROLES, int PREC = PREC_F16, int GROUPS = 4, bool RND = false>
@@ -88,13 +77,10 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
     constexpr int OD = EXT ? 9 : 6;
     constexpr int THREADS = 64 * GROUPS * ROLES;
     constexpr bool SPLIT = PREC != PREC_F16;
-#ifndef DPENV_WS_STAGE_ACTOR
-#define DPENV_WS_STAGE_ACTOR 0
-#endif
     // env-wave rows through LDS transposes (else per lane).  Not in the three-role form: its env wave shares a SIMD with the critic wave and has
     // 256 registers, not 512 - with the staging code the f16 env wave spilled 116 B per lane there (round 4; without it 243 registers, no
     // scratch - and still 1-3 % slower than two roles for f16, so DPENV_WS_CRITIC_WAVE leaves f16 out: profiles/r04_critic_wave.txt)
-    constexpr bool STAGE = (!SPLIT && ROLES == 2) || (PREC == PREC_F32_ACTOR && DPENV_WS_STAGE_ACTOR);
+    constexpr bool STAGE = !SPLIT && ROLES == 2;
     constexpr int NIMG = ws_images(PREC);           // weight images staged: pi_hi, v_hi (, pi_lo (, v_lo))
     // All-exact arithmetic with a SIMD per wave (GROUPS = 2): the CRITIC runs on the ENV wave (round 3).  Two exact evaluations one after
     // the other in the network wave bound the step at 10.8 us while the env wave idles for most of it; with the critic behind the env
@@ -103,14 +89,13 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
     // MFMAs beside the actor's contend for ONE matrix pipe (today's order pairs matrix work with vector work: critic beside env.step,
     // rows beside the actor) and env state + evaluation do not fit 256 registers (10.0 -> 11.4 us exact actor, 13.5 -> 17.2 all exact,
     // with the vessel block and policy constants re-fetched per step and 268 / 412 B of scratch left); and not for the exact-actor
-    // mode with its f16 critic, which gains nothing (7.36 vs 7.34 us).  -DDPENV_WS_ECRITIC=0: the network wave's critic everywhere.
-#if defined(DPENV_WS_SELFCHECK) && !defined(DPENV_WS_ECRITIC)
-#define DPENV_WS_ECRITIC 0           // the diagnostic double evaluation waits for the network wave's critic
+    // mode with its f16 critic, which gains nothing (7.36 vs 7.34 us).
+#ifdef DPENV_WS_SELFCHECK
+    constexpr bool ECRITIC_ON = false;  // the diagnostic double evaluation waits for the network wave's critic
+#else
+    constexpr bool ECRITIC_ON = true;
 #endif
-#ifndef DPENV_WS_ECRITIC
-#define DPENV_WS_ECRITIC 1
-#endif
-    constexpr bool ECRITIC = PREC == PREC_F32 && GROUPS == 2 && ROLES == 2 && (DPENV_WS_ECRITIC != 0);
+    constexpr bool ECRITIC = PREC == PREC_F32 && GROUPS == 2 && ROLES == 2 && ECRITIC_ON;
     // ROLES = 3 (round 4, 128-env workgroups only): a CRITIC WAVE of its own per 64 envs - six waves on the four SIMDs of a CU, in the
     // order E0 E1 A0 A1 C0 C1, so that the actor waves keep a SIMD each and a critic wave shares one with its env wave (matrix work beside
     // vector work, the pairing that nets; MI355X_MICROARCH.md "Two waves per SIMD").  V(o_t) is then evaluated while the actor wave
@@ -130,11 +115,7 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
         for (int k = threadIdx.x; k < 2 * pa.nblk * 32; k += THREADS) lb[k] = pa.bias[k];
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#ifdef DPENV_WS_SWAP_ROLES
-    const int role = (ROLES - 1) - (wave / GROUPS); // diagnostic: the network waves are the first-dispatched (older) ones
-#else
     const int role = wave / GROUPS;                 // 0 = env wave, 1 = network wave
-#endif
     const int g = wave % GROUPS;
     constexpr int OBS_SLOTS = ROLES == 3 ? 2 : 1;
     float* grp = (float*)lds_dyn + img_floats + g * ((STAGE ? WS_GROUP_FLOATS : WS_GROUP_FLOATS_X) + (OBS_SLOTS - 1) * 64 * 9);
@@ -150,17 +131,10 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
     // next observation - with the noise in the env wave that wave was the busy one (tools/ws_profile.py).  xi_t travels in the
     // observation mailbox: once the network wave has turned o_t into fragments the rows are free until the env wave writes
     // o_t+1, which it does after it has waited for mu_t and read xi_t.
-#ifndef DPENV_WS_X_MNOISE
-#define DPENV_WS_X_MNOISE 0      // split arithmetics: the ENV wave draws (it idles ~4 us per step while the network wave evaluates the actor)
-#endif
-#ifndef DPENV_WS_ECRITIC_MNOISE
-#define DPENV_WS_ECRITIC_MNOISE 1  // ... unless the env wave carries the critic: then the network wave (actor only) has the time
-#endif
-#ifndef DPENV_WS_F16_G2_MNOISE
-#define DPENV_WS_F16_G2_MNOISE 0   // f16 with a SIMD per wave: the network wave (two evaluations per step) is the busy one there, the env wave draws
-#endif
-    constexpr bool M_NOISE = (ROLES == 2) && ((!SPLIT && (GROUPS == 4 || DPENV_WS_F16_G2_MNOISE)) || (SPLIT && DPENV_WS_X_MNOISE) ||
-                                              (ECRITIC && DPENV_WS_ECRITIC_MNOISE));
+    // Split arithmetics: the ENV wave draws (it idles ~4 us per step while the network wave evaluates the actor) - unless it carries the critic
+    // (ECRITIC): then the network wave (actor only) has the time.  f16 with a SIMD per wave: the network wave (two evaluations per step) is the
+    // busy one there, the env wave draws.
+    constexpr bool M_NOISE = (ROLES == 2) && ((!SPLIT && GROUPS == 4) || ECRITIC);
     float* xi_mb = obs_mb;
     const uint4* Wpi = lds_w;
     const uint4* Wv = lds_w + pa.nent;
@@ -182,16 +156,10 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
         // ------------------------------------------------------------------------------------ network wave(s)
         // the actor is on the serial chain of the step: let the SIMD's instruction arbiter prefer it; a critic-only wave
         // trails and takes what is left
-#ifndef DPENV_WS_M_PRIO
-#define DPENV_WS_M_PRIO 3
-#endif
-#ifndef DPENV_WS_C_PRIO
-#define DPENV_WS_C_PRIO 1        // the critic wave of the three-role form shares its SIMD with the env wave; same-call A/B at 32 768 envs, all
-#endif                           // exact: priority 0 8.4 us per step, 1 8.05, 2 7.85-8.1, 3 8.1 (profiles/r04_critic_wave.txt)
-#ifndef DPENV_WS_NO_SETPRIO
-        if (ROLES == 3 && role == 2) __builtin_amdgcn_s_setprio(DPENV_WS_C_PRIO);
-        else __builtin_amdgcn_s_setprio(DPENV_WS_M_PRIO);
-#endif
+        // (the critic wave of the three-role form shares its SIMD with the env wave; same-call A/B at 32 768 envs, all exact: priority 0 8.4 us
+        // per step, 1 8.05, 2 7.85-8.1, 3 8.1 - profiles/r04_critic_wave.txt)
+        if (ROLES == 3 && role == 2) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(3);
         // one copy of the loop per role, so that a wave's registers hold only what ITS evaluation needs (with the roles as run-time flags
         // the three-role kernel kept the union of both and spilled)
         auto net_wave = [&](auto ACT_, auto CRI_) __attribute__((always_inline)) {
@@ -229,14 +197,10 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
             }
             if (do_actor && t < pa.T) {
                 WS_TIC(ta_);
-#ifdef DPENV_WS_M_PRIO_CRITIC
-                __builtin_amdgcn_s_setprio(DPENV_WS_M_PRIO);
-#endif
                 if constexpr (SPLIT) mlp_eval_x<KA>(Wpi, Wpi_l, Bpi, pa.n_hidden, inx, pa.leak, outv);
                 else WS_EVAL(Wpi, Bpi, in0, in1);
 #pragma unroll
                 for (int k = 0; k < A; ++k) mu_mb[lane * 9 + k] = outv[k];
-#ifndef DPENV_WS_X_CARRY_FRAGS      // A/B switch (tools/): carry the fragments in registers across the actor's evaluation instead
                 if constexpr (SPLIT && !M_NOISE && do_critic) {
                     // The critic needs the fragments of o_t again.  Carried across the actor's evaluation they are 16 registers the
                     // evaluation does not have (the 256-env geometry leaves a wave 256 registers and no AGPRs: they were spilled to
@@ -247,11 +211,7 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
                     row_from(obs_mb + (t & (OBS_SLOTS - 1)) * (64 * 9));
                     obs_to_frags_x<OD>(o, inx);
                 }
-#endif
                 ws_post(&seq[1], t + 1, lane);                               // mu_t posted
-#ifdef DPENV_WS_M_PRIO_CRITIC
-                __builtin_amdgcn_s_setprio(DPENV_WS_M_PRIO_CRITIC);
-#endif
                 WS_TOC(t_act, ta_);
             }
             if (do_critic) {
@@ -294,9 +254,6 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
     }
 
     // ---------------------------------------------------------------------------------------- E-wave
-#ifdef DPENV_WS_E_PRIO
-    __builtin_amdgcn_s_setprio(DPENV_WS_E_PRIO);
-#endif
     Env s;
     Current cur = {0.0f, 0.0f, 0.0f, 0.0f, 0u};
     float vc0 = 0.0f, beta0 = 0.0f;
@@ -371,10 +328,7 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
     // termination on some env of a 64-env wave ends in about every fourth step, so the whole wave pays the Philox draw there.  The
     // draw is a pure function of (seed, global env id, episode): it is made while this wave waits for the actor's answer, for the episode
     // that would start next, and a reset on the chain is an assignment plus the first observation.  Same values, same rows.
-#ifndef DPENV_WS_PREDRAW
-#define DPENV_WS_PREDRAW 1
-#endif
-    constexpr bool PREDRAW = DPENV_WS_PREDRAW != 0;      // measured (round 3, same call): 1-2 % in every form, e.g. f16 7.28 -> 7.18 us at 65 536 envs
+    constexpr bool PREDRAW = true;        // measured (round 3, same call): 1-2 % in every form, e.g. f16 7.28 -> 7.18 us at 65 536 envs
     ResetDraw rdraw;
     bool need_draw = PREDRAW && (a.auto_reset || pa.reset_at_end);
     for (int t = 0; t <= pa.T; ++t) {
@@ -421,9 +375,6 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
         WS_TOC(t_noi, tn_);
         WS_WAIT_T(w_mu, &seq[1], t + 1);                                     // mu_t posted
         WS_TIC(tp_);
-#ifdef DPENV_WS_DYN_PRIO
-        __builtin_amdgcn_s_setprio(3);                                       // on the chain until o_t+1 is posted
-#endif
         float act[A], mu[A];
         float logp;
 #pragma unroll
@@ -461,13 +412,11 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
         WS_TOC(t_pre, tp_);
         WS_TIC(te_);
         // only what o_t+1 and the reset decision depend on stays on the chain; the reward and the azimuth bookkeeping follow the hand-over
-#if defined(DPENV_WS_SELFCHECK) && !defined(DPENV_WS_DEFER_REWARD)
-#define DPENV_WS_DEFER_REWARD 0      // the diagnostic double evaluation compares whole steps
+#ifdef DPENV_WS_SELFCHECK
+        constexpr bool DEFER = false;    // the diagnostic double evaluation compares whole steps
+#else
+        constexpr bool DEFER = true;
 #endif
-#ifndef DPENV_WS_DEFER_REWARD
-#define DPENV_WS_DEFER_REWARD 1
-#endif
-        constexpr bool DEFER = DPENV_WS_DEFER_REWARD != 0;
         StepRest rest;
         env_step_chain<MODE, EXT, DEFER>(a, ve, s, act, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out, rest, RND ? il : -1);
         if constexpr (!DEFER) env_step_finish<MODE, EXT, false>(a, s, act, rest, true, out);
@@ -538,9 +487,6 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
         ws_post(&seq[0], t + 2, lane);                                       // o_{t+1} (and this step's pre flag) posted
         WS_TOC(t_post, tq_);
         WS_TIC(tr_);
-#ifdef DPENV_WS_DYN_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
         __builtin_amdgcn_sched_barrier(0);                                   // nothing of the rows below moves up into the chain
         if constexpr (DEFER) env_step_finish<MODE, EXT, true>(a, s, act, rest, !do_reset, out);   // reward, azimuths of a continuing env
         logp = action_logp<A>(pc, mu, act);                                  // core.py:42-46 on (a_t, mu_t)
@@ -596,9 +542,6 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
 // Two-wave launches exist for hidden activation leaky-relu / relu in every arithmetic; tanh only in PREC_F16 with four groups
 // (dpenv_set_policy_desc routes the others to the one-wave kernels).  -DDPENV_DEV_FAST (development builds only, never shipped)
 // instantiates the shipped configuration alone: final / continuous angles / extended state, width <= 80.
-#ifndef DPENV_WS_STAGE_ACTOR
-#define DPENV_WS_STAGE_ACTOR 0
-#endif
 namespace dpenv_ws_launch {
 using namespace dpenv;
 
@@ -614,7 +557,7 @@ static hipError_t go(const StepArgs& a, const PolicyArgs& pa, hipStream_t s)
     constexpr int ROLES = (GROUPS == 2 && ((DPENV_WS_CRITIC_WAVE >> PREC) & 1)) ? 3 : 2;
     const dim3 grid((a.n + 64 * GROUPS - 1) / (64 * GROUPS));
     const size_t lds = (size_t)ws_images(PREC) * pa.nent * 16 + (size_t)2 * pa.nblk * 32 * 4 +
-                       (size_t)GROUPS * ((((PREC == PREC_F16 && ROLES == 2) || (PREC == PREC_F32_ACTOR && DPENV_WS_STAGE_ACTOR)) ? WS_GROUP_FLOATS : WS_GROUP_FLOATS_X) +
+                       (size_t)GROUPS * ((((PREC == PREC_F16 && ROLES == 2)) ? WS_GROUP_FLOATS : WS_GROUP_FLOATS_X) +
                                          (ROLES == 3 ? 64 * 9 : 0)) * 4;
     hipError_t e = hipFuncSetAttribute((const void*)policy_rollout_ws_kernel<MODE, EXT, KA, ROLES, PREC, GROUPS, RND>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

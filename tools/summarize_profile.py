@@ -100,6 +100,10 @@ try:
     out['bench_line'] = json.loads(open(src + '/bench_plain.json').read())
 except Exception as e:
     out['bench_line'] = str(e)
+try:
+    out['bench_side_records'] = json.loads(open(src + '/bench_plain_side.json').read())      # round 6: the side records are a file of their own
+except Exception:
+    pass
 # the headline kernel's duration by launch form (round 4): what the tracer does to a dependent chain depends on how it is launched
 hd = {'what': 'step_kernel duration (End - Start timestamp of rocprofv3 --kernel-trace) by launch form, beside the HIP-event SPACING of back-to-back '
               'dependent launches that bench.py reports, traced and untraced.  Three different clocks (profiles/LAB_NOTES.md, round 4): (1) the waves\' '

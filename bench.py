@@ -118,7 +118,8 @@ def hbm_roofline(kernel, bytes_per_env_step, env_steps, seconds, what, launches=
 
 def step_kernel_name(env, ves=None):
     """the instantiation dpenv_step launches for this env (dpenv_kernels.hip: step_kernel<MODE, EXT, VES, RESETW>; dpenv_dev.h MODE_*, VES_*:
-    0 kernel arguments, 1 class table in LDS, 2 per-env blocks into registers, 3 per-env blocks through an LDS image, 4 = 2 + hull re-draw)"""
+    0 kernel arguments, 1 class table in LDS, 2 per-env blocks into registers, 3 per-env blocks through an LDS image, 4 = 2 + hull / current re-draw
+    + the table's thrust loss, 5 = 0 + the single class's thrust-loss coefficients as kernel arguments)"""
     mode = {'full': 0, 'simple': 1, 'limited': 2, 'final': 4 if env.cont_ang else 3}[env.variant]
     if ves is None:
         ves = 1 if env.n_classes > 1 else 0
@@ -708,16 +709,21 @@ def classes_record(args, dev, n, with_classes=True):
     del env
     # config-2 workload (termination + auto-reset on): shared hull / per-env blocks / per-env blocks re-drawn at every reset
     rnd = {}
-    for tag in ('shared_default', 'per_env', 'per_env_randomised', 'thrust_loss_preset'):
-        env = ml4ca_amd.BatchedRevoltEnv(n, device=dev, terminate=True, auto_reset=True, seed=1,
+    for tag in ('shared_default', 'per_env', 'per_env_randomised', 'thrust_loss_preset', 'thrust_loss_per_env', 'current_randomised'):
+        env = ml4ca_amd.BatchedRevoltEnv(n, device=dev, terminate=True, auto_reset=True, seed=1, current=tag == 'current_randomised',
                                          vessel_params=ml4ca_amd.default_vessel('thrust_loss') if tag == 'thrust_loss_preset' else None)
         if tag == 'per_env':
             env.set_vessel_params(hulls)
         if tag == 'per_env_randomised':
             env.set_vessel_randomisation(0.15)
+        if tag == 'thrust_loss_per_env':                 # round 5's form of the preset: the same hull in every env's block (the A/B of the shared-loss kernels)
+            env.set_vessel_params(ml4ca_amd.default_vessel('thrust_loss'))
+        if tag == 'current_randomised':                  # every reset draws the new episode's current (0.2 +- 0.1 m/s, 135 +- 45 deg)
+            env.set_current(torch.full((n,), 0.2, device=dev), torch.full((n,), 2.356, device=dev))
+            env.set_current_randomisation(0.1, 0.785)
         env.reset()
         sec = time_steps(env, reps=20)
-        rnd[tag] = {'step_us': sec * 1e6, 'kernel': step_kernel_name(env, {'shared_default': 0, 'per_env': 2, 'per_env_randomised': 4, 'thrust_loss_preset': 4}[tag])}
+        rnd[tag] = {'step_us': sec * 1e6, 'kernel': step_kernel_name(env, {'shared_default': 0, 'per_env': 2, 'per_env_randomised': 4, 'thrust_loss_preset': 5, 'thrust_loss_per_env': 4, 'current_randomised': 4}[tag])}
         for prec in ('f16',):
             ac.upload(env, precision=prec)
             out = policy_rollout(env, CHUNK, sample=True)
@@ -732,8 +738,11 @@ def classes_record(args, dev, n, with_classes=True):
     per_env['config2_workload'] = dict(rnd, what='terminate + auto_reset on (the training workload): dpenv_step with its reset wave, and the f16 closed loop; '
                                                  'per_env_randomised = dpenv_set_vessel_randomisation(0.15): every reset draws the new episode\'s hull '
                                                  '(four Philox blocks) - in the reset wave of dpenv_step, in a separate instantiation of the closed-loop kernel; '
-                                                 'thrust_loss_preset = dpenv_default_vessel_ex(THRUST_LOSS) as the hull of every env: an inflow thrust loss '
-                                                 'F = K n|n| - Kl |n| u_a, carried by that same general per-env instantiation (32 B more per env-step)')
+                                                 'thrust_loss_preset = dpenv_default_vessel_ex(THRUST_LOSS) as the ONE class of the handle: an inflow thrust loss '
+                                                 'F = K n|n| - Kl |n| u_a with hull and coefficients as kernel arguments (round 6: step_kernel<.., 5, ..>, the closed '
+                                                 'loop\'s SLOSS instantiation) - the default\'s memory traffic; thrust_loss_per_env = round 5\'s form of it (the same '
+                                                 'hull in every env\'s block, the general per-env kernels: 160 B more per env-step); current_randomised = '
+                                                 'dpenv_set_current_randomisation: every reset draws the episode\'s current (general per-env kernels)')
     rec['per_env'] = per_env
     return rec
 

@@ -166,7 +166,7 @@ int main(int argc, char** argv)
     cfg.max_ep_len = 8;
     cfg.seed = 11;
     h = NULL;
-    CHECK(dpenv_create(&cfg, preset, 1, &h));                                  /* one class WITH loss coefficients: installed as per-env blocks */
+    CHECK(dpenv_create(&cfg, preset, 1, &h));                                  /* one class WITH loss coefficients: hull and coefficients as kernel arguments */
     float *tab, *act3, *obs3, *rew3;
     uint8_t* done3;
     const size_t nt = (size_t)DPENV_NPARAM * n3;
@@ -191,7 +191,24 @@ int main(int argc, char** argv)
             htab[(size_t)p * n3 + i] = preset[p] * (1.0f + 0.2f * ((float)(s >> 8) / 16777216.0f - 0.5f));
         }
     hipMemcpy(tab, htab, 4 * nt, hipMemcpyHostToDevice);
-    CHECK(dpenv_set_vessel_params(h, tab, stream));                             /* (synchronises: it learns whether any env carries a loss coefficient) */
+    /* the error path: a refused call (unknown flag bits; KEEP_RANDOMISATION with no randomisation in force) returns DPENV_EINVAL with a message and
+     * leaves the handle as it was - the preset's thrust loss stays in force (tests/test_gpu_round6.py checks the rows) */
+    int refused = dpenv_set_vessel_params_ex(h, tab, 0x80u, stream) == DPENV_EINVAL && strstr(dpenv_last_error(h), "unknown flag") != NULL &&
+                  dpenv_set_vessel_params_ex(h, tab, DPENV_VESSEL_KEEP_RANDOMISATION, stream) == DPENV_EINVAL &&
+                  strstr(dpenv_last_error(h), "KEEP_RANDOMISATION") != NULL;
+    CHECK(dpenv_get_vessel_params(h, tab, stream));                             /* still the preset, every env */
+    hipStreamSynchronize(stream);
+    hipMemcpy(htab, tab, 4 * nt, hipMemcpyDeviceToHost);
+    for (int p = 0; p < DPENV_NPARAM; ++p)
+        for (int i = 0; i < n3; ++i) refused = refused && htab[(size_t)p * n3 + i] == preset[p];
+    s = 4711u;
+    for (int p = 0; p < DPENV_NPARAM; ++p)
+        for (int i = 0; i < n3; ++i) {
+            s = s * 1664525u + 1013904223u;
+            htab[(size_t)p * n3 + i] = preset[p] * (1.0f + 0.2f * ((float)(s >> 8) / 16777216.0f - 0.5f));
+        }
+    hipMemcpy(tab, htab, 4 * nt, hipMemcpyHostToDevice);
+    CHECK(dpenv_set_vessel_params(h, tab, stream));                             /* stream-ordered: no read-back (the kernels learn on the device whether any env carries a loss) */
     float* hact3 = (float*)malloc(4 * (size_t)n3 * ad);
     float* hobs3 = (float*)malloc(4 * (size_t)n3 * od);
     float* hrew3 = (float*)malloc(4 * (size_t)n3);
@@ -224,9 +241,9 @@ int main(int argc, char** argv)
         for (size_t i = 0; i < nt; ++i) tsum += htab[i];
         sums[phase][0] = osum; sums[phase][1] = rsum; sums[phase][2] = tsum;
     }
-    printf("c_abi_demo vessels: %d envs x %d steps on the thrust-loss preset; preset read back %s; per-env blocks: checksums obs %.17g rew %.17g table %.17g; "
-           "randomised: obs %.17g rew %.17g table %.17g\n", n3, S3, same ? "exactly" : "DIFFERENT", sums[0][0], sums[0][1], sums[0][2], sums[1][0], sums[1][1],
-           sums[1][2]);
+    printf("c_abi_demo vessels: %d envs x %d steps on the thrust-loss preset; preset read back %s; refused calls %s; per-env blocks: checksums obs %.17g rew %.17g table %.17g; "
+           "randomised: obs %.17g rew %.17g table %.17g\n", n3, S3, same ? "exactly" : "DIFFERENT", refused ? "left the handle alone" : "CHANGED THE HANDLE", sums[0][0],
+           sums[0][1], sums[0][2], sums[1][0], sums[1][1], sums[1][2]);
     CHECK(dpenv_destroy(h));
-    return same ? 0 : 3;
+    return same && refused ? 0 : 3;
 }

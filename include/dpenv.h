@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DPENV_ABI_VERSION 4
+#define DPENV_ABI_VERSION 5
 
 typedef struct dpenv_s* dpenv_handle;
 typedef void* dpenv_stream; /* hipStream_t; NULL = the null stream */
@@ -167,8 +167,11 @@ int dpenv_obs_dim(const dpenv_config* cfg);
 
 /* Create an environment batch.  vessel_params: host float[n_classes][DPENV_NPARAM], NULL = one
  * default class.  With n_classes > 1 call dpenv_set_vessel_class to assign envs to classes.
- * A single class with thrust-loss coefficients is installed as per-env blocks (every env the same block; dpenv_get_vessel_params works,
- * dpenv_set_vessel_params(h, NULL, s) returns to the class WITHOUT its loss); classes with them are refused. */
+ * A single class with thrust-loss coefficients (dpenv_default_vessel_ex(DPENV_VESSEL_THRUST_LOSS, ...)) runs on kernels that take hull AND
+ * coefficients from their arguments - dpenv_step, dpenv_rollout, and dpenv_policy_rollout's two-wave form in the shipped configuration (final
+ * variant, continuous angles, extended state, leaky-relu): the traffic of the default hull; the other closed-loop forms read that hull from a
+ * per-env image (every env the same block).  dpenv_get_vessel_params works; dpenv_set_vessel_params(h, NULL, s) returns to this class WITH
+ * its loss.  Classes (n_classes > 1) with coefficients are refused. */
 int dpenv_create(const dpenv_config* cfg, const float* vessel_params, int32_t n_classes, dpenv_handle* out);
 int dpenv_destroy(dpenv_handle h);
 /* Message of the last failure on this handle (h == NULL: last failure of dpenv_create in this thread). */
@@ -189,11 +192,20 @@ int dpenv_set_vessel_class(dpenv_handle h, const int32_t* class_id, dpenv_stream
  * streams (+ two for the thrust-loss coefficients).  dpenv_step then reads 128 B more per env-step (SURVEY 8d accounts 108 B: 285 B per
  * env-step); the T-step kernels (dpenv_rollout, dpenv_policy_rollout) load the block once per launch.  A block that is not a vessel (mass
  * matrix not positive definite, non-finite entry, negative loss coefficient) is not rejected here: that env reports DPENV_DONE_FAULT at
- * its first step.  If ANY env has a thrust-loss coefficient the general per-env kernels run from here on (they read 32 B more per
- * env-step and apply the loss; envs without a coefficient get the rows of the plain per-env kernels bit for bit) - the one word this
- * setter reads back: it SYNCHRONISES the stream (do not call it inside a stream capture).
+ * its first step.  If ANY env has a thrust-loss coefficient the general per-env kernels apply it (they read 32 B more per env-step; envs
+ * without a coefficient get the rows of the plain per-env kernels bit for bit).  Whether any env has one is a word the packing kernel leaves
+ * behind the table: the setter does NOT wait for it - it is stream-ordered and may be recorded into a HIP graph.  Outside a capture the word
+ * also travels to the host behind an event and the next launch on this handle takes it from there (waiting for that one event if need be);
+ * a launch that is itself being recorded, and every launch after a RECORDED setter, runs the general kernels, which read the word on the
+ * device.  A refused call (bad flags, a HIP error) leaves the handle's switches - per-env blocks, randomisation, thrust loss - as they were.
  * params == NULL: back to the vessel classes / the single class of dpenv_create (the shared-default fast path: parameters in SGPRs).
- * Switching between the paths voids HIP graphs captured before (the table's address is a kernel argument). */
+ * Switching between the paths voids HIP graphs captured before (the table's address is a kernel argument).
+ * flags (dpenv_set_vessel_params_ex): DPENV_VESSEL_KEEP_RANDOMISATION - the table is installed while the domain randomisation STAYS in force
+ * (dpenv_set_vessel_randomisation must have been called): the restore path of a checkpoint taken mid-episode - fresh handle, same config;
+ * dpenv_set_vessel_randomisation(nominal, range); dpenv_set_vessel_params_ex(saved table, KEEP); dpenv_set_state(saved state, counters) - the
+ * run continues bit for bit, hulls re-drawn at every later reset.  dpenv_set_vessel_params(h, p, s) = _ex(h, p, 0, s): ends the re-draws. */
+enum { DPENV_VESSEL_KEEP_RANDOMISATION = 1 };
+int dpenv_set_vessel_params_ex(dpenv_handle h, const float* params, uint32_t flags, dpenv_stream s);
 int dpenv_set_vessel_params(dpenv_handle h, const float* params, dpenv_stream s);
 /* The parameter vectors in force: DEVICE float[DPENV_NPARAM][n_envs].  Needs per-env blocks in force. */
 int dpenv_get_vessel_params(dpenv_handle h, float* params_out, dpenv_stream s);
@@ -204,7 +216,7 @@ int dpenv_get_vessel_params(dpenv_handle h, float* params_out, dpenv_stream s);
  * 16-bit half (q & 1) of word (q & 7) >> 1 of block q >> 3, q = its slot in the order m11 m22 m23 m33 Xu (0..4) | Xuu Yv Yvv Yr Nv Nr Nrr
  * Nuv (8..15) | Yur Kf[3] Kr[3] lx_bow (16..23) | lx_port lx_star ly[3] Klf[3] (24..31), Klr[3] (5..7); u = h / 32768 - 1: a function of the env and of
  * its episode like the pose sample, so hulls do not depend on the rank count or on the launch form, and a checkpoint (dpenv_get_state
- * counters + dpenv_get_vessel_params) restores them.  nominal: HOST float[DPENV_NPARAM], NULL = class 0 of dpenv_create; rel_range:
+ * counters + dpenv_get_vessel_params) restores them through dpenv_set_vessel_params_ex(..., DPENV_VESSEL_KEEP_RANDOMISATION).  nominal: HOST float[DPENV_NPARAM], NULL = class 0 of dpenv_create; rel_range:
  * HOST float[DPENV_NPARAM], entries in [0, 1), 0 = that parameter is not randomised; every hull of the range must have a positive
  * definite mass matrix (checked).  Until its first reset an env runs on the nominal hull.  Implies per-env blocks;
  * rel_range == NULL stops the re-draws (the hulls in force stay); dpenv_set_vessel_params(h, NULL / table, s) ends it as well.
@@ -215,8 +227,25 @@ int dpenv_set_vessel_randomisation(dpenv_handle h, const float* nominal, const f
 int dpenv_set_current(dpenv_handle h, const float* vc, const float* beta, dpenv_stream s);
 /* Only the PRESENT values (the drift's state), leaving the means alone: restores what dpenv_get_current returned (checkpoints). */
 int dpenv_set_current_present(dpenv_handle h, const float* vc, const float* beta, dpenv_stream s);
-/* present current of every env (differs from the set values only with current_drift) */
+/* present current of every env (differs from the set values only with current_drift / the per-episode randomisation) */
 int dpenv_get_current(dpenv_handle h, float* vc_out, float* beta_out, dpenv_stream s);
+/* the means the drift reverts to (= the values given to dpenv_set_current until a randomised reset re-draws them): with dpenv_get_current the
+ * current's part of a checkpoint - restore with dpenv_set_current(means) followed by dpenv_set_current_present(present values) */
+int dpenv_get_current_mean(dpenv_handle h, float* vc_out, float* beta_out, dpenv_stream s);
+/* Per-episode randomisation of the current through the reset path (config 5 widened; the reference's one operating point is 0.2 m/s towards
+ * 135 deg, results/all_plots/current_box_test/plot_pos.py:78): from this call on EVERY reset of an env - dpenv_reset (also with explicit
+ * init), auto-reset inside dpenv_step / dpenv_rollout / dpenv_policy_rollout, reset_at_end - starts the new episode in a freshly drawn current
+ *   V_c = max(0, vc_nominal[i] + vc_range * u1),   beta_c = beta_nominal[i] + beta_range * u2,   u1, u2 uniform in [-1, 1) (24 bits),
+ * words 0 and 1 of Philox4x32-10 keyed by config.seed with counter (global env id, episode counter, tag 3): a function of the env and of
+ * its episode like the pose sample and the hull draw - independent of the rank count and of the launch form.  The drawn values become the
+ * present current AND the mean the drift (config.current_drift) reverts to.  vc_nominal, beta_nominal: DEVICE float[n_envs], copied; NULL =
+ * the means in force (what dpenv_set_current gave).  Until its first reset an env keeps the current it has.  Needs config.current_enabled.
+ * The re-draw lives where the hull re-draw lives, in the general per-env kernels: without per-env blocks in force the single class is
+ * installed as per-env blocks (every env the same one; +160 B read per env-step of dpenv_step), vessel classes are refused; dpenv_set_vessel_
+ * params(h, NULL, s) is refused while it is on.  Both ranges 0: off (currents stay as they are).  Like the hull randomisation, a dpenv_reset
+ * with explicit init then advances the episode counter too.  Stream-ordered, may be recorded into a graph. */
+int dpenv_set_current_randomisation(dpenv_handle h, const float* vc_nominal, const float* beta_nominal, float vc_range, float beta_range,
+                                    dpenv_stream s);
 
 /* Revolt.reset (customEnv.py:135-194) for the envs selected by mask (device uint8[n], NULL = all).
  * init: device float[6][n] = N, E, psi, u, v, r (the **init override, customEnv.py:141,152), NULL =

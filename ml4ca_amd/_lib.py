@@ -20,7 +20,8 @@ POLICY_F16, POLICY_F32, POLICY_F32_ACTOR = 0, 1, 2
 LAUNCH_AUTO, LAUNCH_ONE_WAVE, LAUNCH_TWO_WAVE = 0, 1, 2
 DONE_TERMINAL, DONE_TIMELIMIT, DONE_FAULT = 1, 2, 4
 NSTATE, NPARAM, NPARAM_USED, MAX_CLASSES = 15, 32, 32, 64
-ABI_VERSION = 4
+ABI_VERSION = 5
+VESSEL_KEEP_RANDOMISATION = 1          # dpenv_set_vessel_params_ex flag
 
 # canonical state rows (dpenv.h DPENV_S_*)
 S = dict(N=0, E=1, PSI=2, U=3, V=4, R=5, REF_N=6, REF_E=7, REF_PSI=8,
@@ -88,11 +89,14 @@ SYMBOLS = {
     'dpenv_set_reset_fraction': (C.c_int, [_VP, _F]),
     'dpenv_set_vessel_class': (C.c_int, [_VP, _VP, _VP]),
     'dpenv_set_vessel_params': (C.c_int, [_VP, _VP, _VP]),
+    'dpenv_set_vessel_params_ex': (C.c_int, [_VP, _VP, C.c_uint32, _VP]),
     'dpenv_get_vessel_params': (C.c_int, [_VP, _VP, _VP]),
     'dpenv_set_vessel_randomisation': (C.c_int, [_VP, C.POINTER(C.c_float), C.POINTER(C.c_float), _VP]),
     'dpenv_set_current': (C.c_int, [_VP, _VP, _VP, _VP]),
     'dpenv_set_current_present': (C.c_int, [_VP, _VP, _VP, _VP]),
     'dpenv_get_current': (C.c_int, [_VP, _VP, _VP, _VP]),
+    'dpenv_get_current_mean': (C.c_int, [_VP, _VP, _VP, _VP]),
+    'dpenv_set_current_randomisation': (C.c_int, [_VP, _VP, _VP, _F, _F, _VP]),
     'dpenv_reset': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
     'dpenv_step': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     'dpenv_step_ex': (C.c_int, [_VP, C.POINTER(StepIO), _VP]),

@@ -33,8 +33,19 @@ struct dpenv_s {
     int32_t* class_id;
     float4* env_tab;        // per-env parameter blocks + thrust-loss rows ET[DRAW_GROUPS][env_stride] (dpenv_dev.h), always allocated
     int env_stride;
-    uint32_t* loss_flag;    // device word the packing kernel reports "some env has a thrust-loss coefficient" through
-    bool loss_on;           // ... read back: the kernels of the general per-env form apply the loss (StepArgs.loss_on)
+    uint32_t* loss_flag;    // device word BEHIND the table (ET[DRAW_GROUPS][stride] | flag): the packing kernel reports "some env has a thrust-loss
+                            //   coefficient" through it, and the general per-env kernels read it themselves while the host does not know (LOSS_DEVICE)
+    int loss_state;         // LOSS_OFF / LOSS_ON / LOSS_DEVICE -> StepArgs.loss_on (per-env blocks in force only)
+    bool loss_pending;      // the flag word is on its way to loss_host behind loss_ev: resolved (without blocking a capture) by the next launch
+    hipEvent_t loss_ev;
+    uint32_t* loss_host;    // pinned host word
+    bool rand_loss;         // the randomisation's nominal hull has a thrust-loss coefficient (then every drawn hull has one)
+    bool shared_loss;       // the SINGLE class of dpenv_create has thrust-loss coefficients: kernels with the shared-loss instantiation take them from
+                            //   the arguments (StepArgs.kl, VES_ARGS_LOSS); for the others env_tab holds that hull for every env while no
+                            //   per-env table is in force (repacked from raw0_dev when the caller returns to the class)
+    float* raw0_dev;        // device copy of raw0
+    bool cur_rand;          // per-episode randomisation of the current (dpenv_set_current_randomisation): needs per-env blocks in force
+    float* cur_nom;         // device float[2][env_stride]: nominal V_c | beta_c of every env
     float* rand_tab;        // device float[RAND_TAB_FLOATS]: nominal | relative half-range of the domain randomisation
     float rand_host[RAND_TAB_FLOATS];   // its host image (the source of the stream-ordered upload must outlive the call)
     float raw0[DPENV_NPARAM];           // public parameter vector of class 0 (the randomisation's default nominal hull)
@@ -64,6 +75,8 @@ struct dpenv_s {
     int device;
     std::string err;
 };
+
+enum { LOSS_OFF = 0, LOSS_ON = 1, LOSS_DEVICE = 2 };
 
 static thread_local std::string g_create_err;
 
@@ -287,7 +300,13 @@ extern "C" int dpenv_create(const dpenv_config* cfg, const float* vessel_params,
     h->classes_assigned = false;
     h->per_env = false;
     h->randomise = false;
-    h->loss_on = false;
+    h->loss_state = LOSS_OFF;
+    h->loss_pending = false;
+    h->loss_ev = nullptr;
+    h->loss_host = nullptr;
+    h->rand_loss = false;
+    h->shared_loss = false;
+    h->cur_rand = false;
     h->current_set = false;
     h->pol_buf = nullptr; h->pol_buf_bytes = 0;
     h->pol_slot = 0;
@@ -337,8 +356,9 @@ extern "C" int dpenv_create(const dpenv_config* cfg, const float* vessel_params,
     const size_t o_s3 = off; off += npad * 16;
     const size_t o_ct = off; off += align_up(sizeof(VesselDev) * MAX_CLASSES, 256);
     const size_t o_rt = off; off += align_up(sizeof(float) * RAND_TAB_FLOATS, 256);
-    const size_t o_lf = off; off += 256;
-    const size_t o_et = off; off += npad * 16 * DRAW_GROUPS;
+    const size_t o_r0 = off; off += 256;                                 // raw0_dev
+    const size_t o_cn = off; off += npad * 4 * 2;                        // cur_nom
+    const size_t o_et = off; off += npad * 16 * DRAW_GROUPS + 256;      // the per-env table and, behind it, its thrust-loss flag word
     h->blob_bytes = off;
     void* blob = nullptr;
     e = hipMalloc(&blob, off);
@@ -348,9 +368,20 @@ extern "C" int dpenv_create(const dpenv_config* cfg, const float* vessel_params,
     }
     h->blob = (float*)blob;
     char* b = (char*)blob;
+    e = hipEventCreateWithFlags(&h->loss_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&h->loss_host, sizeof(uint32_t), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        if (h->loss_ev) (void)hipEventDestroy(h->loss_ev);
+        (void)hipFree(blob);
+        delete h;
+        return fail(nullptr, DPENV_EHIP, "event / pinned word of the per-env table's flag: %s", hipGetErrorString(e));
+    }
+    *h->loss_host = 0u;
     e = hipMemset(blob, 0, off);
     if (e == hipSuccess) e = hipMemcpy(b + o_ct, tab, sizeof(VesselDev) * n_classes, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
+        (void)hipEventDestroy(h->loss_ev);
+        (void)hipHostFree(h->loss_host);
         (void)hipFree(blob);
         delete h;
         return fail(nullptr, DPENV_EHIP, "state initialisation failed: %s", hipGetErrorString(e));
@@ -368,7 +399,9 @@ extern "C" int dpenv_create(const dpenv_config* cfg, const float* vessel_params,
     h->env_tab = (float4*)(b + o_et);
     h->env_stride = (int)npad;
     h->rand_tab = (float*)(b + o_rt);
-    h->loss_flag = (uint32_t*)(b + o_lf);
+    h->raw0_dev = (float*)(b + o_r0);
+    h->cur_nom = (float*)(b + o_cn);
+    h->loss_flag = (uint32_t*)(b + o_et + npad * 16 * DRAW_GROUPS);     // = env_tab + DRAW_GROUPS * env_stride: where thrust_loss_on() looks (dpenv_env_dev.h)
     a.class_tab = (const float*)(b + o_ct);
     a.n_classes = n_classes;
     a.v0 = tab[0];
@@ -399,22 +432,28 @@ extern "C" int dpenv_create(const dpenv_config* cfg, const float* vessel_params,
     a.noise_ctr = h->noise_ctr;
     a.S3 = (float4*)(b + o_s3);
     {
-        // a single class WITH thrust-loss coefficients: only the general per-env kernels carry the loss code (dpenv_dev.h), so the hull is
-        // installed as per-env blocks, every env the same one (dpenv_set_vessel_params(h, NULL) would return to the class without its loss)
+        // a single class WITH thrust-loss coefficients (the thrust-loss preset): the step / fused-rollout kernels and the two-wave closed loop of
+        // the shipped configuration have an instantiation that takes hull AND coefficients from the kernel arguments (VES_ARGS_LOSS, round 6);
+        // the remaining kernels (one-wave closed loop, other env variants' two-wave forms) carry the loss code in their general per-env form
+        // only - for them the table holds this hull for every env
         bool any = false;
-        for (int p = DPENV_P_KLF_BOW; p <= DPENV_P_KLR_STAR; ++p) any = any || h->raw0[p] != 0.0f;
-        if (any) {
-            e = hipMemcpy(h->rand_tab, h->raw0, sizeof h->raw0, hipMemcpyHostToDevice);     // (the nominal half of the randomisation's table: its default)
-            if (e == hipSuccess) e = dpenv_dev_launch_pack_env_vessels(h->rand_tab, 1, 0, h->env_tab, nullptr, h->env_stride, cfg->n_envs, nullptr);
-            if (e == hipSuccess) e = hipDeviceSynchronize();
-            if (e != hipSuccess) {
-                (void)hipFree(blob);
-                delete h;
-                return fail(nullptr, DPENV_EHIP, "per-env blocks of the thrust-loss hull: %s", hipGetErrorString(e));
-            }
-            h->per_env = true;
-            h->loss_on = true;
+        for (int p = 0; p < 3; ++p) {
+            a.kl[p] = h->raw0[DPENV_P_KLF_BOW + p]; a.kl[3 + p] = h->raw0[DPENV_P_KLR_BOW + p];
+            any = any || a.kl[p] != 0.0f || a.kl[3 + p] != 0.0f;
         }
+        e = hipMemcpy(h->raw0_dev, h->raw0, sizeof h->raw0, hipMemcpyHostToDevice);
+        if (e == hipSuccess && any) {
+            e = dpenv_dev_launch_pack_env_vessels(h->raw0_dev, 1, 0, h->env_tab, nullptr, h->env_stride, cfg->n_envs, nullptr);
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+        }
+        if (e != hipSuccess) {
+            (void)hipEventDestroy(h->loss_ev);
+            (void)hipHostFree(h->loss_host);
+            (void)hipFree(blob);
+            delete h;
+            return fail(nullptr, DPENV_EHIP, "the class hull's device copy / per-env image: %s", hipGetErrorString(e));
+        }
+        h->shared_loss = any && n_classes == 1;
     }
     *out = h;
     return DPENV_OK;
@@ -428,6 +467,8 @@ extern "C" int dpenv_destroy(dpenv_handle h)
     if (h->pol_buf) (void)hipFree(h->pol_buf);
     if (h->pol_raw) (void)hipFree(h->pol_raw);
     for (int k = 0; k < 2; ++k) if (h->pol_read[k]) (void)hipEventDestroy(h->pol_read[k]);
+    if (h->loss_ev) (void)hipEventDestroy(h->loss_ev);
+    if (h->loss_host) (void)hipHostFree(h->loss_host);
     delete h;
     return DPENV_OK;
 }
@@ -489,7 +530,72 @@ extern "C" int dpenv_get_current(dpenv_handle h, float* vc_out, float* beta_out,
     return DPENV_OK;
 }
 
-static void bind_optional(dpenv_handle h, StepArgs& a)
+extern "C" int dpenv_get_current_mean(dpenv_handle h, float* vc_out, float* beta_out, dpenv_stream s)
+{
+    if (!h || !vc_out || !beta_out) return fail(h, DPENV_EINVAL, "dpenv_get_current_mean: NULL argument");
+    DeviceGuard dev_guard(h->device);
+    if (!h->cfg.current_enabled) return fail(h, DPENV_EINVAL, "config.current_enabled is 0");
+    const size_t bytes = sizeof(float) * (size_t)h->cfg.n_envs;
+    HIP_TRY(h, hipMemcpyAsync(vc_out, h->cur_vc0, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
+    HIP_TRY(h, hipMemcpyAsync(beta_out, h->cur_beta0, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
+    return DPENV_OK;
+}
+
+extern "C" int dpenv_set_current_randomisation(dpenv_handle h, const float* vc_nominal, const float* beta_nominal, float vc_range,
+                                               float beta_range, dpenv_stream s)
+{
+    if (!h) return DPENV_EINVAL;
+    DeviceGuard dev_guard(h->device);
+    if (!h->cfg.current_enabled) return fail(h, DPENV_EINVAL, "config.current_enabled is 0");
+    if (!(vc_range >= 0.0f) || !(beta_range >= 0.0f) || !std::isfinite(vc_range) || !std::isfinite(beta_range))
+        return fail(h, DPENV_EINVAL, "the half-ranges must be finite and >= 0");
+    if (vc_range == 0.0f && beta_range == 0.0f) {             // off: every env keeps the current (and the drift mean) it has
+        h->cur_rand = false;
+        h->args.cur_range_v = h->args.cur_range_b = 0.0f;
+        return DPENV_OK;
+    }
+    if (!h->per_env && h->n_classes > 1)
+        return fail(h, DPENV_EINVAL, "the re-draw lives in the per-env kernels: with vessel classes give every env its block first (dpenv_set_vessel_params)");
+    const size_t bytes = sizeof(float) * (size_t)h->cfg.n_envs;
+    // NULL: the means in force - unless the randomisation is already on (then the means are drawn values: the nominals stay what they are)
+    if (vc_nominal || !h->cur_rand)
+        HIP_TRY(h, hipMemcpyAsync(h->cur_nom, vc_nominal ? vc_nominal : h->cur_vc0, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
+    if (beta_nominal || !h->cur_rand)
+        HIP_TRY(h, hipMemcpyAsync(h->cur_nom + h->env_stride, beta_nominal ? beta_nominal : h->cur_beta0, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
+    if (!h->per_env) {
+        // the single class as per-env blocks, every env the same one (with its thrust-loss coefficients, if it has any)
+        HIP_TRY(h, dpenv_dev_launch_pack_env_vessels(h->raw0_dev, 1, 0, h->env_tab, nullptr, h->env_stride, h->cfg.n_envs, (hipStream_t)s));
+        h->per_env = true;
+        h->randomise = false;
+        h->loss_pending = false;
+        h->loss_state = h->shared_loss ? LOSS_ON : LOSS_OFF;
+    }
+    h->cur_rand = true;
+    h->args.cur_range_v = vc_range;
+    h->args.cur_range_b = beta_range;
+    return DPENV_OK;
+}
+
+// The packing kernel's flag word is on its way to the host (dpenv_set_vessel_params): take it if it has arrived; wait for it unless the launch
+// that asks is being RECORDED into a graph - a recorded launch (and every launch after a setter that was itself recorded) leaves the
+// question to the kernel, which reads the word where the packing kernel left it (StepArgs.loss_on == 2; thrust_loss_on, dpenv_env_dev.h)
+static void resolve_loss(dpenv_handle h, hipStream_t s)
+{
+    if (!h->loss_pending) return;
+    hipError_t q = hipEventQuery(h->loss_ev);
+    if (q == hipErrorNotReady) {
+        (void)hipGetLastError();                                        // (not an error: the launch below must not report it)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s, &cap);
+        if (cap != hipStreamCaptureStatusNone) return;
+        q = hipEventSynchronize(h->loss_ev);
+    }
+    if (q != hipSuccess) { (void)hipGetLastError(); return; }            // the device-side reading stays in force
+    h->loss_state = *(volatile uint32_t*)h->loss_host != 0u ? LOSS_ON : LOSS_OFF;
+    h->loss_pending = false;
+}
+
+static void bind_optional(dpenv_handle h, StepArgs& a, hipStream_t s)
 {
     // current_enabled without dpenv_set_current = zero current (the block is zero-initialised)
     a.cur_vc = h->cfg.current_enabled ? h->cur_vc : nullptr;
@@ -498,55 +604,92 @@ static void bind_optional(dpenv_handle h, StepArgs& a)
     a.cur_beta0 = h->cur_beta0;
     a.drift_ctr = h->drift_ctr;
     a.class_id = h->class_id;
+    resolve_loss(h, s);
     a.env_tab = h->per_env ? h->env_tab : nullptr;
     a.env_stride = h->env_stride;
-    a.loss_on = (h->per_env && h->loss_on) ? 1 : 0;
+    a.loss_on = h->per_env ? h->loss_state : (h->shared_loss ? (int)LOSS_SHARED : (int)LOSS_NONE);
     a.rand_tab = (h->per_env && h->randomise) ? h->rand_tab : nullptr;
+    const bool cr = h->per_env && h->cur_rand && h->cfg.current_enabled;
+    a.cur_nom = cr ? h->cur_nom : nullptr;
+    a.cur_nom_stride = h->env_stride;
 }
 
-// where the kernels take a lane's vessel from (dpenv_dev.h VES_*)
+// a kernel without a shared-loss instantiation on a handle whose single class has thrust-loss coefficients: its general per-env form, on the
+// table image of that hull (every env the same block)
+static void bind_shared_loss_as_table(dpenv_handle h, StepArgs& a)
+{
+    if (a.loss_on != LOSS_SHARED) return;
+    a.env_tab = h->env_tab;
+    a.loss_on = LOSS_TABLE;
+}
+
+// where the kernels take a lane's vessel from (dpenv_dev.h VES_*); call after bind_optional (which settles loss_state)
 static int vessel_source(dpenv_handle h)
 {
-    if (h->per_env) return (h->randomise || h->loss_on) ? VES_ENV_RND : (h->cfg.per_env_lds ? VES_ENV_LDS : VES_ENV_VGPR);
-    return h->n_classes > 1 ? VES_CLASS_LDS : VES_ARGS;
+    if (h->per_env)
+        return (h->randomise || h->loss_state != LOSS_OFF || (h->cur_rand && h->cfg.current_enabled)) ? VES_ENV_RND
+               : (h->cfg.per_env_lds ? VES_ENV_LDS : VES_ENV_VGPR);
+    return h->n_classes > 1 ? VES_CLASS_LDS : (h->shared_loss ? VES_ARGS_LOSS : VES_ARGS);
 }
 
 static bool classes_missing(dpenv_handle h) { return !h->per_env && h->n_classes > 1 && !h->classes_assigned; }
 
 // ---- per-env parameter blocks ------------------------------------------------------------------------------------------------
-extern "C" int dpenv_set_vessel_params(dpenv_handle h, const float* params, dpenv_stream s)
+extern "C" int dpenv_set_vessel_params_ex(dpenv_handle h, const float* params, uint32_t flags, dpenv_stream s)
 {
     if (!h) return DPENV_EINVAL;
     DeviceGuard dev_guard(h->device);
-    h->randomise = false;
-    h->loss_on = false;
+    // everything that can refuse the call comes first; the handle's switches (per_env, randomise, loss_state) change only after the last
+    // call that can fail (ADVICE / VERDICT r05: a refused call used to leave the thrust loss and the re-draws silently off)
+    if (flags & ~(uint32_t)DPENV_VESSEL_KEEP_RANDOMISATION) return fail(h, DPENV_EINVAL, "dpenv_set_vessel_params_ex: unknown flag bits 0x%x", flags);
+    const bool keep = (flags & DPENV_VESSEL_KEEP_RANDOMISATION) != 0;
+    if (keep && (!params || !h->randomise))
+        return fail(h, DPENV_EINVAL, "DPENV_VESSEL_KEEP_RANDOMISATION needs a table and the randomisation in force (dpenv_set_vessel_randomisation first)");
     if (!params) {
-        h->per_env = false;               // back to the classes / the single class (which carry no thrust loss)
-        h->loss_on = false;
+        if (h->cur_rand)
+            return fail(h, DPENV_EINVAL, "the per-episode current randomisation lives in the per-env kernels: switch it off first "
+                                         "(dpenv_set_current_randomisation with both ranges 0)");
+        // back to the classes / the single class; a single class WITH thrust-loss coefficients keeps them (kernel arguments), and the table
+        // becomes the image of that hull again for the kernels that read it there
+        if (h->shared_loss && h->per_env)
+            HIP_TRY(h, dpenv_dev_launch_pack_env_vessels(h->raw0_dev, 1, 0, h->env_tab, nullptr, h->env_stride, h->cfg.n_envs, (hipStream_t)s));
+        h->per_env = false;
+        h->randomise = false;
+        h->loss_pending = false;
+        h->loss_state = LOSS_OFF;
         return DPENV_OK;
     }
-    {
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing((hipStream_t)s, &cap);
-        if (cap != hipStreamCaptureStatusNone)      // this setter reads one word back (below): it cannot be recorded into a graph
-            return fail(h, DPENV_EINVAL, "dpenv_set_vessel_params synchronises its stream and cannot be called while the stream is being captured");
-    }
-    HIP_TRY(h, hipMemsetAsync(h->loss_flag, 0, sizeof(uint32_t), (hipStream_t)s));          // the packing kernel sets it if any env has a coefficient
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    HIP_TRY(h, hipStreamIsCapturing((hipStream_t)s, &cap));
+    // stream-ordered, no read-back: the packing kernel leaves "some env has a thrust-loss coefficient" in the word behind the table
+    HIP_TRY(h, hipMemsetAsync(h->loss_flag, 0, sizeof(uint32_t), (hipStream_t)s));
     HIP_TRY(h, dpenv_dev_launch_pack_env_vessels(params, (int64_t)h->cfg.n_envs, 1, h->env_tab, h->loss_flag, h->env_stride, h->cfg.n_envs, (hipStream_t)s));
-    // which kernels run from here on depends on whether any env has a thrust-loss coefficient (the general per-env form applies it, the
-    // plain one does not carry the code): the one word the host has to wait for - this setter synchronises the stream
-    uint32_t flag = 0;
-    HIP_TRY(h, hipMemcpyAsync(&flag, h->loss_flag, sizeof flag, hipMemcpyDeviceToHost, (hipStream_t)s));
-    HIP_TRY(h, hipStreamSynchronize((hipStream_t)s));
+    // which kernels run from here on depends on that word (the general per-env form applies the loss, the plain one does not carry the code).
+    // Outside a capture it also travels to a pinned host word behind an event: the next launch takes the answer from there (resolve_loss);
+    // recorded into a graph the setter leaves it on the device, where the general kernels read it themselves.
+    bool pending = false;
+    if (cap == hipStreamCaptureStatusNone) {
+        HIP_TRY(h, hipMemcpyAsync(h->loss_host, h->loss_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)s));
+        HIP_TRY(h, hipEventRecord(h->loss_ev, (hipStream_t)s));
+        pending = true;
+    }
     h->per_env = true;
-    h->loss_on = flag != 0u;
+    if (!keep) h->randomise = false;
+    if (h->randomise && h->rand_loss) { h->loss_state = LOSS_ON; h->loss_pending = false; }     // every drawn hull has a coefficient: nothing to ask
+    else { h->loss_state = LOSS_DEVICE; h->loss_pending = pending; }
     return DPENV_OK;
+}
+
+extern "C" int dpenv_set_vessel_params(dpenv_handle h, const float* params, dpenv_stream s)
+{
+    return dpenv_set_vessel_params_ex(h, params, 0u, s);
 }
 
 extern "C" int dpenv_get_vessel_params(dpenv_handle h, float* params_out, dpenv_stream s)
 {
     if (!h || !params_out) return fail(h, DPENV_EINVAL, "dpenv_get_vessel_params: NULL argument");
-    if (!h->per_env) return fail(h, DPENV_EINVAL, "no per-env parameter blocks in force (dpenv_set_vessel_params / dpenv_set_vessel_randomisation)");
+    if (!h->per_env && !h->shared_loss)
+        return fail(h, DPENV_EINVAL, "no per-env parameter blocks in force (dpenv_set_vessel_params / dpenv_set_vessel_randomisation)");
     DeviceGuard dev_guard(h->device);
     HIP_TRY(h, dpenv_dev_launch_unpack_env_vessels(h->env_tab, h->env_stride, params_out, h->cfg.n_envs, (hipStream_t)s));
     return DPENV_OK;
@@ -579,8 +722,10 @@ extern "C" int dpenv_set_vessel_randomisation(dpenv_handle h, const float* nomin
     HIP_TRY(h, dpenv_dev_launch_pack_env_vessels(h->rand_tab, 1, 0, h->env_tab, nullptr, h->env_stride, h->cfg.n_envs, (hipStream_t)s));
     h->per_env = true;
     h->randomise = true;
-    h->loss_on = false;                                 // a draw scales the nominal value: no coefficient there, none in any hull
-    for (int p = DPENV_P_KLF_BOW; p <= DPENV_P_KLR_STAR; ++p) h->loss_on = h->loss_on || nom[p] != 0.0f;
+    h->rand_loss = false;                               // a draw scales the nominal value: no coefficient there, none in any hull
+    for (int p = DPENV_P_KLF_BOW; p <= DPENV_P_KLR_STAR; ++p) h->rand_loss = h->rand_loss || nom[p] != 0.0f;
+    h->loss_state = h->rand_loss ? LOSS_ON : LOSS_OFF;
+    h->loss_pending = false;
     return DPENV_OK;
 }
 
@@ -590,7 +735,7 @@ extern "C" int dpenv_reset(dpenv_handle h, const uint8_t* mask, const float* ini
     if (!h) return DPENV_EINVAL;
     DeviceGuard dev_guard(h->device);
     StepArgs a = h->args;
-    bind_optional(h, a);
+    bind_optional(h, a, (hipStream_t)s);
     a.obs = obs_out;
     HIP_TRY(h, dpenv_dev_launch_reset(&a, h->mode, h->cfg.extended_state, mask, init, ref, (hipStream_t)s));
     // the reset kernel writes the lagged thrust columns (S3) of the envs it re-draws: a full reset makes them valid everywhere, a
@@ -609,7 +754,7 @@ extern "C" int dpenv_step_ex(dpenv_handle h, const dpenv_step_io* io, dpenv_stre
     if (classes_missing(h))
         return fail(h, DPENV_EINVAL, "n_classes > 1 but dpenv_set_vessel_class was never called");
     StepArgs a = h->args;
-    bind_optional(h, a);
+    bind_optional(h, a, (hipStream_t)s);
     a.action = io->action;
     a.new_ref = io->new_ref;
     a.obs = io->obs;
@@ -655,7 +800,7 @@ extern "C" int dpenv_rollout(dpenv_handle h, const dpenv_rollout_io* io, dpenv_s
     if (classes_missing(h))
         return fail(h, DPENV_EINVAL, "n_classes > 1 but dpenv_set_vessel_class was never called");
     StepArgs a = h->args;
-    bind_optional(h, a);
+    bind_optional(h, a, (hipStream_t)s);
     RolloutArgs ra;
     std::memset(&ra, 0, sizeof ra);
     ra.T = io->T; ra.actions = io->actions; ra.obs = io->obs; ra.rew = io->reward; ra.done = io->done;
@@ -967,7 +1112,7 @@ extern "C" int dpenv_policy_rollout(dpenv_handle h, const dpenv_policy_rollout_i
         if (io->switch_step[k] < 0 || io->switch_step[k] >= io->T || (k > 0 && io->switch_step[k] <= io->switch_step[k - 1]))
             return fail(h, DPENV_EINVAL, "switch_step must be strictly increasing within [0, T)");
     StepArgs a = h->args;
-    bind_optional(h, a);
+    bind_optional(h, a, (hipStream_t)s);
     PolicyArgs pa = h->pol;
     pa.T = io->T; pa.noise = io->noise; pa.obs_out = io->obs; pa.act_out = io->act; pa.rew = io->reward; pa.val = io->value;
     pa.logp = io->logp; pa.done = io->done; pa.boot = io->boot; pa.last_obs = io->last_obs; pa.last_val = io->last_value;
@@ -984,7 +1129,10 @@ extern "C" int dpenv_policy_rollout(dpenv_handle h, const dpenv_policy_rollout_i
     // the two-wave kernels carry the randomisation's hull re-draw in an instantiation of their own, built for the shipped training configuration
     // (final / continuous angles / extended state, leaky-relu or relu networks); everything else runs the one-wave kernels while the
     // randomisation is on - the same rows bit for bit, the draw a run-time switch there
-    if ((a.rand_tab || a.loss_on) && pa.ws && !(h->mode == MODE_FINAL_CONT && h->cfg.extended_state && pa.act == DPENV_ACT_LEAKY_RELU)) pa.ws = 0;
+    const bool shipped = h->mode == MODE_FINAL_CONT && h->cfg.extended_state && pa.act == DPENV_ACT_LEAKY_RELU;
+    if ((a.rand_tab || a.loss_on != LOSS_NONE || a.cur_nom) && pa.ws && !shipped) pa.ws = 0;
+    // the one-wave kernels (and only they, after the line above) know the thrust loss through the table alone
+    if (!pa.ws) bind_shared_loss_as_table(h, a);
     if (pa.split) HIP_TRY(h, dpenv_dev_launch_policy_rollout_x(&a, &pa, h->mode, h->cfg.extended_state, (hipStream_t)s));
     else HIP_TRY(h, dpenv_dev_launch_policy_rollout(&a, &pa, h->mode, h->cfg.extended_state, (hipStream_t)s));
     h->lag_valid = true;

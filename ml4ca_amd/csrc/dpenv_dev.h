@@ -61,9 +61,17 @@ enum { VES_ARGS = 0,      // one class: kernel arguments (SGPRs)
        VES_CLASS_LDS = 1, // vessel classes: [class][param] table staged into LDS as [param][class]
        VES_ENV_VGPR = 2,  // per-env blocks: eight coalesced float4 loads per lane straight into registers
        VES_ENV_LDS = 3,   // per-env blocks: LDS-DMA (global_load_lds_dwordx4) into a [group][lane] image, read back when needed (the A/B of SURVEY 7)
-       VES_ENV_RND = 4 }; // the GENERAL per-env form: VES_ENV_VGPR + the domain randomisation's hull re-draw in the reset paths (while StepArgs.rand_tab)
+       VES_ENV_RND = 4,   // the GENERAL per-env form: VES_ENV_VGPR + the domain randomisation's hull re-draw in the reset paths (while StepArgs.rand_tab)
                           //   + the inflow thrust loss (while StepArgs.loss_on).  Its own instantiation: the draw's four Philox blocks cost the register
                           //   allocation of the other forms 15-70 VGPRs when they share the code, the loss 10-16
+       VES_ARGS_LOSS = 5 }; // one class WITH thrust-loss coefficients (round 6): hull and coefficients as kernel arguments (StepArgs.v0, StepArgs.kl; SGPRs) -
+                          //   the regime the reference trains in (customEnv.py:17,26) at the default's memory traffic, not at 160 B per env-step of
+                          //   identical per-env blocks
+// StepArgs.loss_on
+enum { LOSS_NONE = 0,     // no thrust loss anywhere
+       LOSS_TABLE = 1,    // some env of the per-env table has a coefficient (the host knows)
+       LOSS_TABLE_FLAG = 2, // ask the table: the word behind it, written by pack_env_vessels_kernel (thrust_loss_on, dpenv_env_dev.h)
+       LOSS_SHARED = 3 }; // the single class's coefficients in StepArgs.kl: only kernels instantiated for it are launched with this value
 
 struct StepArgs {
     // library-owned state streams (see dpenv_kernels.hip header)
@@ -83,8 +91,8 @@ struct StepArgs {
     // optional per-env inputs owned by the library
     float* cur_vc;            // present current speed / direction (read-write with drift)
     float* cur_beta;
-    const float* cur_vc0;     // means the drift reverts to
-    const float* cur_beta0;
+    float* cur_vc0;           // means the drift reverts to (written by a reset when the current is randomised per episode)
+    float* cur_beta0;
     uint32_t* drift_ctr;      // per-env draw counter of the drift noise
     int32_t current_drift;
     float drift_a;            // dt / tau
@@ -115,9 +123,16 @@ struct StepArgs {
     float4* env_tab;          // per-env parameter blocks ET[ENV_GROUPS][env_stride], NULL = classes / the single class (written by the kernels only
                               //   when the randomisation re-draws a hull)
     int32_t env_stride;
-    int32_t loss_on;          // some env has a non-zero inflow thrust-loss coefficient (rows ENV_GROUPS.. of env_tab): the general per-env kernels apply it
+    int32_t loss_on;          // LOSS_* below the VES_ enum: whether / where from the kernels that carry the inflow thrust loss apply it
     const float* rand_tab;    // domain randomisation on: device float[RAND_TAB_FLOATS] (nominal | relative half-range); every reset - explicit,
                               //   auto, reset_at_end - re-draws the env's hull for the new episode, Philox keyed (seed; global env id, episode)
+    // ---- round 6 (appended: the fields above keep their offsets) ----
+    float kl[8];              // LOSS_SHARED: Klf bow, port, star | Klr bow, port, star of the single class (two pad)
+    const float* cur_nom;     // per-episode randomisation of the current on (dpenv_set_current_randomisation): device float[2][cur_nom_stride], the
+                              //   nominal V_c | beta_c of every env; every reset draws the new episode's current around them (current_redraw)
+    int32_t cur_nom_stride;
+    float cur_range_v;        // half-ranges of the draw: V_c [m/s], beta_c [rad]
+    float cur_range_b;
 };
 
 // fused T-step rollout (dpenv_rollout)

@@ -385,6 +385,20 @@ struct ThrustLoss {
     float u, v, r;
 };
 
+// StepArgs.loss_on (LOSS_*, dpenv_dev.h) for the kernels that read the per-env TABLE: LOSS_TABLE = the host knows that some env has a coefficient;
+// LOSS_TABLE_FLAG = ask the table: the word behind it, ET[DRAW_GROUPS][stride] | flag, where pack_env_vessels_kernel left the answer - a
+// dpenv_set_vessel_params that was recorded into a graph, or whose answer has not reached the host yet (dpenv_api.hip: resolve_loss), costs no
+// read-back this way.  Launch-uniform either way.
+__device__ __forceinline__ bool thrust_loss_on(const StepArgs& a)
+{
+    if (a.loss_on == LOSS_TABLE_FLAG) return *reinterpret_cast<const uint32_t*>(a.env_tab + (int64_t)DRAW_GROUPS * a.env_stride) != 0u;
+    return a.loss_on == LOSS_TABLE;
+}
+// `il` argument of env_step_chain / env_step: where the step's thrust-loss coefficients come from.  A compile-time constant in every kernel
+// but the one-wave closed loop (which always passes its env index and decides at run time).
+constexpr int IL_NONE = -1;        // no loss code compiled in: the kernel is what it was before the loss existed
+constexpr int IL_SHARED = -2;      // the single class's coefficients, StepArgs.kl (kernel arguments): VES_ARGS_LOSS / the closed loop's HULL_SHARED_LOSS
+
 // SupervisedTau.py:42-83: tau = B(alpha) F, F_i = K_i n_i |n_i|
 // sc != nullptr: sin/cos of the port and starboard azimuths are already known (sc = {sin_p, cos_p, sin_s, cos_s})
 // tl != nullptr (wave-uniform): the inflow thrust loss above is applied; nullptr - the default hull - is the reference's law, untouched
@@ -513,6 +527,56 @@ __device__ __forceinline__ void current_drift_step(const StepArgs& a, Current& c
     c.vc = fmaf(a.drift_sv, zc, fmaf(a.drift_a, vc0 - c.vc, c.vc));
     c.beta = fmaf(a.drift_sb, zs, fmaf(a.drift_a, beta0 - c.beta, c.beta));
     current_components(c);
+}
+
+// Per-episode randomisation of the current (round 6; dpenv_set_current_randomisation): every reset - explicit, auto, reset_at_end - draws the new
+// episode's current around the env's nominal one,
+//     V_c = max(0, V_nom + range_v u1),   beta_c = beta_nom + range_b u2,   u1, u2 = u01_sym of words 0, 1 of
+// Philox4x32-10 keyed by the seed with counter (global env id, episode, tag 3): a function of the env and of its episode like the pose sample
+// (tags 0, 1), the reset thrust (tag 2) and the hull (0x48000000 | block) - independent of the rank count and of the launch form.  The drawn
+// values become both the present current and the mean the drift reverts to.  Lives where the hull re-draw lives: in the reset kernel and in
+// the GENERAL per-env kernels (dpenv_dev.h VES_ENV_RND, the closed loop's HULL_ENV_RND and one-wave forms); every other kernel is untouched.
+// current_draw: the draw itself, inlined where the caller has registers to spare (the reset kernel, dpenv_step's reset wave and one-wave reset
+// branch, the fused rollout's reset branch); current_redraw_call: the same as a function call, like the hull draw's (redraw_vessel_table_call
+// above), for the closed-loop kernels that run at the edge of the register file - the Philox rounds use the callee's registers, two floats come back.
+__device__ __forceinline__ float2 current_draw(const float* nom, int nom_stride, float range_v, float range_b, uint32_t seed_lo, uint32_t seed_hi,
+                                               int64_t gid, int i, uint32_t episode)
+{
+    uint32_t w[4];
+    philox4x32_10((uint32_t)((uint64_t)gid & 0xffffffffu), (uint32_t)((uint64_t)gid >> 32), episode, 3u, seed_lo, seed_hi, w);
+    const float v = fmaxf(nom[i] + range_v * u01_sym(w[0]), 0.0f);           // (a product and a sum, never contracted: -ffp-contract=off)
+    const float b = nom[nom_stride + i] + range_b * u01_sym(w[1]);
+    return make_float2(v, b);
+}
+__device__ __forceinline__ float2 current_draw(const StepArgs& a, int i, int il, uint32_t episode)
+{
+    return current_draw(a.cur_nom, a.cur_nom_stride, a.cur_range_v, a.cur_range_b, a.seed_lo, a.seed_hi, a.env_id_base + i, il, episode);
+}
+static __device__ __attribute__((noinline)) float2 current_redraw_call(const float* nom, int nom_stride, float range_v, float range_b, uint32_t seed_lo,
+                                                                       uint32_t seed_hi, int64_t gid, int i, uint32_t episode)
+{
+    return current_draw(nom, nom_stride, range_v, range_b, seed_lo, seed_hi, gid, i, episode);
+}
+// the caller's registers: the present current, its components, the drift's means.  The caller stores them (cur_vc, cur_beta, cur_vc0,
+// cur_beta0) where it stores the drifting current: at once in the one-step kernels, at the end of the launch in the T-step kernels.
+__device__ __forceinline__ void current_redraw(const StepArgs& a, int i, uint32_t episode, Current& c, float& vc0, float& beta0)
+{
+    const float2 d = current_redraw_call(a.cur_nom, a.cur_nom_stride, a.cur_range_v, a.cur_range_b, a.seed_lo, a.seed_hi, a.env_id_base + i, i, episode);
+    c.vc = d.x; c.beta = d.y;
+    vc0 = d.x; beta0 = d.y;
+    current_components(c);
+}
+__device__ __forceinline__ void current_redraw_inline(const StepArgs& a, int i, uint32_t episode, Current& c, float& vc0, float& beta0)
+{
+    const float2 d = current_draw(a, i, i, episode);
+    c.vc = d.x; c.beta = d.y;
+    vc0 = d.x; beta0 = d.y;
+    current_components(c);
+}
+__device__ __forceinline__ void store_current(const StepArgs& a, int i, const Current& c, float vc0, float beta0, bool means)
+{
+    a.cur_vc[i] = c.vc; a.cur_beta[i] = c.beta;
+    if (means) { a.cur_vc0[i] = vc0; a.cur_beta0[i] = beta0; }
 }
 
 // Exploration noise of the policy (core.py:85 tf.random_normal inside the graph): A standard normals for draw `ctr` of env
@@ -837,8 +901,9 @@ struct StepRest {
 // ENV:104-133 up to and including the observation and the termination bits - everything the NEXT policy input depends on.
 // DEFER: leave the reward (and, for the continuous-angle variant, the two atan2 behind the azimuth bookkeeping) to env_step_finish,
 // so that a kernel can hand the observation over first.  cur = constant current (vcN, vcE in NED) present.
-// il: the env's (clamped) index, for the thrust-loss table; < 0 (a compile-time constant in every kernel but the general per-env ones, VES_ENV_RND /
-// the closed loop's RND and one-wave forms) = no table: the loss code is not even compiled in, those kernels are what they were without it.
+// il: the env's (clamped) index, for the thrust-loss table; IL_SHARED = the single class's coefficients (kernel arguments); IL_NONE (a compile-time
+// constant in every kernel but the general per-env ones, the shared-loss ones and the one-wave closed loop) = the loss code is not even
+// compiled in, those kernels are what they were without it.
 template <int MODE, bool EXT, bool DEFER>
 __device__ __forceinline__ void env_step_chain(const StepArgs& a, const Vessel& ve, Env& s, const float* act, bool has_ref,
                                                float nrN, float nrE, float nrP, bool cur, float vcN, float vcE, StepOut& out, StepRest& rest,
@@ -847,10 +912,15 @@ __device__ __forceinline__ void env_step_chain(const StepArgs& a, const Vessel& 
 #pragma unroll
     for (int k = 0; k < 3; ++k) { rest.ang_prev[k] = s.ang[k]; rest.pt_old[k] = s.pt[k]; }   // ENV:102
     Wrench w;
-    if (il >= 0 && a.loss_on) {                          // launch-uniform (a kernel argument): some env of this handle has a thrust-loss coefficient
-        const float4 q0 = a.env_tab[(int64_t)ENV_GROUPS * a.env_stride + il], q1 = a.env_tab[(int64_t)(ENV_GROUPS + 1) * a.env_stride + il];
+    if (il == IL_SHARED || (il >= 0 && thrust_loss_on(a))) {     // launch-uniform
         ThrustLoss tl;
-        tl.klf[0] = q0.x; tl.klf[1] = q0.y; tl.klf[2] = q0.z; tl.klr[0] = q0.w; tl.klr[1] = q1.x; tl.klr[2] = q1.y;
+        if (il == IL_SHARED) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { tl.klf[k] = a.kl[k]; tl.klr[k] = a.kl[3 + k]; }
+        } else {
+            const float4 q0 = a.env_tab[(int64_t)ENV_GROUPS * a.env_stride + il], q1 = a.env_tab[(int64_t)(ENV_GROUPS + 1) * a.env_stride + il];
+            tl.klf[0] = q0.x; tl.klf[1] = q0.y; tl.klf[2] = q0.z; tl.klr[0] = q0.w; tl.klr[1] = q1.x; tl.klr[2] = q1.y;
+        }
         tl.u = s.u; tl.v = s.v; tl.r = s.r;
         if (cur) {                                       // through the water: nu_r = nu - R(psi)^T v_c (env_plant forms the same difference)
             tl.u -= fmaf(s.cs, vcN, s.sn * vcE);

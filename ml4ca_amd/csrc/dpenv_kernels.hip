@@ -50,6 +50,7 @@ constexpr int STEP_TRACE_RING = 8;
 // every launch holds a finished env, so every launch paid for the draw; tools/step_placement.py).  Same
 // functions on the same inputs: every row is bit-identical to the one-wave form.
 constexpr int RESETW_FIELDS = 18;       // N, E, psi | o[0..8] | pt[0..2] | sin psi, cos psi | episode counter (bits)
+constexpr int RESETW_FIELDS_RND = 20;   // the general per-env form: | the new episode's current V_c, beta_c (dpenv_set_current_randomisation)
 
 template <int MODE>
 __device__ __forceinline__ void reset_wave(const StepArgs& a, float* lds, int lane, int blk)
@@ -100,14 +101,15 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(const 
     constexpr int A = ModeTraits<MODE>::A;
     constexpr int OD = EXT ? 9 : 6;
     constexpr bool PER_CLASS = VES == VES_CLASS_LDS;
-    constexpr bool RND = VES == VES_ENV_RND;            // domain randomisation: a reset re-draws the hull
+    constexpr bool RND = VES == VES_ENV_RND;            // domain randomisation: a reset re-draws the hull (and the current)
     constexpr bool ENV_VGPR = VES == VES_ENV_VGPR || RND;
+    constexpr int IL = VES == VES_ARGS_LOSS ? IL_SHARED : IL_NONE;    // (RND: the lane's own row of the table)
     static_assert(!RESETW || BLOCK == 64, "the reset wave pairs with ONE env wave");
     static_assert(VES != VES_ENV_LDS || BLOCK == 64, "the LDS-DMA image is [group][lane] of one wave");
     __shared__ float lds_io[BLOCK * 9];
     __shared__ float lds_cls[PER_CLASS ? VD_COUNT * MAX_CLASSES : 1];
     __shared__ float4 lds_pe[VES == VES_ENV_LDS ? ENV_GROUPS * 64 : 1];
-    __shared__ float lds_rst[RESETW ? RESETW_FIELDS * 64 : 1];
+    __shared__ float lds_rst[RESETW ? (RND ? RESETW_FIELDS_RND : RESETW_FIELDS) * 64 : 1];
     __shared__ uint32_t lds_fin[RESETW ? 64 : 1];      // env wave -> reset wave: this env finished and is being re-drawn
 
     if (RESETW && threadIdx.x >= BLOCK) {
@@ -120,6 +122,10 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(const 
         const bool rnd = RND && a.rand_tab != nullptr;  // (the general per-env kernel also serves fixed hulls with a thrust loss)
         if (rnd)
             draw_env_groups(hull_key(a), a.env_id_base + i, __float_as_uint(lds_rst[17 * 64 + lane]), [&](int g, const float4& q) { hull[g] = q; });
+        if (RND && a.cur_nom) {                         // the current of the episode that would start now
+            const float2 cd = current_draw(a, i, i < a.n ? i : a.n - 1, __float_as_uint(lds_rst[17 * 64 + lane]));
+            lds_rst[18 * 64 + lane] = cd.x; lds_rst[19 * 64 + lane] = cd.y;
+        }
         __syncthreads();
         if (rnd && lds_fin[lane] != 0u) {
 #pragma unroll
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(const 
 
     StepOut out;
     StepRest rest;
-    env_step_chain<MODE, EXT, false>(a, ve, s, act, a.new_ref != nullptr, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out, rest, RND ? il : -1);
+    env_step_chain<MODE, EXT, false>(a, ve, s, act, a.new_ref != nullptr, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out, rest, RND ? il : IL);
     bool rf_dirty = (a.new_ref != nullptr) || (MODE == MODE_FULL);
     // Without auto-reset the state, the observation and the termination bits are final HERE, ~100 instructions (exp, three square roots, the
     // penalties) before the reward: their stores - 85 of the 89 bytes an env-step writes - go out now and travel while the reward is computed;
@@ -258,10 +264,19 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(const 
         }
         const uint32_t ep = RESETW ? __float_as_uint(lds_rst[17 * 64 + tid]) : (uint32_t)a.episode[i];
         a.episode[i] = (int)(ep + 1u);
-        if (RESETW) reset_from_lds<MODE>(lds_rst, tid, s, o_next);
-        else {
+        if (RESETW) {
+            reset_from_lds<MODE>(lds_rst, tid, s, o_next);
+            if (RND && a.cur_nom) {                                  // the new episode's current, drawn by the reset wave: present value and drift mean
+                const float v = lds_rst[18 * 64 + tid], b = lds_rst[19 * 64 + tid];
+                a.cur_vc[i] = v; a.cur_beta[i] = b; a.cur_vc0[i] = v; a.cur_beta0[i] = b;
+            }
+        } else {
             env_auto_reset<MODE>(a, s, a.env_id_base + i, ep, o_next);
             if (RND && a.rand_tab) redraw_vessel_table(a, i, ep);   // domain randomisation: the new episode's hull (the reset wave does this in the two-wave form)
+            if (RND && a.cur_nom) {
+                const float2 cd = current_draw(a, i, i, ep);
+                a.cur_vc[i] = cd.x; a.cur_beta[i] = cd.y; a.cur_vc0[i] = cd.x; a.cur_beta0[i] = cd.y;
+            }
         }
         rf_dirty = true;
     }
@@ -311,6 +326,7 @@ __global__ __launch_bounds__(RBLOCK) void rollout_kernel(const StepArgs a, const
     constexpr int A = ModeTraits<MODE>::A;
     constexpr int OD = EXT ? 9 : 6;
     constexpr bool PER_CLASS = VES == VES_CLASS_LDS, RND = VES == VES_ENV_RND, PER_ENV = VES == VES_ENV_VGPR || RND;
+    constexpr int IL = VES == VES_ARGS_LOSS ? IL_SHARED : IL_NONE;
     __shared__ float lds_act[RBLOCK * 7];
     __shared__ float lds_obs[RBLOCK * 9];
     __shared__ float lds_cls[PER_CLASS ? VD_COUNT * MAX_CLASSES : 1];
@@ -366,6 +382,7 @@ __global__ __launch_bounds__(RBLOCK) void rollout_kernel(const StepArgs a, const
     };
     fetch(0);
     int next_switch = 0;
+    bool cur_dirty = false;                      // a reset drew a new current (RND only): present value and drift mean go back at the end
     float lag[3] = {0.0f, 0.0f, 0.0f};
     for (int t = 0; t < ra.T; ++t) {
         float act[A];
@@ -391,7 +408,7 @@ __global__ __launch_bounds__(RBLOCK) void rollout_kernel(const StepArgs a, const
             ++next_switch;
         }
         StepOut out;
-        env_step<MODE, EXT>(a, ve, s, act, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out, RND ? il : -1);
+        env_step<MODE, EXT>(a, ve, s, act, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out, RND ? il : IL);
         if (a.current_drift) current_drift_step(a, cur, vc0, beta0, a.env_id_base + i);
         float o_next[9];
 #pragma unroll
@@ -399,6 +416,7 @@ __global__ __launch_bounds__(RBLOCK) void rollout_kernel(const StepArgs a, const
         if (a.auto_reset && out.d != 0u && live) {
             env_auto_reset<MODE>(a, s, a.env_id_base + i, episode, o_next);
             if (RND && a.rand_tab) redraw_vessel(a, i, episode, ve);   // domain randomisation: the new episode runs on a new hull
+            if (RND && a.cur_nom) { current_redraw_inline(a, i, episode, cur, vc0, beta0); cur_dirty = true; }   // ... in a new current
             ++episode; ep_dirty = true; rf_dirty = true;
         }
         lag[0] = o_next[6]; lag[1] = o_next[7]; lag[2] = o_next[8];
@@ -430,6 +448,7 @@ __global__ __launch_bounds__(RBLOCK) void rollout_kernel(const StepArgs a, const
         if (EXT) a.S3[i] = make_float4(lag[0], lag[1], lag[2], 0.0f);          // thrust columns of the last observation returned (see step_kernel)
         if (ep_dirty) a.episode[i] = (int)episode;
         if (a.current_drift) { a.cur_vc[i] = cur.vc; a.cur_beta[i] = cur.beta; a.drift_ctr[i] = cur.ctr; }
+        if (RND && cur_dirty) store_current(a, i, cur, vc0, beta0, true);
     }
 }
 
@@ -467,13 +486,14 @@ __device__ __forceinline__ void mb_wait(int* p, int v)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-constexpr int RW_REC = 18;              // re-draw record: N, E, psi | o[0..8] | pt[0..2] | sin psi, cos psi | (unused)
+constexpr int RW_REC = 18;              // re-draw record: N, E, psi | o[0..8] | pt[0..2] | sin psi, cos psi | the new episode's index (bits; RND only)
 template <int MODE, bool EXT, int VES>
 __global__ __launch_bounds__(128) void rollout_ws_kernel(const StepArgs a, const RolloutArgs ra)
 {
     constexpr int A = ModeTraits<MODE>::A;
     constexpr int OD = EXT ? 9 : 6;
     constexpr bool PER_CLASS = VES == VES_CLASS_LDS, RND = VES == VES_ENV_RND, PER_ENV = VES == VES_ENV_VGPR || RND;
+    constexpr int IL = VES == VES_ARGS_LOSS ? IL_SHARED : IL_NONE;
     __shared__ float act_mb[2][64 * 7];          // a_t rows by step parity, [lane * A + k]
     __shared__ float post_mb[2][64 * 9];         // o_t+1 rows (pre-reset) by step parity, [lane * OD + k]: also the staged image of the row store
     __shared__ uint32_t done_mb[2][64];
@@ -536,6 +556,7 @@ __global__ __launch_bounds__(128) void rollout_ws_kernel(const StepArgs a, const
 #pragma unroll
             for (int k = 0; k < 3; ++k) { rec_pt[k] = s.pt[k]; rec_mb[(12 + k) * 64 + lane] = s.pt[k]; }
             rec_mb[15 * 64 + lane] = s.sn; rec_mb[16 * 64 + lane] = s.cs;
+            if (RND) rec_mb[17 * 64 + lane] = __uint_as_float(episode);        // the env wave draws the new episode's current from it
             ++version;
             mb_post(&seq[2], version, lane);
         };
@@ -665,7 +686,7 @@ __global__ __launch_bounds__(128) void rollout_ws_kernel(const StepArgs a, const
     Vessel ve = PER_ENV ? vessel_from_env(a.env_tab, a.env_stride, il)
                         : (PER_CLASS ? vessel_from_lds(lds_cls, a.n_classes, cls) : vessel_from_args(a.v0));
     if (!PER_CLASS && !PER_ENV) pin_vessel_in_vgprs(ve);
-    bool rf_dirty = (MODE == MODE_FULL);
+    bool rf_dirty = (MODE == MODE_FULL), cur_dirty = false;
     int next_switch = 0, need = 1;               // re-draw record version this wave may read: 1 + setpoint switches so far + re-draw events so far
     for (int t = 0; t < ra.T; ++t) {
         mb_wait(&seq[0], t + 1);                                             // a_t posted (long ago: the row wave runs two steps ahead)
@@ -683,7 +704,7 @@ __global__ __launch_bounds__(128) void rollout_ws_kernel(const StepArgs a, const
         }
         StepOut out;
         StepRest rest;
-        env_step_chain<MODE, EXT, true>(a, ve, s, act, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out, rest, RND ? il : -1);
+        env_step_chain<MODE, EXT, true>(a, ve, s, act, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out, rest, RND ? il : IL);
         if (a.current_drift) current_drift_step(a, cur, vc0, beta0, a.env_id_base + i);
         const bool do_reset = resets && out.d != 0u && live;
         float* pm = post_mb[t & 1];
@@ -708,6 +729,7 @@ __global__ __launch_bounds__(128) void rollout_ws_kernel(const StepArgs a, const
                                          make_float4(hull_mb[(4 * g + 0) * 64 + lane], hull_mb[(4 * g + 1) * 64 + lane],
                                                      hull_mb[(4 * g + 2) * 64 + lane], hull_mb[(4 * g + 3) * 64 + lane]));
                 }
+                if (RND && a.cur_nom) { current_redraw_inline(a, i, __float_as_uint(rec_mb[17 * 64 + lane]), cur, vc0, beta0); cur_dirty = true; }
                 rf_dirty = true;
             }
             ++need;
@@ -723,6 +745,7 @@ __global__ __launch_bounds__(128) void rollout_ws_kernel(const StepArgs a, const
     if (live) {
         store_env(a, i, s, rf_dirty);
         if (a.current_drift) { a.cur_vc[i] = cur.vc; a.cur_beta[i] = cur.beta; a.drift_ctr[i] = cur.ctr; }
+        if (RND && cur_dirty) store_current(a, i, cur, vc0, beta0, true);
     }
 }
 
@@ -747,7 +770,7 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(const StepArgs a, const ui
         float eta[3], nu[3], pt[3] = {0.0f, 0.0f, 0.0f};
         // the episode counter advances with every reset that consumes random numbers (sampled pose, or drawn thrust)
         const uint32_t ep = (uint32_t)a.episode[i];
-        if (!init || a.reset_acts || a.rand_tab) a.episode[i] = (int)(ep + 1u);
+        if (!init || a.reset_acts || a.rand_tab || a.cur_nom) a.episode[i] = (int)(ep + 1u);
         if (init) {
             // explicit **init (ENV:141,152,159-161); the 50 held sub-steps (ENV:164-167) keep it in place
             for (int k = 0; k < 3; ++k) { eta[k] = init[(int64_t)k * n + i]; nu[k] = init[(int64_t)(3 + k) * n + i]; }
@@ -767,6 +790,10 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(const StepArgs a, const ui
         // reset's own previous thrust (ENV:190,196-205) - written per env, so that a MASKED reset leaves the other envs' lag alone
         a.S3[i] = make_float4(pt[0] * 0.01f, pt[1] * 0.01f, pt[2] * 0.01f, 0.0f);
         if (a.rand_tab) redraw_vessel_table(a, i, ep);      // domain randomisation: every reset starts its episode on a freshly drawn hull
+        if (a.cur_nom) {                                    // ... and in a freshly drawn current
+            const float2 cd = current_draw(a, i, i, ep);
+            a.cur_vc[i] = cd.x; a.cur_beta[i] = cd.y; a.cur_vc0[i] = cd.x; a.cur_beta0[i] = cd.y;
+        }
     }
     if (a.obs) {
         const float pt[3] = {s2.x, s2.y, s2.z};
@@ -1109,6 +1136,7 @@ static hipError_t launch_step_mode(const StepArgs& a, bool ext, int ves, bool re
     case VES_ENV_VGPR: return launch_step_ves<MODE, VES_ENV_VGPR>(a, ext, reset_wave, s);
     case VES_ENV_LDS: return launch_step_ves<MODE, (BLOCK == 64 ? VES_ENV_LDS : VES_ENV_VGPR)>(a, ext, reset_wave, s);
     case VES_ENV_RND: return launch_step_ves<MODE, VES_ENV_RND>(a, ext, reset_wave, s);
+    case VES_ARGS_LOSS: return launch_step_ves<MODE, VES_ARGS_LOSS>(a, ext, reset_wave, s);
     }
     return hipErrorInvalidValue;
 }
@@ -1122,7 +1150,8 @@ extern "C" int dpenv_debug_set_step_trace(void* p)      // device buffer of STEP
 
 extern "C" hipError_t dpenv_dev_launch_step(const StepArgs* a, int mode, int ext, int ves, int reset_wave, hipStream_t s)
 {
-    if (ves >= VES_ENV_VGPR && !a->env_tab) return hipErrorInvalidValue;
+    if (ves >= VES_ENV_VGPR && ves <= VES_ENV_RND && !a->env_tab) return hipErrorInvalidValue;
+    if ((ves == VES_ARGS_LOSS) != (a->loss_on == LOSS_SHARED)) return hipErrorInvalidValue;
     switch (mode) {
     case MODE_FULL: return launch_step_mode<MODE_FULL>(*a, ext, ves, reset_wave != 0, s);
     case MODE_SIMPLE: return launch_step_mode<MODE_SIMPLE>(*a, ext, ves, reset_wave != 0, s);
@@ -1169,6 +1198,7 @@ static hipError_t launch_rollout_mode(const StepArgs& a, const RolloutArgs& ra, 
     case VES_CLASS_LDS: return launch_rollout_ves<MODE, VES_CLASS_LDS>(a, ra, ext, two_wave, s);
     case VES_ENV_VGPR: case VES_ENV_LDS: return launch_rollout_ves<MODE, VES_ENV_VGPR>(a, ra, ext, two_wave, s);   // a T-step kernel's staging area is the register file
     case VES_ENV_RND: return launch_rollout_ves<MODE, VES_ENV_RND>(a, ra, ext, two_wave, s);
+    case VES_ARGS_LOSS: return launch_rollout_ves<MODE, VES_ARGS_LOSS>(a, ra, ext, two_wave, s);
     }
     return hipErrorInvalidValue;
 }
@@ -1176,7 +1206,8 @@ static hipError_t launch_rollout_mode(const StepArgs& a, const RolloutArgs& ra, 
 extern "C" hipError_t dpenv_dev_launch_rollout(const StepArgs* a, const RolloutArgs* ra, int mode, int ext, int ves, int two_wave,
                                                hipStream_t s)
 {
-    if (ves >= VES_ENV_VGPR && !a->env_tab) return hipErrorInvalidValue;
+    if (ves >= VES_ENV_VGPR && ves <= VES_ENV_RND && !a->env_tab) return hipErrorInvalidValue;
+    if ((ves == VES_ARGS_LOSS) != (a->loss_on == LOSS_SHARED)) return hipErrorInvalidValue;
     switch (mode) {
     case MODE_FULL: return launch_rollout_mode<MODE_FULL>(*a, *ra, ext, ves, two_wave != 0, s);
     case MODE_SIMPLE: return launch_rollout_mode<MODE_SIMPLE>(*a, *ra, ext, ves, two_wave != 0, s);

@@ -177,6 +177,7 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
             if (do_reset) {
                 env_auto_reset<MODE>(a, s, a.env_id_base + i, episode, o);
                 if (a.rand_tab) redraw_vessel_cold(a, i, episode, ve);    // domain randomisation: the new episode runs on a new hull
+                if (a.cur_nom) current_redraw(a, i, episode, cur, vc0, beta0);    // ... in a new current (stored with the final state)
                 ++episode; ep_dirty = true; rf_dirty = true;
             }
         }
@@ -207,6 +208,7 @@ __global__ __launch_bounds__(PBLOCK) void policy_rollout_kernel(const StepArgs a
         if (EXT) a.S3[i] = make_float4(o[6], o[7], o[8], 0.0f);
         if (ep_dirty) a.episode[i] = (int)episode;
         if (a.current_drift) { a.cur_vc[i] = cur.vc; a.cur_beta[i] = cur.beta; a.drift_ctr[i] = cur.ctr; }
+        if (a.cur_nom && ep_dirty) store_current(a, i, cur, vc0, beta0, true);
         if (draw) a.noise_ctr[i] = nctr;
     }
 }

@@ -70,9 +70,13 @@ __device__ __forceinline__ void ws_wait(int* p, int v)
 #define WS_EVAL(W_, B_, f0_, f1_) mlp_eval<KA>(W_, B_, pa.n_hidden, f0_, f1_, leak, outv)
 //  RND: the domain randomisation's hull re-draw compiled into the reset branch (instantiated for the shipped training configuration only -
 //  final variant, continuous angles, extended state, leaky-relu - see dpenv_ws_launch::pick and dpenv_env_dev.h redraw_vessel_cold).
-template <int MODE, bool EXT, int KA, int ROLES, int PREC = PREC_F16, int GROUPS = 4, bool RND = false>
+//  SLOSS (round 6): the single class's thrust-loss coefficients from the kernel arguments (StepArgs.kl, LOSS_SHARED) - the thrust-loss preset
+//  on the shared hull, without per-env blocks; same configurations as RND.
+template <int MODE, bool EXT, int KA, int ROLES, int PREC = PREC_F16, int GROUPS = 4, bool RND = false, bool SLOSS = false>
 __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(const StepArgs a, const PolicyArgs pa)
 {
+    static_assert(!(RND && SLOSS), "per-env blocks carry their own coefficients");
+    constexpr int IL = SLOSS ? IL_SHARED : IL_NONE;
     constexpr int A = ModeTraits<MODE>::A;
     constexpr int OD = EXT ? 9 : 6;
     constexpr int THREADS = 64 * GROUPS * ROLES;
@@ -418,7 +422,7 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
         constexpr bool DEFER = true;
 #endif
         StepRest rest;
-        env_step_chain<MODE, EXT, DEFER>(a, ve, s, act, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out, rest, RND ? il : -1);
+        env_step_chain<MODE, EXT, DEFER>(a, ve, s, act, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, out, rest, RND ? il : IL);
         if constexpr (!DEFER) env_step_finish<MODE, EXT, false>(a, s, act, rest, true, out);
         WS_TOC(t_env, te_);
         WS_TIC(tq_);
@@ -426,7 +430,7 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
         {
             ws_wait(&seq[2], t + 1);                                         // critic(o_t) done: the partner is idle from here
                 StepOut outB;
-            env_step<MODE, EXT>(a, ve, sB, actB, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, outB, RND ? il : -1);
+            env_step<MODE, EXT>(a, ve, sB, actB, has_ref, nrN, nrE, nrP, a.cur_vc != nullptr, cur.vcN, cur.vcE, outB, RND ? il : IL);
             const float fa[20] = {s.N, s.E, s.psi, s.u, s.v, s.r, s.sn, s.cs, out.reward, out.o[0], out.o[1], out.o[2], out.o[3],
                                   out.o[4], out.o[5], out.o[6], out.o[7], out.o[8], __uint_as_float(out.d), s.ang[1]};
             const float fb[20] = {sB.N, sB.E, sB.psi, sB.u, sB.v, sB.r, sB.sn, sB.cs, outB.reward, outB.o[0], outB.o[1], outB.o[2],
@@ -453,6 +457,7 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
         for (int k = 0; k < 9; ++k) o[k] = out.o[k];
         // ppo.py:305-322 with reset_at_end: after the LAST step of the block every env is cut and re-drawn, ended or not
         const bool do_reset = ((a.auto_reset && out.d != 0u) || (pa.reset_at_end && t == pa.T - 1)) && live;
+        float new_vc = 0.0f, new_beta = 0.0f;                               // RND: the re-drawn env's new current (dpenv_set_current_randomisation)
         const bool terminal = (out.d & DONE_TERMINAL) != 0u;
         const bool ended = (out.d != 0u) || (t == pa.T - 1);
         boot_wanted = ended && !terminal;                                    // ppo.py:311
@@ -473,6 +478,9 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
                 // domain randomisation: the new episode runs on a new hull (the RND instantiation also serves fixed hulls with a thrust loss)
                 if constexpr (VE_RELOAD) { if (a.rand_tab) redraw_vessel_table_call(a.rand_tab, a.seed_lo, a.seed_hi, a.env_tab, a.env_stride, a.env_id_base + i, i, episode); }
                 else if constexpr (RND) { if (a.rand_tab) redraw_vessel_cold(a, i, episode, ve); }
+                // ... in a new current: drawn here, put in force behind this step's drift update below (the drift of step t belongs to the episode
+                // that ended - dpenv_step applies it before the reset -, the new episode starts exactly on the drawn values)
+                if constexpr (RND) { if (a.cur_nom) { const float2 cd = current_redraw_call(a.cur_nom, a.cur_nom_stride, a.cur_range_v, a.cur_range_b, a.seed_lo, a.seed_hi, a.env_id_base + i, i, episode); new_vc = cd.x; new_beta = cd.y; } }
                 ++episode; ep_dirty = true; rf_dirty = true;
             }
         }
@@ -491,6 +499,7 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
         if constexpr (DEFER) env_step_finish<MODE, EXT, true>(a, s, act, rest, !do_reset, out);   // reward, azimuths of a continuing env
         logp = action_logp<A>(pc, mu, act);                                  // core.py:42-46 on (a_t, mu_t)
         if (a.current_drift) current_drift_step(a, cur, vc0, beta0, a.env_id_base + i);   // the current of step t+1: not needed by o_t+1
+        if constexpr (RND) { if (a.cur_nom && do_reset) { cur.vc = new_vc; cur.beta = new_beta; vc0 = new_vc; beta0 = new_beta; current_components(cur); } }
         put_rows_a(pa.act_out, (int64_t)t * stride_a, act);
         if (t + 1 < pa.T) put_rows_o(pa.obs_out, (int64_t)(t + 1) * stride_o, o);
         if (live) {
@@ -531,6 +540,7 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
         if (EXT) a.S3[i] = make_float4(o[6], o[7], o[8], 0.0f);
         if (ep_dirty) a.episode[i] = (int)episode;
         if (a.current_drift) { a.cur_vc[i] = cur.vc; a.cur_beta[i] = cur.beta; a.drift_ctr[i] = cur.ctr; }
+        if constexpr (RND) { if (a.cur_nom && ep_dirty) store_current(a, i, cur, vc0, beta0, true); }
         if (draw) a.noise_ctr[i] = nctr;
     }
 }
@@ -551,7 +561,7 @@ using namespace dpenv;
 // on a SIMD leave), 5.27 -> 5.33 / 4.79 -> 4.92 without it (no scratch): the f16 step is its chain already - so the two split arithmetics
 // get the critic wave, f16 keeps two roles.
 // (DPENV_WS_CRITIC_WAVE: dpenv_dev.h, default 6)
-template <int MODE, bool EXT, int KA, int PREC, int GROUPS, bool RND = false>
+template <int MODE, bool EXT, int KA, int PREC, int GROUPS, bool RND = false, bool SLOSS = false>
 static hipError_t go(const StepArgs& a, const PolicyArgs& pa, hipStream_t s)
 {
     constexpr int ROLES = (GROUPS == 2 && ((DPENV_WS_CRITIC_WAVE >> PREC) & 1)) ? 3 : 2;
@@ -559,10 +569,10 @@ static hipError_t go(const StepArgs& a, const PolicyArgs& pa, hipStream_t s)
     const size_t lds = (size_t)ws_images(PREC) * pa.nent * 16 + (size_t)2 * pa.nblk * 32 * 4 +
                        (size_t)GROUPS * ((((PREC == PREC_F16 && ROLES == 2)) ? WS_GROUP_FLOATS : WS_GROUP_FLOATS_X) +
                                          (ROLES == 3 ? 64 * 9 : 0)) * 4;
-    hipError_t e = hipFuncSetAttribute((const void*)policy_rollout_ws_kernel<MODE, EXT, KA, ROLES, PREC, GROUPS, RND>,
+    hipError_t e = hipFuncSetAttribute((const void*)policy_rollout_ws_kernel<MODE, EXT, KA, ROLES, PREC, GROUPS, RND, SLOSS>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((policy_rollout_ws_kernel<MODE, EXT, KA, ROLES, PREC, GROUPS, RND>), grid, dim3(64 * GROUPS * ROLES), lds, s, a, pa);
+    hipLaunchKernelGGL((policy_rollout_ws_kernel<MODE, EXT, KA, ROLES, PREC, GROUPS, RND, SLOSS>), grid, dim3(64 * GROUPS * ROLES), lds, s, a, pa);
     return hipGetLastError();
 }
 
@@ -571,7 +581,12 @@ static hipError_t go(const StepArgs& a, const PolicyArgs& pa, hipStream_t s)
 template <int MODE, bool EXT, int KA, int PREC, int GROUPS>
 static hipError_t pick(const StepArgs& a, const PolicyArgs& pa, hipStream_t s)
 {
-    if (a.rand_tab || a.loss_on) {
+    if (a.loss_on == LOSS_SHARED) {                       // the single class's coefficients as kernel arguments
+        if (a.env_tab) return hipErrorInvalidValue;
+        if constexpr (MODE == MODE_FINAL_CONT && EXT && KA < 16) return go<MODE, EXT, KA, PREC, GROUPS, false, true>(a, pa, s);
+        else return hipErrorNotSupported;
+    }
+    if (a.rand_tab || a.loss_on != LOSS_NONE || a.cur_nom) {   // the general per-env form: hull / current re-draws, the table's thrust loss
         if constexpr (MODE == MODE_FINAL_CONT && EXT && KA < 16) return go<MODE, EXT, KA, PREC, GROUPS, true>(a, pa, s);
         else return hipErrorNotSupported;
     }

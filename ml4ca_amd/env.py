@@ -195,6 +195,12 @@ class BatchedRevoltEnv(object):
         return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
 
     def _chk(self, t, shape, dtype, what):
+        """Argument check of a tensor handed to the C ABI: type, device, dtype, shape, contiguity - ONCE per tensor object (a weak reference keyed by
+        id()): a tensor that passed is not looked at again, which is what keeps a Python `for` over step() at the GPU's rate (bench_side.json
+        eager_loop: the full check costs ~0.4 us per tensor, four tensors per call, against a 4.9 us kernel).  The price: a tensor that
+        is CHANGED IN PLACE between calls - t_(), transpose_(), resize_(), as_strided_(), set_(), `.data = ...` - is not re-checked, and the kernels
+        would then read or write through a pointer whose extent no longer matches.  Do not reshape tensors you pass to reset / step / rollout in
+        place; make a new tensor (a new object is checked)."""
         if t is None:
             return None
         ok = self._ok.get(id(t))
@@ -263,7 +269,9 @@ class BatchedRevoltEnv(object):
 
         action: float32 [n, act_dim] (or [act_dim, n] with layout='soa'); new_ref: float32 [3, n], visible from
         the NEXT observation (ENV:131).  out: optional (obs, reward, done) tensors to write into (e.g. rows of a
-        [T, n, .] rollout buffer); otherwise internal buffers are reused (obs is double-buffered)."""
+        [T, n, .] rollout buffer); otherwise internal buffers are reused (obs is double-buffered).
+        Tensors are checked (device, dtype, shape, contiguity) the first time the OBJECT is seen, not on every call: do not change the shape or
+        strides of a tensor in place (t_(), resize_(), set_() ...) between calls - pass a new tensor instead (_chk)."""
         f32, chk = self._f32, self._chk
         chk(action, self._ashape, f32, 'action')
         if out is None:
@@ -386,6 +394,25 @@ class BatchedRevoltEnv(object):
         _lib.check(self.lib.dpenv_get_current(self._h, self._ptr(vc), self._ptr(beta), self._stream()), self._h)
         return vc, beta
 
+    def get_current_mean(self):
+        """(vc, beta) the drift reverts to: what set_current gave, or what the last randomised reset drew (set_current_randomisation)."""
+        torch = _torch()
+        vc = torch.empty(self.n_envs, dtype=torch.float32, device=self.device)
+        beta = torch.empty(self.n_envs, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.dpenv_get_current_mean(self._h, self._ptr(vc), self._ptr(beta), self._stream()), self._h)
+        return vc, beta
+
+    def set_current_randomisation(self, vc_range, beta_range, vc_nominal=None, beta_nominal=None):
+        """Per-episode randomisation of the current through the reset path (dpenv_set_current_randomisation): every reset starts its
+        episode in V_c = max(0, vc_nominal + vc_range u1), beta_c = beta_nominal + beta_range u2, u ~ U[-1, 1), keyed (seed; global env
+        id, episode).  Nominals: float32 [n] device tensors, default the means in force (set_current).  Both ranges 0: off."""
+        torch = _torch()
+        for t, what in ((vc_nominal, 'vc_nominal'), (beta_nominal, 'beta_nominal')):
+            if t is not None:
+                self._chk(t, (self.n_envs,), torch.float32, what)
+        _lib.check(self.lib.dpenv_set_current_randomisation(self._h, self._ptr(vc_nominal), self._ptr(beta_nominal), float(vc_range),
+                                                            float(beta_range), self._stream()), self._h)
+
     def set_vessel_class(self, class_id):
         torch = _torch()
         self._chk(class_id, (self.n_envs,), torch.int32, 'class_id')
@@ -393,18 +420,20 @@ class BatchedRevoltEnv(object):
             raise ValueError('class ids must be in [0, %d)' % self.n_classes)
         _lib.check(self.lib.dpenv_set_vessel_class(self._h, self._ptr(class_id), self._stream()), self._h)
 
-    def set_vessel_params(self, params):
-        """Per-env hull / thruster parameters (dpenv_set_vessel_params): float32 [NPARAM, n] device tensor, row p = parameter
+    def set_vessel_params(self, params, keep_randomisation=False):
+        """Per-env hull / thruster parameters (dpenv_set_vessel_params_ex): float32 [NPARAM, n] device tensor, row p = parameter
         _lib.P[...] of every env - the constants the reference hard-codes for its one vessel (qp_allocator.py:51-55,69-70;
         SupervisedTau.py:35-36,69-71), the build-owned plant's mass / damping terms and (rows 26..31) the thrusters' inflow-loss
         coefficients.  A single length-NPARAM vector is given to every env.  None returns to the vessel classes / the single class given
-        to the constructor.  Synchronises the stream (the library reads back whether any env has a thrust loss: dpenv.h)."""
+        to the constructor.  Stream-ordered (no read-back; may be recorded into a graph).  keep_randomisation=True installs the table
+        while set_vessel_randomisation stays in force: the restore path of a checkpoint (get_state + get_vessel_params) taken mid-episode."""
         torch = _torch()
         if params is not None and not (hasattr(params, 'dim') and params.dim() == 2):
             one = torch.as_tensor(np.asarray(params.cpu() if hasattr(params, 'cpu') else params, np.float32).reshape(_lib.NPARAM), device=self.device)
             params = one[:, None].expand(_lib.NPARAM, self.n_envs).contiguous()
         self._chk(params, (_lib.NPARAM, self.n_envs), torch.float32, 'params')
-        _lib.check(self.lib.dpenv_set_vessel_params(self._h, self._ptr(params), self._stream()), self._h)
+        flags = _lib.VESSEL_KEEP_RANDOMISATION if keep_randomisation else 0
+        _lib.check(self.lib.dpenv_set_vessel_params_ex(self._h, self._ptr(params), flags, self._stream()), self._h)
 
     def get_vessel_params(self):
         """float32 [NPARAM, n]: the per-env parameter vectors in force (set explicitly, or drawn by the randomisation)."""

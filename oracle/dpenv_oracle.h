@@ -110,14 +110,18 @@ typedef struct dpo_config {
     void dpo_policy_noise_##suffix(const dpo_config* c, int64_t env_gid, uint32_t draw, int32_t adim, REAL* xi); \
     void dpo_draw_vessel_##suffix(const dpo_config* c, const REAL* rand_tab, int64_t env_gid,          \
                                   uint32_t episode, REAL* params);                                     \
+    void dpo_draw_current_##suffix(const dpo_config* c, int64_t env_gid, uint32_t episode, REAL nom_v, \
+                                   REAL nom_b, REAL range_v, REAL range_b, REAL* out);                 \
     void dpo_reset_##suffix(const dpo_config* c, int32_t n, REAL* state, int32_t* counters,            \
                             const uint8_t* mask, const REAL* init, const REAL* ref, REAL* obs,         \
-                            REAL* vessel_env, const REAL* rand_tab);                                   \
+                            REAL* vessel_env, const REAL* rand_tab, REAL* current, REAL* current_mean, \
+                            const REAL* cur_rand);                                                     \
     void dpo_step_##suffix(const dpo_config* c, const REAL* vessel, int32_t n, REAL* state,            \
                            int32_t* counters, const REAL* action, const REAL* new_ref,                 \
                            const REAL* plant_override, REAL* current, REAL* obs, REAL* rew,            \
-                           uint8_t* done, REAL* parts, REAL* final_obs, const REAL* current_mean,      \
-                           uint32_t* drift_ctr, REAL* vessel_env, const REAL* rand_tab);               \
+                           uint8_t* done, REAL* parts, REAL* final_obs, REAL* current_mean,            \
+                           uint32_t* drift_ctr, REAL* vessel_env, const REAL* rand_tab,                \
+                           const REAL* cur_rand);                                                      \
     void dpo_discount_cumsum_##suffix(const REAL* x, int32_t n, REAL discount, REAL* y);               \
     void dpo_gae_##suffix(const REAL* rew, const REAL* val, const uint8_t* end, const REAL* boot,      \
                           const REAL* last_val, int32_t T, int32_t n, REAL gamma, REAL lam,            \

@@ -434,13 +434,41 @@ void FN(dpo_draw_vessel)(const dpo_config* c, const REAL* rand_tab, int64_t gid,
     }
 }
 
+/*
+ * Build-defined (round 6; config 5 widened): per-episode randomisation of the current.  cur_rand = { range_v, range_b | nominal V_c [n] |
+ * nominal beta_c [n] }: the current of episode `episode` of env `gid` is V_c = max(0, V_nom + range_v u1), beta_c = beta_nom + range_b u2,
+ * u1, u2 = u01_sym of words 0, 1 of Philox4x32-10 keyed by the seed with counter (global env id, episode, tag 3) - beside the pose sample
+ * (tags 0, 1) and the reset thrust (tag 2).  The reference's one operating point: 0.2 m/s towards 135 deg (current_box_test/plot_pos.py:78).
+ */
+void FN(dpo_draw_current)(const dpo_config* c, int64_t gid, uint32_t episode, REAL nom_v, REAL nom_b, REAL range_v, REAL range_b, REAL* out)
+{
+    uint32_t key[2] = {(uint32_t)(c->seed & 0xffffffffu), (uint32_t)(c->seed >> 32)};
+    uint32_t ctr[4] = {(uint32_t)((uint64_t)gid & 0xffffffffu), (uint32_t)((uint64_t)gid >> 32), episode, 3u};
+    uint32_t w[4];
+    dpo_philox4x32_10(ctr, key, w);
+    const REAL pv = range_v * FN(u01_sym)(w[0]);
+    const REAL pb = range_b * FN(u01_sym)(w[1]);
+    const REAL v = nom_v + pv;
+    out[0] = v > R(0) ? v : R(0);
+    out[1] = nom_b + pb;
+}
+
 static void FN(reset_one)(const dpo_config* c, int32_t n, int32_t i, REAL* state, int32_t* counters,
-                          const REAL* init, const REAL* ref, REAL* vessel_env, const REAL* rand_tab)
+                          const REAL* init, const REAL* ref, REAL* vessel_env, const REAL* rand_tab,
+                          REAL* current, REAL* current_mean, const REAL* cur_rand)
 {
     REAL eta[3], nu[3], ang[3], pt[3] = {R(0), R(0), R(0)};
     /* the episode counter advances with every reset that consumes random numbers (sampled pose, or drawn thrust) */
     const uint32_t ep = (uint32_t)counters[n + i];
-    if (!init || c->reset_acts || (rand_tab && vessel_env)) counters[n + i] += 1;
+    const int redraw_current = cur_rand && current;
+    if (!init || c->reset_acts || (rand_tab && vessel_env) || redraw_current) counters[n + i] += 1;
+    if (redraw_current) {
+        /* every reset starts its episode in a freshly drawn current: present value and the mean the drift reverts to */
+        REAL d[2];
+        FN(dpo_draw_current)(c, c->env_id_base + i, ep, cur_rand[2 + i], cur_rand[2 + n + i], cur_rand[0], cur_rand[1], d);
+        current[i] = d[0]; current[n + i] = d[1];
+        if (current_mean) { current_mean[i] = d[0]; current_mean[n + i] = d[1]; }
+    }
     if (rand_tab && vessel_env) {
         /* domain randomisation: every reset starts its episode on a freshly drawn hull */
         REAL pv[DPO_NPARAM];
@@ -492,11 +520,12 @@ static void FN(obs_of_state)(const dpo_config* c, int32_t n, int32_t i, const RE
 
 /* ENV:135-194.  mask NULL = all envs; init [6][n] SoA or NULL = sample; ref [3][n] or NULL = keep. */
 void FN(dpo_reset)(const dpo_config* c, int32_t n, REAL* state, int32_t* counters, const uint8_t* mask,
-                   const REAL* init, const REAL* ref, REAL* obs, REAL* vessel_env, const REAL* rand_tab)
+                   const REAL* init, const REAL* ref, REAL* obs, REAL* vessel_env, const REAL* rand_tab,
+                   REAL* current, REAL* current_mean, const REAL* cur_rand)
 {
     const int od = FN(dpo_obs_dim)(c);
     for (int32_t i = 0; i < n; ++i) {
-        if (!mask || mask[i]) FN(reset_one)(c, n, i, state, counters, init, ref, vessel_env, rand_tab);
+        if (!mask || mask[i]) FN(reset_one)(c, n, i, state, counters, init, ref, vessel_env, rand_tab, current, current_mean, cur_rand);
         if (obs) FN(obs_of_state)(c, n, i, state, obs + (int64_t)i * od);
     }
 }
@@ -530,9 +559,11 @@ static void FN(current_drift)(const dpo_config* c, int64_t gid, uint32_t* ctr, R
 
 void FN(dpo_step)(const dpo_config* c, const REAL* vessel, int32_t n, REAL* state, int32_t* counters,
                   const REAL* action, const REAL* new_ref, const REAL* plant_override, REAL* current,
-                  REAL* obs, REAL* rew, uint8_t* done, REAL* parts_out, REAL* final_obs, const REAL* current_mean,
-                  uint32_t* drift_ctr, REAL* vessel_env, const REAL* rand_tab)
+                  REAL* obs, REAL* rew, uint8_t* done, REAL* parts_out, REAL* final_obs, REAL* current_mean,
+                  uint32_t* drift_ctr, REAL* vessel_env, const REAL* rand_tab, const REAL* cur_rand)
 {
+    /* cur_rand { range_v, range_b | nominal V_c [n] | nominal beta_c [n] } or NULL: an auto-reset re-draws the env's current (after the drift
+     * step of the episode that ended: the new episode starts exactly on the drawn values) */
     /* vessel_env [DPO_NPARAM][n] or NULL: every env's OWN parameter vector (the kernels' per-env blocks) instead of the shared `vessel`;
      * rand_tab { nominal[32] | range[32] } or NULL: domain randomisation - an auto-reset re-draws the env's column of vessel_env */
     const int ad = FN(dpo_act_dim)(c), od = FN(dpo_obs_dim)(c);
@@ -581,7 +612,7 @@ void FN(dpo_step)(const dpo_config* c, const REAL* vessel, int32_t n, REAL* stat
         if (c->auto_reset && d) {
             /* ppo.py:305-322: finished envs are reset and the next policy input is the reset obs */
             if (final_obs) for (int k = 0; k < od; ++k) final_obs[(int64_t)i * od + k] = o[k];
-            FN(reset_one)(c, n, i, state, counters, (const REAL*)0, (const REAL*)0, vessel_env, rand_tab);
+            FN(reset_one)(c, n, i, state, counters, (const REAL*)0, (const REAL*)0, vessel_env, rand_tab, current, current_mean, cur_rand);
             FN(obs_of_state)(c, n, i, state, o);
         }
     }

@@ -170,17 +170,39 @@ class Oracle(object):
             assert vessel_env is not None
         return vessel_env, self._a(rand_tab, (2 * NPARAM,))
 
-    def reset(self, state, counters, mask=None, init=None, ref=None, vessel_env=None, rand_tab=None):
+    def draw_current(self, gid, episode, nom_v, nom_b, range_v, range_b):
+        """(V_c, beta_c) of episode `episode` of env `gid` under the per-episode randomisation of the current."""
+        out = np.zeros(2, self.dtype)
+        fn = self._f('dpo_draw_current')
+        ft = C.c_double if self.sfx == 'f64' else C.c_float
+        fn.argtypes = [C.c_void_p, C.c_int64, C.c_uint32, ft, ft, ft, ft, C.c_void_p]
+        fn(C.byref(self.cfg), int(gid), int(episode), float(nom_v), float(nom_b), float(range_v), float(range_b), _p(out))
+        return out
+
+    def _cur_rand(self, cur_rand, current, current_mean, n):
+        """cur_rand = (range_v, range_b, nominal_v [n], nominal_b [n]) -> the oracle's flat table; current / current_mean [2][n] are then
+        updated IN PLACE by every reset (pass contiguous arrays of the oracle's dtype)"""
+        if cur_rand is None:
+            return None
+        rv, rb, nv, nb = cur_rand
+        for x in (current, current_mean):
+            assert x is not None and x.dtype == self.dtype and x.flags.c_contiguous and x.shape == (2, n)
+        return np.ascontiguousarray(np.concatenate([[rv, rb], np.asarray(nv).reshape(n), np.asarray(nb).reshape(n)]), self.dtype)
+
+    def reset(self, state, counters, mask=None, init=None, ref=None, vessel_env=None, rand_tab=None, current=None, current_mean=None,
+              cur_rand=None):
         n = state.shape[1]
         obs = np.zeros((n, self.obs_dim), self.dtype)
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
         ve, rt = self._vessel_env(vessel_env, rand_tab, n)
+        cr = self._cur_rand(cur_rand, current, current_mean, n)
         self._f('dpo_reset')(C.byref(self.cfg), C.c_int32(n), _p(state), _p(counters), _p(m),
-                             _p(self._a(init, (6, n))), _p(self._a(ref, (3, n))), _p(obs), _p(ve), _p(rt))
+                             _p(self._a(init, (6, n))), _p(self._a(ref, (3, n))), _p(obs), _p(ve), _p(rt),
+                             _p(current if cr is not None else None), _p(current_mean if cr is not None else None), _p(cr))
         return obs
 
     def step(self, state, counters, action, new_ref=None, plant_override=None, current=None,
-             want_parts=False, want_final_obs=False, current_mean=None, drift_ctr=None, vessel_env=None, rand_tab=None):
+             want_parts=False, want_final_obs=False, current_mean=None, drift_ctr=None, vessel_env=None, rand_tab=None, cur_rand=None):
         """current [2][n] is updated IN PLACE when the config enables drift (pass a contiguous array of the
         oracle's dtype together with current_mean [2][n] and drift_ctr uint32[n])."""
         n = state.shape[1]
@@ -197,11 +219,12 @@ class Oracle(object):
             cur = current
         else:
             cur = self._a(current, (2, n))
+        cr = self._cur_rand(cur_rand, current, current_mean, n)         # (asserts that current / current_mean can be written in place)
         ve, rt = self._vessel_env(vessel_env, rand_tab, n)
         self._f('dpo_step')(C.byref(self.cfg), _p(self.vessel), C.c_int32(n), _p(state), _p(counters), _p(a),
                             _p(self._a(new_ref, (3, n))), _p(self._a(plant_override, (6, n))),
                             _p(cur), _p(obs), _p(rew), _p(done), _p(parts), _p(fobs),
-                            _p(self._a(current_mean, (2, n))), _p(drift_ctr), _p(ve), _p(rt))
+                            _p(current_mean if cr is not None else self._a(current_mean, (2, n))), _p(drift_ctr), _p(ve), _p(rt), _p(cr))
         out = [obs, rew, done]
         if want_parts:
             out.append(parts)
@@ -213,7 +236,7 @@ class Oracle(object):
         """step() writing into caller-provided arrays: nothing but the C loop runs (used for CPU timing)."""
         n = state.shape[1]
         self._f('dpo_step')(C.byref(self.cfg), _p(self.vessel), C.c_int32(n), _p(state), _p(counters), _p(action),
-                            _p(new_ref), None, None, _p(obs), _p(rew), _p(done), None, None, None, None, None, None)
+                            _p(new_ref), None, None, _p(obs), _p(rew), _p(done), None, None, None, None, None, None, None)
 
     def discount_cumsum(self, x, discount):
         x = self._a(x)

@@ -54,7 +54,8 @@ def test_plain_c_program_steps_the_env(tmp_path):
     assert abs(got[5]) < 1e-2 * n * T and abs(got[6] / (n * T) - 1.0) < 1e-3   # normalised: mean 0, variance 1
     # per-env vessels from the same C program: the thrust-loss preset through dpenv_create (read back exactly), explicit per-env blocks with
     # their own loss coefficients, then the randomisation around the preset - checksums against the same calls through the Python binding
-    v = re.search(r'vessels: (\d+) envs x (\d+) steps .* preset read back (\w+); per-env blocks: checksums obs (\S+) rew (\S+) table (\S+); '
+    assert 'refused calls left the handle alone' in out, out
+    v = re.search(r'vessels: (\d+) envs x (\d+) steps .* preset read back (\w+); refused calls left the handle alone; per-env blocks: checksums obs (\S+) rew (\S+) table (\S+); '
                   r'randomised: obs (\S+) rew (\S+) table (\S+)', out)
     assert v and v.group(3) == 'exactly', out
     n3, S3 = int(v.group(1)), int(v.group(2))

@@ -287,31 +287,5 @@ def test_thrust_loss_in_other_closed_loop_variants_runs_the_one_wave_kernels():
             assert torch.equal(r, out['rew'][t]) and torch.equal(d, out['done'][t]) and torch.equal(o, nxt), (mode, t)
 
 
-def test_set_vessel_params_refuses_a_capturing_stream():
-    """the setter reads one word back (does any env carry a thrust-loss coefficient?) and therefore synchronises: inside a stream capture
-    it returns DPENV_EINVAL instead of breaking the capture, and the handle is as it was"""
-    torch = torch_()
-    n = 256
-    env, _ = H.make_pair('final_cont', n)
-    hulls = H.to_dev(H.random_hulls(np.random.RandomState(0), n, loss=0.1))
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    raised = False
-    with torch.cuda.stream(side):
-        g = torch.cuda.CUDAGraph()
-        g.capture_begin()
-        try:
-            y = hulls * 1.0                                   # (a node, so that the graph is not empty)
-            try:
-                env.set_vessel_params(hulls)
-            except Exception as e:
-                raised = 'captur' in str(e)
-        finally:
-            g.capture_end()
-    torch.cuda.current_stream().wait_stream(side)
-    assert raised
-    with pytest.raises(Exception):
-        env.get_vessel_params()                               # no per-env blocks came into force
-    env.set_vessel_params(hulls)                              # and outside a capture it works
-    assert torch.equal(env.get_vessel_params(), hulls)
-    del y
+# (round 6: dpenv_set_vessel_params no longer reads a word back and CAN be recorded into a graph - tests/test_gpu_round6.py
+#  test_set_vessel_params_recorded_into_a_graph replaces the refusal test that stood here)

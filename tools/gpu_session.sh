@@ -29,7 +29,7 @@ bench_line() {   # name limit args...  -> $O/name.json (the ONE stdout line), $O
 for s in "$@"; do
     arg=; case $s in *=*) arg=${s#*=}; s=${s%%=*};; esac
     case $s in
-    tests|tests\?) step $s 1100 python3 -m pytest tests -q -m gpu -x $arg;;
+    tests|tests\?) case "$arg" in *tests/*) step $s 1100 python3 -m pytest -q -m gpu -x $arg;; *) step $s 1100 python3 -m pytest tests -q -m gpu -x $arg;; esac;;
     smoke) step smoke 300 python3 -c "import __graft_entry__ as g; g.smoke()";;
     bench) bench_line bench_default 500;;
     bench_driver) bench_line bench_driver_form 300 --steps 20 --warmup 5;;

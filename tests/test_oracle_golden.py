@@ -454,3 +454,37 @@ def test_inflow_thrust_loss_in_the_oracle():
     rt0 = rt.copy()
     rt0[26:32] = 0.0
     assert np.array_equal(o.draw_vessel(rt0, 3, 4)[:26], o.draw_vessel(rt, 3, 4)[:26]) and np.all(o.draw_vessel(rt0, 3, 4)[26:] == 0)
+
+
+def test_per_episode_current_draw_in_the_oracle():
+    """dpo_draw_current (round 6; build-owned like the drift): V_c = max(0, V_nom + r_V u1), beta_c = beta_nom + r_b u2 with u1, u2 the first two words
+    of Philox(seed; global env id, episode, tag 3) as 24-bit uniforms in [-1, 1) - spelled out here from the Philox primitive; uniform, independent,
+    f32 = f64 to rounding; and the reset path: present value and drift mean both take the draw, the episode counter advances even with explicit init."""
+    cfg = O.make_config(seed=0x1234_5678_9abc, current_enabled=1, env_id_base=7)
+    o64, o32 = O.Oracle(cfg, np.float64), O.Oracle(cfg, np.float32)
+    gid, ep = (1 << 33) + 5, 17
+    w = O.philox([gid & 0xffffffff, gid >> 32, ep, 3], [cfg.seed & 0xffffffff, cfg.seed >> 32])
+    u = [2.0 * (int(x) >> 8) / 16777216.0 - 1.0 for x in w[:2]]
+    d = o64.draw_current(gid, ep, 0.2, 2.356, 0.1, 0.785)
+    assert d[0] == 0.2 + 0.1 * u[0] and d[1] == 2.356 + 0.785 * u[1]
+    assert o64.draw_current(gid, ep, 0.05, 0.0, 0.5, 0.0)[0] >= 0.0                       # never a negative speed
+    draws = np.array([o64.draw_current(g, e, 0.2, 1.0, 0.1, 0.5) for g in range(400) for e in range(10)])
+    dv, db = (draws[:, 0] - 0.2) / 0.1, (draws[:, 1] - 1.0) / 0.5
+    for x in (dv, db):
+        assert -1.0 <= x.min() < -0.99 and 0.99 < x.max() < 1.0 and abs(x.mean()) < 0.03 and abs(x.std() - 1 / np.sqrt(3)) < 0.02
+    assert abs(np.corrcoef(dv, db)[0, 1]) < 0.05
+    d32 = np.array([o32.draw_current(g, 3, 0.2, 1.0, 0.1, 0.5) for g in range(200)])
+    d64 = np.array([o64.draw_current(g, 3, 0.2, 1.0, 0.1, 0.5) for g in range(200)])
+    assert np.abs(d32 - d64).max() < 2e-7
+    # through reset: masked, with explicit init
+    n = 64
+    st, ctr = o64.new_state(n)
+    cur = np.ascontiguousarray(np.stack([np.full(n, 0.2), np.full(n, 2.0)]))
+    mean = cur.copy()
+    cr = (0.1, 0.5, np.full(n, 0.2), np.full(n, 2.0))
+    mask = (np.arange(n) % 3 == 0).astype(np.uint8)
+    o64.reset(st, ctr, mask=mask, init=np.zeros((6, n)), current=cur, current_mean=mean, cur_rand=cr)
+    assert np.array_equal(ctr[1], mask.astype(np.int32)) and np.array_equal(cur, mean)
+    assert np.all(cur[0, mask == 0] == 0.2) and np.all(cur[0, mask == 1] != 0.2)
+    k = 3
+    assert np.array_equal(cur[:, k], o64.draw_current(cfg.env_id_base + k, 0, 0.2, 2.0, 0.1, 0.5))

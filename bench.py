@@ -175,6 +175,8 @@ def parse():
     ap.add_argument('--eager-loop', type=int, default=1, help='the eager-loop record (a Python `for` over env.step without a graph); 0 leaves it out - the profile '
                                                               'round does, because the leg launches the HEADLINE kernel ~14 000 times eagerly and a kernel-trace average '
                                                               'over all dispatches of that kernel would then be an average over two launch forms')
+    ap.add_argument('--multi-handle', type=int, default=1, help='the multi_handle record (independent chains); 0 leaves it out - the profile round does: its chains launch '
+                                                                'the HEADLINE instantiation at other batch sizes, which a per-kernel average of the trace would mix in')
     ap.add_argument('--init-timeout', type=float, default=180.0, help='seconds a rank waits for its peers in init_process_group / the first barrier '
                                                                        'before it gives up with a message and a non-zero exit code')
     ap.add_argument('--rendezvous-only', action='store_true', help='diagnostic: the ranks join the process group, exchange one all-reduce and rank 0 '
@@ -1354,7 +1356,7 @@ def main():
             classes = {'error': '%s: %s' % (type(e).__name__, e), 'traceback': traceback.format_exc()[-1500:]}
 
     multi = None
-    if rank == 0 and side_legs and world == 1:
+    if rank == 0 and side_legs and world == 1 and args.multi_handle:
         try:
             multi = multi_handle_record(dev, n)
         except Exception as e:       # pragma: no cover - a side record must not cost the line

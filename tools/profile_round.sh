@@ -14,13 +14,14 @@ pass() {      # name limit command...
     if [ $rc -ne 0 ]; then tail -n 5 $O/$name.err; echo "profile round $TAG ends at pass $name"; exit $rc; fi
 }
 # (--eager-loop 0 in every traced pass: the eager-loop record launches the headline kernel ~14 000 times EAGERLY - dispatch duration 6.0 us under the
-# tracer - which would turn the per-kernel average of the default, graph-replayed command into an average over two launch forms)
-pass kt 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- $B --no-cpu-baseline --eager-loop 0
+# tracer - which would turn the per-kernel average of the default, graph-replayed command into an average over two launch forms; --multi-handle 0
+# (round 6): the independent-chains record launches the headline instantiation at 16 384 ... 131 072 envs)
+pass kt 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- $B --no-cpu-baseline --eager-loop 0 --multi-handle 0
 # the headline kernel's own duration, unstretched: (i) eager launches (the host spaces them: every dispatch's timestamps are its own), (ii) a
 # 50-step graph replayed; the plain run above traces every node of the one long graph and is kept for the other kernels' durations
 pass kt_eager 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_eager -- $B --no-graph --steps 250 --warmup 50 --no-cpu-baseline --no-fused
 pass kt_g50 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_g50 -- $B --graph-steps 50 --steps 50 --warmup 50 --no-cpu-baseline --no-fused
-P="--steps 250 --warmup 50 --no-cpu-baseline --eager-loop 0"
+P="--steps 250 --warmup 50 --no-cpu-baseline --eager-loop 0 --multi-handle 0"
 pass pf 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $B $P
 pass pw 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $B $P
 pass sq 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $O/pmc_sq -- $B $P

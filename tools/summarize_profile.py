@@ -15,7 +15,7 @@ src = 'gpurun_out/prof_%s' % tag
 dst = sys.argv[2] if len(sys.argv) > 2 else 'profiles'       # on the GPU box: a directory under gpurun_out/, copied to profiles/ afterwards
 os.makedirs(dst, exist_ok=True)
 out = {'tag': tag, 'n_envs': 65536,
-       'commands': {'kernel_trace': 'rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --eager-loop 0 (the eager-loop record launches the headline kernel eagerly ~14 000 times: its dispatches are profiled on their own, headline_kernel_duration.eager)',
+       'commands': {'kernel_trace': 'rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --eager-loop 0 --multi-handle 0 (the eager-loop record launches the headline kernel eagerly ~14 000 times: its dispatches are profiled on their own, headline_kernel_duration.eager)',
                     'pmc': 'rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ_*> --output-format csv -- python3 bench.py --steps 250 --warmup 50 --no-cpu-baseline --eager-loop 0 (one pass per counter set)'},
        'correction': 'gfx950: FETCH_SIZE tallies 128-B requests of wide coalesced reads at 64 B -> x2 (MI355X_MICROARCH.md, HBM); '
                      'WRITE_SIZE exact; both in KiB', 'kernels': {}}
@@ -116,7 +116,7 @@ hd = {'what': 'step_kernel duration (End - Start timestamp of rocprofv3 --kernel
               'gives a fraction 5-6 % lower, by (1) 38 % higher.'}
 for form, sub, cmd in (('eager', 'kt_eager', 'bench.py --no-graph --steps 250 --warmup 50 --no-cpu-baseline --no-fused'),
                        ('graph_50_steps', 'kt_g50', 'bench.py --graph-steps 50 --steps 50 --warmup 50 --no-cpu-baseline --no-fused'),
-                       ('one_long_graph', 'kt', 'bench.py --no-cpu-baseline --eager-loop 0')):
+                       ('one_long_graph', 'kt', 'bench.py --no-cpu-baseline --eager-loop 0 --multi-handle 0')):
     f = glob.glob(src + '/%s/*/*_kernel_trace.csv' % sub)
     if not f:
         continue

@@ -42,10 +42,17 @@ def evaluate_actor(ac, dev, preset, precision, seed, out=print):
         [round(float(x), 1) for x in r['EpRet']], [int(x) for x in r['EpLen']]))
     res = {'EpRet_mean': float(r['EpRet'].mean()), 'EpLen_mean': float(r['EpLen'].float().mean())}
     T, nb = 1250, 1024
-    for tag, spread in (('nominal hull', 0.0), ('hulls +-15 %', 0.15), ('hulls +-30 %', 0.30), ('hulls +-50 %', 0.50)):
-        env = ml4ca_amd.BatchedRevoltEnv(nb, device=dev, terminate=False, time_limit=False, seed=seed + 77, vessel_params=nominal)
+    # (the last two rows: the thesis' current box test - 0.2 m/s towards 135 deg, results/all_plots/current_box_test/plot_pos.py:78 - and a spread
+    # of currents around it: +-0.1 m/s, +-90 deg, one draw per env)
+    for tag, spread, cur in (('nominal hull', 0.0, None), ('hulls +-15 %', 0.15, None), ('hulls +-30 %', 0.30, None), ('hulls +-50 %', 0.50, None),
+                             ('current 0.2 m/s @ 135 deg', 0.0, (0.0, 0.0)), ('currents 0.2 +-0.1 m/s, 135 +-90 deg', 0.0, (0.1, 1.5708))):
+        env = ml4ca_amd.BatchedRevoltEnv(nb, device=dev, terminate=False, time_limit=False, seed=seed + 77, vessel_params=nominal, current=cur is not None)
         if spread > 0:
             env.set_vessel_randomisation(spread, nominal=nominal)          # one draw per env at the reset below; no resets after it
+        if cur is not None:
+            env.set_current(torch.full((nb,), 0.2, device=dev), torch.full((nb,), 2.35619, device=dev))
+            if cur[0] > 0:
+                env.set_current_randomisation(cur[0], cur[1])              # one draw per env at the reset below
         ac.upload(env, precision=precision)
         start = torch.zeros((3, nb), device=dev)
         env.reset(init=torch.zeros((6, nb), device=dev), new_ref=start.clone())
@@ -86,6 +93,10 @@ def main():
     ap.add_argument('--randomise', type=float, default=0.0, help='R > 0: domain randomisation - every reset (also the ones inside the rollout launch) draws the '
                                                                   'new episode\'s hull: each of the 26 vessel parameters = nominal x (1 + R u), u ~ U[-1, 1), '
                                                                   'Philox keyed (seed; global env id, episode): independent of the rank count')
+    ap.add_argument('--current', default='', help="'V,BETA_DEG': train in a current (e.g. '0.2,135': the reference's one operating point, "
+                                                 'results/all_plots/current_box_test/plot_pos.py:78)')
+    ap.add_argument('--randomise-current', default='', help="'RV,RB_DEG' with --current: every reset (also inside the rollout launch) draws the new episode's current, "
+                                                           'V_c = max(0, V + RV u1), beta_c = BETA + RB u2 (dpenv_set_current_randomisation)')
     ap.add_argument('--preset', default='no_loss', choices=('no_loss', 'thrust_loss'), help='nominal hull (dpenv_default_vessel_ex)')
     ap.add_argument('--eval', action='store_true', help='after training: run_RL_policy + the box test (IAE, energy) on the nominal hull and on spreads of hulls')
     ap.add_argument('--eval-presets', default='', help="comma-separated presets to run --eval on (default: the training preset), e.g. 'no_loss,thrust_loss': "
@@ -105,10 +116,17 @@ def main():
         else:
             torch.distributed.init_process_group(args.backend)
     torch.manual_seed(args.seed + 1000 * rank)
-    env = ml4ca_amd.BatchedRevoltEnv(args.envs, auto_reset=True, seed=args.seed, device=dev, env_id_base=rank * args.envs,
+    env = ml4ca_amd.BatchedRevoltEnv(args.envs, auto_reset=True, seed=args.seed, device=dev, env_id_base=rank * args.envs, current=bool(args.current),
                                      vessel_params=ml4ca_amd.default_vessel(args.preset) if args.preset != 'no_loss' else None)   # final / ext / cont_ang
     if args.randomise > 0:
         env.set_vessel_randomisation(args.randomise, nominal=ml4ca_amd.default_vessel(args.preset))
+    if args.current:
+        import math
+        v_c, b_c = (float(x) for x in args.current.split(','))
+        env.set_current(torch.full((args.envs,), v_c, device=dev), torch.full((args.envs,), math.radians(b_c), device=dev))
+        if args.randomise_current:
+            r_v, r_b = (float(x) for x in args.randomise_current.split(','))
+            env.set_current_randomisation(r_v, math.radians(r_b))
     ac = ActorCritic(9, 7, (80, 80, 80), leak=0.2, seed=args.seed, device=dev, activation=args.activation)
     D.sync_params(ac.parameters())                                               # sync_all_params, ppo.py:255
     for p in ac.parameters():

@@ -240,9 +240,10 @@ int dpenv_get_current_mean(dpenv_handle h, float* vc_out, float* beta_out, dpenv
  * its episode like the pose sample and the hull draw - independent of the rank count and of the launch form.  The drawn values become the
  * present current AND the mean the drift (config.current_drift) reverts to.  vc_nominal, beta_nominal: DEVICE float[n_envs], copied; NULL =
  * the means in force (what dpenv_set_current gave).  Until its first reset an env keeps the current it has.  Needs config.current_enabled.
- * The re-draw lives where the hull re-draw lives, in the general per-env kernels: without per-env blocks in force the single class is
- * installed as per-env blocks (every env the same one; +160 B read per env-step of dpenv_step), vessel classes are refused; dpenv_set_vessel_
- * params(h, NULL, s) is refused while it is on.  Both ranges 0: off (currents stay as they are).  Like the hull randomisation, a dpenv_reset
+ * The re-draw lives in the kernels that carry re-draws: with ONE class, the shared training form (hull and thrust-loss coefficients - zero for
+ * a hull without a loss - as kernel arguments: the default's memory traffic, the default's rows until a reset draws); with per-env blocks in
+ * force, the general per-env kernels; vessel classes (n_classes > 1 without per-env blocks) are refused, and so is returning to them with
+ * dpenv_set_vessel_params(h, NULL, s) while it is on.  Both ranges 0: off (currents stay as they are).  Like the hull randomisation, a dpenv_reset
  * with explicit init then advances the episode counter too.  Stream-ordered, may be recorded into a graph. */
 int dpenv_set_current_randomisation(dpenv_handle h, const float* vc_nominal, const float* beta_nominal, float vc_range, float beta_range,
                                     dpenv_stream s);

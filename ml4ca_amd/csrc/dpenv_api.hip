@@ -442,7 +442,7 @@ extern "C" int dpenv_create(const dpenv_config* cfg, const float* vessel_params,
             any = any || a.kl[p] != 0.0f || a.kl[3 + p] != 0.0f;
         }
         e = hipMemcpy(h->raw0_dev, h->raw0, sizeof h->raw0, hipMemcpyHostToDevice);
-        if (e == hipSuccess && any) {
+        if (e == hipSuccess) {       // the table starts as the image of class 0 for every env (what the kernels without a shared form read)
             e = dpenv_dev_launch_pack_env_vessels(h->raw0_dev, 1, 0, h->env_tab, nullptr, h->env_stride, cfg->n_envs, nullptr);
             if (e == hipSuccess) e = hipDeviceSynchronize();
         }
@@ -555,21 +555,13 @@ extern "C" int dpenv_set_current_randomisation(dpenv_handle h, const float* vc_n
         return DPENV_OK;
     }
     if (!h->per_env && h->n_classes > 1)
-        return fail(h, DPENV_EINVAL, "the re-draw lives in the per-env kernels: with vessel classes give every env its block first (dpenv_set_vessel_params)");
+        return fail(h, DPENV_EINVAL, "the re-draw has no vessel-class form: with vessel classes give every env its block first (dpenv_set_vessel_params)");
     const size_t bytes = sizeof(float) * (size_t)h->cfg.n_envs;
     // NULL: the means in force - unless the randomisation is already on (then the means are drawn values: the nominals stay what they are)
     if (vc_nominal || !h->cur_rand)
         HIP_TRY(h, hipMemcpyAsync(h->cur_nom, vc_nominal ? vc_nominal : h->cur_vc0, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
     if (beta_nominal || !h->cur_rand)
         HIP_TRY(h, hipMemcpyAsync(h->cur_nom + h->env_stride, beta_nominal ? beta_nominal : h->cur_beta0, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
-    if (!h->per_env) {
-        // the single class as per-env blocks, every env the same one (with its thrust-loss coefficients, if it has any)
-        HIP_TRY(h, dpenv_dev_launch_pack_env_vessels(h->raw0_dev, 1, 0, h->env_tab, nullptr, h->env_stride, h->cfg.n_envs, (hipStream_t)s));
-        h->per_env = true;
-        h->randomise = false;
-        h->loss_pending = false;
-        h->loss_state = h->shared_loss ? LOSS_ON : LOSS_OFF;
-    }
     h->cur_rand = true;
     h->args.cur_range_v = vc_range;
     h->args.cur_range_b = beta_range;
@@ -607,20 +599,22 @@ static void bind_optional(dpenv_handle h, StepArgs& a, hipStream_t s)
     resolve_loss(h, s);
     a.env_tab = h->per_env ? h->env_tab : nullptr;
     a.env_stride = h->env_stride;
-    a.loss_on = h->per_env ? h->loss_state : (h->shared_loss ? (int)LOSS_SHARED : (int)LOSS_NONE);
+    // the per-episode current re-draw lives in the general per-env kernels and in the shared training form (one class)
+    const bool cr = h->cur_rand && h->cfg.current_enabled && (h->per_env || h->n_classes == 1);
+    a.loss_on = h->per_env ? h->loss_state : ((h->shared_loss || cr) ? (int)LOSS_SHARED : (int)LOSS_NONE);
     a.rand_tab = (h->per_env && h->randomise) ? h->rand_tab : nullptr;
-    const bool cr = h->per_env && h->cur_rand && h->cfg.current_enabled;
     a.cur_nom = cr ? h->cur_nom : nullptr;
     a.cur_nom_stride = h->env_stride;
 }
 
-// a kernel without a shared-loss instantiation on a handle whose single class has thrust-loss coefficients: its general per-env form, on the
-// table image of that hull (every env the same block)
+// a kernel without a shared training form (the one-wave closed loop; the two-wave closed loop of other env variants) on a handle that runs on it:
+// the thrust loss through the table image of the class hull (every env the same block) in its general per-env form, or no loss at all; the
+// current re-draw is a run-time switch in those kernels whatever the vessel's source
 static void bind_shared_loss_as_table(dpenv_handle h, StepArgs& a)
 {
     if (a.loss_on != LOSS_SHARED) return;
-    a.env_tab = h->env_tab;
-    a.loss_on = LOSS_TABLE;
+    if (h->shared_loss) { a.env_tab = h->env_tab; a.loss_on = LOSS_TABLE; }
+    else a.loss_on = LOSS_NONE;
 }
 
 // where the kernels take a lane's vessel from (dpenv_dev.h VES_*); call after bind_optional (which settles loss_state)
@@ -629,7 +623,8 @@ static int vessel_source(dpenv_handle h)
     if (h->per_env)
         return (h->randomise || h->loss_state != LOSS_OFF || (h->cur_rand && h->cfg.current_enabled)) ? VES_ENV_RND
                : (h->cfg.per_env_lds ? VES_ENV_LDS : VES_ENV_VGPR);
-    return h->n_classes > 1 ? VES_CLASS_LDS : (h->shared_loss ? VES_ARGS_LOSS : VES_ARGS);
+    if (h->n_classes > 1) return VES_CLASS_LDS;
+    return (h->shared_loss || (h->cur_rand && h->cfg.current_enabled)) ? VES_ARGS_LOSS : VES_ARGS;
 }
 
 static bool classes_missing(dpenv_handle h) { return !h->per_env && h->n_classes > 1 && !h->classes_assigned; }
@@ -646,12 +641,12 @@ extern "C" int dpenv_set_vessel_params_ex(dpenv_handle h, const float* params, u
     if (keep && (!params || !h->randomise))
         return fail(h, DPENV_EINVAL, "DPENV_VESSEL_KEEP_RANDOMISATION needs a table and the randomisation in force (dpenv_set_vessel_randomisation first)");
     if (!params) {
-        if (h->cur_rand)
-            return fail(h, DPENV_EINVAL, "the per-episode current randomisation lives in the per-env kernels: switch it off first "
+        if (h->cur_rand && h->n_classes > 1)
+            return fail(h, DPENV_EINVAL, "the per-episode current randomisation has no vessel-class form: switch it off first "
                                          "(dpenv_set_current_randomisation with both ranges 0)");
         // back to the classes / the single class; a single class WITH thrust-loss coefficients keeps them (kernel arguments), and the table
         // becomes the image of that hull again for the kernels that read it there
-        if (h->shared_loss && h->per_env)
+        if (h->per_env)
             HIP_TRY(h, dpenv_dev_launch_pack_env_vessels(h->raw0_dev, 1, 0, h->env_tab, nullptr, h->env_stride, h->cfg.n_envs, (hipStream_t)s));
         h->per_env = false;
         h->randomise = false;
@@ -688,7 +683,7 @@ extern "C" int dpenv_set_vessel_params(dpenv_handle h, const float* params, dpen
 extern "C" int dpenv_get_vessel_params(dpenv_handle h, float* params_out, dpenv_stream s)
 {
     if (!h || !params_out) return fail(h, DPENV_EINVAL, "dpenv_get_vessel_params: NULL argument");
-    if (!h->per_env && !h->shared_loss)
+    if (!h->per_env && h->n_classes > 1)
         return fail(h, DPENV_EINVAL, "no per-env parameter blocks in force (dpenv_set_vessel_params / dpenv_set_vessel_randomisation)");
     DeviceGuard dev_guard(h->device);
     HIP_TRY(h, dpenv_dev_launch_unpack_env_vessels(h->env_tab, h->env_stride, params_out, h->cfg.n_envs, (hipStream_t)s));

@@ -64,14 +64,15 @@ enum { VES_ARGS = 0,      // one class: kernel arguments (SGPRs)
        VES_ENV_RND = 4,   // the GENERAL per-env form: VES_ENV_VGPR + the domain randomisation's hull re-draw in the reset paths (while StepArgs.rand_tab)
                           //   + the inflow thrust loss (while StepArgs.loss_on).  Its own instantiation: the draw's four Philox blocks cost the register
                           //   allocation of the other forms 15-70 VGPRs when they share the code, the loss 10-16
-       VES_ARGS_LOSS = 5 }; // one class WITH thrust-loss coefficients (round 6): hull and coefficients as kernel arguments (StepArgs.v0, StepArgs.kl; SGPRs) -
-                          //   the regime the reference trains in (customEnv.py:17,26) at the default's memory traffic, not at 160 B per env-step of
-                          //   identical per-env blocks
+       VES_ARGS_LOSS = 5 }; // the SHARED training form (round 6): one class, hull AND the six thrust-loss coefficients as kernel arguments (StepArgs.v0,
+                          //   StepArgs.kl; SGPRs; zeros = no loss: the default's rows bit for bit) + the per-episode current re-draw in the reset
+                          //   paths (while StepArgs.cur_nom) - the regime the reference trains in (customEnv.py:17,26) and a randomised current at
+                          //   the default's memory traffic, not at 160 B per env-step of identical per-env blocks
 // StepArgs.loss_on
 enum { LOSS_NONE = 0,     // no thrust loss anywhere
        LOSS_TABLE = 1,    // some env of the per-env table has a coefficient (the host knows)
        LOSS_TABLE_FLAG = 2, // ask the table: the word behind it, written by pack_env_vessels_kernel (thrust_loss_on, dpenv_env_dev.h)
-       LOSS_SHARED = 3 }; // the single class's coefficients in StepArgs.kl: only kernels instantiated for it are launched with this value
+       LOSS_SHARED = 3 }; // the single class's coefficients in StepArgs.kl (possibly all zero): only kernels instantiated for it are launched with this value
 
 struct StepArgs {
     // library-owned state streams (see dpenv_kernels.hip header)

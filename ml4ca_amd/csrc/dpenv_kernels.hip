@@ -50,7 +50,7 @@ constexpr int STEP_TRACE_RING = 8;
 // every launch holds a finished env, so every launch paid for the draw; tools/step_placement.py).  Same
 // functions on the same inputs: every row is bit-identical to the one-wave form.
 constexpr int RESETW_FIELDS = 18;       // N, E, psi | o[0..8] | pt[0..2] | sin psi, cos psi | episode counter (bits)
-constexpr int RESETW_FIELDS_RND = 20;   // the general per-env form: | the new episode's current V_c, beta_c (dpenv_set_current_randomisation)
+constexpr int RESETW_FIELDS_RND = 20;   // the general per-env form and the shared training form (VES 4, 5): | the new episode's current V_c, beta_c
 
 template <int MODE>
 __device__ __forceinline__ void reset_wave(const StepArgs& a, float* lds, int lane, int blk)
@@ -104,12 +104,13 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(const 
     constexpr bool RND = VES == VES_ENV_RND;            // domain randomisation: a reset re-draws the hull (and the current)
     constexpr bool ENV_VGPR = VES == VES_ENV_VGPR || RND;
     constexpr int IL = VES == VES_ARGS_LOSS ? IL_SHARED : IL_NONE;    // (RND: the lane's own row of the table)
+    constexpr bool CURR = RND || VES == VES_ARGS_LOSS;                // the forms that re-draw the current with the episode (dpenv_set_current_randomisation)
     static_assert(!RESETW || BLOCK == 64, "the reset wave pairs with ONE env wave");
     static_assert(VES != VES_ENV_LDS || BLOCK == 64, "the LDS-DMA image is [group][lane] of one wave");
     __shared__ float lds_io[BLOCK * 9];
     __shared__ float lds_cls[PER_CLASS ? VD_COUNT * MAX_CLASSES : 1];
     __shared__ float4 lds_pe[VES == VES_ENV_LDS ? ENV_GROUPS * 64 : 1];
-    __shared__ float lds_rst[RESETW ? (RND ? RESETW_FIELDS_RND : RESETW_FIELDS) * 64 : 1];
+    __shared__ float lds_rst[RESETW ? (CURR ? RESETW_FIELDS_RND : RESETW_FIELDS) * 64 : 1];
     __shared__ uint32_t lds_fin[RESETW ? 64 : 1];      // env wave -> reset wave: this env finished and is being re-drawn
 
     if (RESETW && threadIdx.x >= BLOCK) {
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(const 
         const bool rnd = RND && a.rand_tab != nullptr;  // (the general per-env kernel also serves fixed hulls with a thrust loss)
         if (rnd)
             draw_env_groups(hull_key(a), a.env_id_base + i, __float_as_uint(lds_rst[17 * 64 + lane]), [&](int g, const float4& q) { hull[g] = q; });
-        if (RND && a.cur_nom) {                         // the current of the episode that would start now
+        if (CURR && a.cur_nom) {                        // the current of the episode that would start now
             const float2 cd = current_draw(a, i, i < a.n ? i : a.n - 1, __float_as_uint(lds_rst[17 * 64 + lane]));
             lds_rst[18 * 64 + lane] = cd.x; lds_rst[19 * 64 + lane] = cd.y;
         }
@@ -266,14 +267,14 @@ __global__ __launch_bounds__(RESETW ? 2 * BLOCK : BLOCK) void step_kernel(const 
         a.episode[i] = (int)(ep + 1u);
         if (RESETW) {
             reset_from_lds<MODE>(lds_rst, tid, s, o_next);
-            if (RND && a.cur_nom) {                                  // the new episode's current, drawn by the reset wave: present value and drift mean
+            if (CURR && a.cur_nom) {                                 // the new episode's current, drawn by the reset wave: present value and drift mean
                 const float v = lds_rst[18 * 64 + tid], b = lds_rst[19 * 64 + tid];
                 a.cur_vc[i] = v; a.cur_beta[i] = b; a.cur_vc0[i] = v; a.cur_beta0[i] = b;
             }
         } else {
             env_auto_reset<MODE>(a, s, a.env_id_base + i, ep, o_next);
             if (RND && a.rand_tab) redraw_vessel_table(a, i, ep);   // domain randomisation: the new episode's hull (the reset wave does this in the two-wave form)
-            if (RND && a.cur_nom) {
+            if (CURR && a.cur_nom) {
                 const float2 cd = current_draw(a, i, i, ep);
                 a.cur_vc[i] = cd.x; a.cur_beta[i] = cd.y; a.cur_vc0[i] = cd.x; a.cur_beta0[i] = cd.y;
             }
@@ -327,6 +328,7 @@ __global__ __launch_bounds__(RBLOCK) void rollout_kernel(const StepArgs a, const
     constexpr int OD = EXT ? 9 : 6;
     constexpr bool PER_CLASS = VES == VES_CLASS_LDS, RND = VES == VES_ENV_RND, PER_ENV = VES == VES_ENV_VGPR || RND;
     constexpr int IL = VES == VES_ARGS_LOSS ? IL_SHARED : IL_NONE;
+    constexpr bool CURR = RND || VES == VES_ARGS_LOSS;
     __shared__ float lds_act[RBLOCK * 7];
     __shared__ float lds_obs[RBLOCK * 9];
     __shared__ float lds_cls[PER_CLASS ? VD_COUNT * MAX_CLASSES : 1];
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(RBLOCK) void rollout_kernel(const StepArgs a, const
         if (a.auto_reset && out.d != 0u && live) {
             env_auto_reset<MODE>(a, s, a.env_id_base + i, episode, o_next);
             if (RND && a.rand_tab) redraw_vessel(a, i, episode, ve);   // domain randomisation: the new episode runs on a new hull
-            if (RND && a.cur_nom) { current_redraw_inline(a, i, episode, cur, vc0, beta0); cur_dirty = true; }   // ... in a new current
+            if (CURR && a.cur_nom) { current_redraw_inline(a, i, episode, cur, vc0, beta0); cur_dirty = true; }  // ... in a new current
             ++episode; ep_dirty = true; rf_dirty = true;
         }
         lag[0] = o_next[6]; lag[1] = o_next[7]; lag[2] = o_next[8];
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(RBLOCK) void rollout_kernel(const StepArgs a, const
         if (EXT) a.S3[i] = make_float4(lag[0], lag[1], lag[2], 0.0f);          // thrust columns of the last observation returned (see step_kernel)
         if (ep_dirty) a.episode[i] = (int)episode;
         if (a.current_drift) { a.cur_vc[i] = cur.vc; a.cur_beta[i] = cur.beta; a.drift_ctr[i] = cur.ctr; }
-        if (RND && cur_dirty) store_current(a, i, cur, vc0, beta0, true);
+        if (CURR && cur_dirty) store_current(a, i, cur, vc0, beta0, true);
     }
 }
 
@@ -494,6 +496,7 @@ __global__ __launch_bounds__(128) void rollout_ws_kernel(const StepArgs a, const
     constexpr int OD = EXT ? 9 : 6;
     constexpr bool PER_CLASS = VES == VES_CLASS_LDS, RND = VES == VES_ENV_RND, PER_ENV = VES == VES_ENV_VGPR || RND;
     constexpr int IL = VES == VES_ARGS_LOSS ? IL_SHARED : IL_NONE;
+    constexpr bool CURR = RND || VES == VES_ARGS_LOSS;
     __shared__ float act_mb[2][64 * 7];          // a_t rows by step parity, [lane * A + k]
     __shared__ float post_mb[2][64 * 9];         // o_t+1 rows (pre-reset) by step parity, [lane * OD + k]: also the staged image of the row store
     __shared__ uint32_t done_mb[2][64];
@@ -556,7 +559,7 @@ __global__ __launch_bounds__(128) void rollout_ws_kernel(const StepArgs a, const
 #pragma unroll
             for (int k = 0; k < 3; ++k) { rec_pt[k] = s.pt[k]; rec_mb[(12 + k) * 64 + lane] = s.pt[k]; }
             rec_mb[15 * 64 + lane] = s.sn; rec_mb[16 * 64 + lane] = s.cs;
-            if (RND) rec_mb[17 * 64 + lane] = __uint_as_float(episode);        // the env wave draws the new episode's current from it
+            if (CURR) rec_mb[17 * 64 + lane] = __uint_as_float(episode);       // the env wave draws the new episode's current from it
             ++version;
             mb_post(&seq[2], version, lane);
         };
@@ -729,7 +732,7 @@ __global__ __launch_bounds__(128) void rollout_ws_kernel(const StepArgs a, const
                                          make_float4(hull_mb[(4 * g + 0) * 64 + lane], hull_mb[(4 * g + 1) * 64 + lane],
                                                      hull_mb[(4 * g + 2) * 64 + lane], hull_mb[(4 * g + 3) * 64 + lane]));
                 }
-                if (RND && a.cur_nom) { current_redraw_inline(a, i, __float_as_uint(rec_mb[17 * 64 + lane]), cur, vc0, beta0); cur_dirty = true; }
+                if (CURR && a.cur_nom) { current_redraw_inline(a, i, __float_as_uint(rec_mb[17 * 64 + lane]), cur, vc0, beta0); cur_dirty = true; }
                 rf_dirty = true;
             }
             ++need;
@@ -745,7 +748,7 @@ __global__ __launch_bounds__(128) void rollout_ws_kernel(const StepArgs a, const
     if (live) {
         store_env(a, i, s, rf_dirty);
         if (a.current_drift) { a.cur_vc[i] = cur.vc; a.cur_beta[i] = cur.beta; a.drift_ctr[i] = cur.ctr; }
-        if (RND && cur_dirty) store_current(a, i, cur, vc0, beta0, true);
+        if (CURR && cur_dirty) store_current(a, i, cur, vc0, beta0, true);
     }
 }
 

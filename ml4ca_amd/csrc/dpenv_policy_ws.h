@@ -70,13 +70,15 @@ __device__ __forceinline__ void ws_wait(int* p, int v)
 #define WS_EVAL(W_, B_, f0_, f1_) mlp_eval<KA>(W_, B_, pa.n_hidden, f0_, f1_, leak, outv)
 //  RND: the domain randomisation's hull re-draw compiled into the reset branch (instantiated for the shipped training configuration only -
 //  final variant, continuous angles, extended state, leaky-relu - see dpenv_ws_launch::pick and dpenv_env_dev.h redraw_vessel_cold).
-//  SLOSS (round 6): the single class's thrust-loss coefficients from the kernel arguments (StepArgs.kl, LOSS_SHARED) - the thrust-loss preset
-//  on the shared hull, without per-env blocks; same configurations as RND.
+//  SLOSS (round 6): the SHARED training form - the single class's thrust-loss coefficients from the kernel arguments (StepArgs.kl, LOSS_SHARED;
+//  zeros for a hull without a loss: the rows of the default kernels bit for bit) and the per-episode current re-draw: the thrust-loss preset and /
+//  or dpenv_set_current_randomisation on the shared hull, without per-env blocks; same configurations as RND.
 template <int MODE, bool EXT, int KA, int ROLES, int PREC = PREC_F16, int GROUPS = 4, bool RND = false, bool SLOSS = false>
 __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(const StepArgs a, const PolicyArgs pa)
 {
     static_assert(!(RND && SLOSS), "per-env blocks carry their own coefficients");
     constexpr int IL = SLOSS ? IL_SHARED : IL_NONE;
+    constexpr bool CURR = RND || SLOSS;            // the forms that re-draw the current with the episode
     constexpr int A = ModeTraits<MODE>::A;
     constexpr int OD = EXT ? 9 : 6;
     constexpr int THREADS = 64 * GROUPS * ROLES;
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
         for (int k = 0; k < 9; ++k) o[k] = out.o[k];
         // ppo.py:305-322 with reset_at_end: after the LAST step of the block every env is cut and re-drawn, ended or not
         const bool do_reset = ((a.auto_reset && out.d != 0u) || (pa.reset_at_end && t == pa.T - 1)) && live;
-        float new_vc = 0.0f, new_beta = 0.0f;                               // RND: the re-drawn env's new current (dpenv_set_current_randomisation)
+        float new_vc = 0.0f, new_beta = 0.0f;                               // CURR: the re-drawn env's new current (dpenv_set_current_randomisation)
         const bool terminal = (out.d & DONE_TERMINAL) != 0u;
         const bool ended = (out.d != 0u) || (t == pa.T - 1);
         boot_wanted = ended && !terminal;                                    // ppo.py:311
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
                 else if constexpr (RND) { if (a.rand_tab) redraw_vessel_cold(a, i, episode, ve); }
                 // ... in a new current: drawn here, put in force behind this step's drift update below (the drift of step t belongs to the episode
                 // that ended - dpenv_step applies it before the reset -, the new episode starts exactly on the drawn values)
-                if constexpr (RND) { if (a.cur_nom) { const float2 cd = current_redraw_call(a.cur_nom, a.cur_nom_stride, a.cur_range_v, a.cur_range_b, a.seed_lo, a.seed_hi, a.env_id_base + i, i, episode); new_vc = cd.x; new_beta = cd.y; } }
+                if constexpr (CURR) { if (a.cur_nom) { const float2 cd = current_redraw_call(a.cur_nom, a.cur_nom_stride, a.cur_range_v, a.cur_range_b, a.seed_lo, a.seed_hi, a.env_id_base + i, i, episode); new_vc = cd.x; new_beta = cd.y; } }
                 ++episode; ep_dirty = true; rf_dirty = true;
             }
         }
@@ -499,7 +501,7 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
         if constexpr (DEFER) env_step_finish<MODE, EXT, true>(a, s, act, rest, !do_reset, out);   // reward, azimuths of a continuing env
         logp = action_logp<A>(pc, mu, act);                                  // core.py:42-46 on (a_t, mu_t)
         if (a.current_drift) current_drift_step(a, cur, vc0, beta0, a.env_id_base + i);   // the current of step t+1: not needed by o_t+1
-        if constexpr (RND) { if (a.cur_nom && do_reset) { cur.vc = new_vc; cur.beta = new_beta; vc0 = new_vc; beta0 = new_beta; current_components(cur); } }
+        if constexpr (CURR) { if (a.cur_nom && do_reset) { cur.vc = new_vc; cur.beta = new_beta; vc0 = new_vc; beta0 = new_beta; current_components(cur); } }
         put_rows_a(pa.act_out, (int64_t)t * stride_a, act);
         if (t + 1 < pa.T) put_rows_o(pa.obs_out, (int64_t)(t + 1) * stride_o, o);
         if (live) {
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(64 * GROUPS * ROLES) void policy_rollout_ws_kernel(
         if (EXT) a.S3[i] = make_float4(o[6], o[7], o[8], 0.0f);
         if (ep_dirty) a.episode[i] = (int)episode;
         if (a.current_drift) { a.cur_vc[i] = cur.vc; a.cur_beta[i] = cur.beta; a.drift_ctr[i] = cur.ctr; }
-        if constexpr (RND) { if (a.cur_nom && ep_dirty) store_current(a, i, cur, vc0, beta0, true); }
+        if constexpr (CURR) { if (a.cur_nom && ep_dirty) store_current(a, i, cur, vc0, beta0, true); }
         if (draw) a.noise_ctr[i] = nctr;
     }
 }

@@ -512,11 +512,53 @@ def test_current_randomisation_argument_checks():
         with pytest.raises(RuntimeError, match='half-ranges'):
             e1.set_current_randomisation(*bad)
     e1.set_current_randomisation(0.05, 0.2)
-    with pytest.raises(RuntimeError, match='switch it off first'):
-        e1.set_vessel_params(None)
+    e1.set_vessel_params(None)                                # one class: the shared training form carries the re-draw
     e1.set_current_randomisation(0.0, 0.0)
-    e1.set_vessel_params(None)
     vp = np.tile(np.asarray(ml4ca_amd.default_vessel(), np.float32), (2, 1))
     e2 = ml4ca_amd.BatchedRevoltEnv(n, current=True, vessel_params=vp)
-    with pytest.raises(RuntimeError, match='vessel classes'):
+    with pytest.raises(RuntimeError, match='vessel-class form'):
         e2.set_current_randomisation(0.05, 0.2)
+    e2.set_vessel_params(torch.from_numpy(np.tile(vp[0][:, None], (1, n))).to(e2.device))      # per-env blocks: now it may ...
+    e2.set_current_randomisation(0.05, 0.2)
+    with pytest.raises(RuntimeError, match='switch it off first'):                               # ... and the classes may not come back under it
+        e2.set_vessel_params(None)
+
+
+@pytest.mark.parametrize('loss', [False, True])
+def test_current_randomisation_on_the_shared_hull_equals_the_per_env_form(loss):
+    """one class + dpenv_set_current_randomisation runs the shared training form (step_kernel<.., VES_ARGS_LOSS>, coefficients zero without a loss);
+    the same hull as per-env blocks runs the general per-env form: the same rows, states and currents bit for bit - and, without a loss, until
+    the first reset the rows of a plain default handle in the same (fixed) current"""
+    torch = torch_()
+    n = 1500 + 7
+    rng = np.random.RandomState(3)
+    hull = preset() if loss else None
+    kw = dict(auto_reset=True, max_ep_len=8, seed=9, vessel_params=hull)
+    a, _, cr = _cur_pair(n, drift=True, **kw)
+    b, _, _ = _cur_pair(n, drift=True, **kw)
+    import ml4ca_amd
+    b.set_vessel_params(np.asarray(ml4ca_amd.default_vessel('thrust_loss' if loss else 'no_loss'), np.float32))
+    for e in (a, b):
+        e.reset()
+    for t in range(20):
+        act = H.to_dev(H.random_actions(rng, n, 7, scale=1.0))
+        oa, ra, da, _ = a.step(act)
+        ob, rb, db, _ = b.step(act)
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db), t
+    sa, sb = a.get_state(), b.get_state()
+    assert torch.equal(sa[0], sb[0]) and torch.equal(sa[1], sb[1]) and int(sa[1][1].min()) >= 3
+    ca, cb = _currents(a), _currents(b)
+    assert np.array_equal(ca[0], cb[0]) and np.array_equal(ca[1], cb[1])
+    if not loss:
+        c, _ = H.make_pair('final_cont', n, current=True, seed=9)                 # a default handle: plain kernels, no re-draw
+        d, _, _ = _cur_pair(n, seed=9)
+        d.reset(); c.reset()
+        v, bta = d.get_current()
+        c.set_current(v.clone(), bta.clone())
+        st, ctr = d.get_state()
+        c.set_state(st, ctr)
+        for t in range(5):
+            act = H.to_dev(H.random_actions(rng, n, 7))
+            oc, rc, dc, _ = c.step(act)
+            od, rd, dd, _ = d.step(act)
+            assert torch.equal(oc, od) and torch.equal(rc, rd) and torch.equal(dc, dd), t

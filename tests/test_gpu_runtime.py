@@ -324,3 +324,19 @@ def test_bench_two_ranks_started_by_bench_itself_on_one_gpu():
         assert leg in c4, leg
     assert c4['exchange_76B']['recv_GBps_per_rank'] > 0 and c4['exchange_compact']['alone']['recv_GBps_per_rank'] > 0
     assert {'chunks_1', 'chunks_4', 'chunks_8'} <= set(c4['exchange_compact'])
+
+
+def test_bench_side_records_cannot_cost_the_headline_line():
+    """bench.py --side-timeout: a per-rank watchdog ends a run whose side records do not finish (a hung collective of the config-4 record on a node
+    it was never run on) with the exit code of a successful run - the ONE stdout line is already out, stderr says what happened."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--envs', '8192', '--steps', '20', '--warmup', '5', '--cpu-seconds', '0.6',
+                        '--side-timeout', '0.2', '--side-json', '/tmp/bench_side_watchdog.json'], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1 and 'roofline' in json.loads(lines[0]) and 'cpu_baseline' in json.loads(lines[0])
+    assert 'side records still running after' in p.stderr and 'exit code 0' in p.stderr

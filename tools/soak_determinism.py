@@ -2,7 +2,9 @@
 """Soak: the closed loop at full size (65 536 envs, auto-reset, drifting current, in-kernel noise) run TWICE from the same seed in every
 network arithmetic / launch form - every row of every launch must be identical between the two runs (any timing-dependent fault, e.g. a
 missing wait state beside the matrix pipe, shows up as a difference), everything finite, no fault bits.
-Usage: python tools/soak_determinism.py [launches=60] [randomise=0] [preset=no_loss]     randomise R > 0 (round 5): hulls re-drawn at every reset inside
+Usage: python tools/soak_determinism.py [launches=60] [randomise=0] [preset=no_loss] [current=0]    current C > 0 (round 6): every reset also draws the
+episode's current, 0.2 +- C m/s from any direction (dpenv_set_current_randomisation: the shared training form with one class, the general per-env
+kernels with randomised hulls); the currents join the digest.  randomise R > 0 (round 5): hulls re-drawn at every reset inside
 the launches (the RND instantiations of the two-wave kernels, the function-call draw of the one-wave kernels); the table of hulls joins the digest.
 preset thrust_loss: the nominal hull carries inflow thrust-loss coefficients (the general per-env kernels apply them; with R = 0 every env runs on the
 preset itself, installed as per-env blocks)"""
@@ -18,6 +20,7 @@ from ml4ca_amd.policy import ActorCritic, policy_rollout
 launches = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 randomise = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
 preset = sys.argv[3] if len(sys.argv) > 3 else 'no_loss'
+cur_rand = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
 nominal = ml4ca_amd.default_vessel(preset)
 T = 50
 # round 3: every arithmetic in both launch forms, at 65 536 envs (256-env workgroups) and 32 768 envs (128-env workgroups); the one-wave form
@@ -32,6 +35,8 @@ for n, prec, form in [(nn, p, f) for nn in (65536, 32768) for p in ('f16', 'f32_
         env.set_current(torch.full((n,), 0.2, device=env.device), torch.full((n,), 2.356, device=env.device))
         if randomise > 0:
             env.set_vessel_randomisation(randomise, nominal=nominal)
+        if cur_rand > 0:
+            env.set_current_randomisation(cur_rand, 3.14159)
         env.reset()
         dig = []
         for _ in range(launches):
@@ -43,10 +48,12 @@ for n, prec, form in [(nn, p, f) for nn in (65536, 32768) for p in ('f16', 'f32_
         dig.append((int(st.view(torch.int32).to(torch.int64).sum()), int(ctr.to(torch.int64).sum())))
         if randomise > 0 or preset != 'no_loss':
             dig.append((int(env.get_vessel_params().view(torch.int32).to(torch.int64).sum()),))
+        if cur_rand > 0:
+            dig.append(tuple(int(x.view(torch.int32).to(torch.int64).sum()) for x in env.get_current() + env.get_current_mean()))
         digests.append(dig)
     same = digests[0] == digests[1]
     cross = ref.setdefault((n, prec), digests[0]) == digests[0]
-    print('%-9s %-8s %d launches x %d steps x %d envs%s: two runs %s%s' % (prec, form, launches, T, n, (' (hulls re-drawn)' if randomise > 0 else '') + (' [%s]' % preset if preset != 'no_loss' else ''), 'IDENTICAL' if same else 'DIFFER',
+    print('%-9s %-8s %d launches x %d steps x %d envs%s: two runs %s%s' % (prec, form, launches, T, n, (' (hulls re-drawn)' if randomise > 0 else '') + (' (currents re-drawn)' if cur_rand > 0 else '') + (' [%s]' % preset if preset != 'no_loss' else ''), 'IDENTICAL' if same else 'DIFFER',
                                                                         '' if form == 'two_wave' else (', = the two-wave form' if cross else ', DIFFERS from the two-wave form')))
     if not cross:
         sys.exit(1)

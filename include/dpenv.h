@@ -159,7 +159,13 @@ int dpenv_default_vessel(float params[DPENV_NPARAM]);
  * DPENV_P_KLR_*) from +1.4 / -1.1 m/s ahead / astern "with thrust losses" (the velocity bounds the reference trains with, customEnv.py:26);
  * yaw then comes out at 0.505 rad/s against the recorded 0.52 (tests/calibration/fit_thrust_loss_preset.py).  Pass the vector to
  * dpenv_create (one class), in a dpenv_set_vessel_params block, or as `nominal` to dpenv_set_vessel_randomisation. */
-enum { DPENV_VESSEL_NO_LOSS = 0, DPENV_VESSEL_THRUST_LOSS = 1 };
+enum { DPENV_VESSEL_NO_LOSS = 0, DPENV_VESSEL_THRUST_LOSS = 1,
+       /* round 6, a FLAG (combine with THRUST_LOSS: 3): the sway-yaw part of the hull (m22, Yv, Yvv, Yr, Nv, Nr, Nrr, Yur) refitted jointly to
+        * what the default hull is fitted to AND to the reference's 32 recorded Cybersea station-keeping runs in a current from 16 directions
+        * (results/all_plots/dyn_pos/) AND to the recorded steady sway speed: sway 0.350 m/s (recorded 0.35; default hull 0.29), yaw 0.605, the
+        * station-keeping yaw-moment residual halved, at 0.01-0.02 m on the free-drift / box-test / replay rows
+        * (tests/calibration/fit_dynpos_preset.py).  Not the default: every row the default hull has produced stays. */
+       DPENV_VESSEL_DYNPOS_FIT = 2 };
 int dpenv_default_vessel_ex(int32_t kind, float params[DPENV_NPARAM]);
 /* Derived sizes for a config. */
 int dpenv_act_dim(const dpenv_config* cfg);

@@ -163,12 +163,13 @@ def default_config():
     return cfg
 
 
-VESSEL_NO_LOSS, VESSEL_THRUST_LOSS = 0, 1
+VESSEL_NO_LOSS, VESSEL_THRUST_LOSS, VESSEL_DYNPOS_FIT = 0, 1, 2        # DYNPOS_FIT is a flag: 3 = both
 
 
 def default_vessel(kind='no_loss'):
     """Parameter vector of a preset of the build-owned plant: 'no_loss' (the default hull) or 'thrust_loss' (dpenv.h: DPENV_VESSEL_*)."""
     import numpy as np
     p = (C.c_float * NPARAM)()
-    check(load().dpenv_default_vessel_ex({'no_loss': VESSEL_NO_LOSS, 'thrust_loss': VESSEL_THRUST_LOSS}[kind], p))
+    check(load().dpenv_default_vessel_ex({'no_loss': VESSEL_NO_LOSS, 'thrust_loss': VESSEL_THRUST_LOSS, 'dynpos_fit': VESSEL_DYNPOS_FIT,
+                                         'dynpos_fit_thrust_loss': VESSEL_DYNPOS_FIT | VESSEL_THRUST_LOSS}[kind], p))
     return np.array(p[:], dtype=np.float32)

@@ -94,6 +94,7 @@ typedef struct dpo_config {
     int  dpo_obs_dim_##suffix(const dpo_config* c);                                                    \
     void dpo_default_vessel_##suffix(REAL* p);                                                         \
     void dpo_thrust_loss_vessel_##suffix(REAL* p);                                                     \
+    void dpo_dynpos_fit_vessel_##suffix(REAL* p);                                                      \
     void dpo_decode_##suffix(const dpo_config* c, const REAL* action, const REAL ang_in[3],            \
                              REAL thrust_out[3], REAL ang_out[3]);                                     \
     void dpo_thrust_map_##suffix(const REAL* vessel, const REAL n_pct[3], const REAL alpha[3],         \

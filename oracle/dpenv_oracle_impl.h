@@ -87,6 +87,17 @@ void FN(dpo_thrust_loss_vessel)(REAL* p)
     p[DPO_P_KLF_BOW] = p[DPO_P_KLR_BOW] = R(THRUST_LOSS_KL_BOW);
 }
 
+/* BUILD-OWNED third preset (round 6; tests/calibration/fit_dynpos_preset.py): the sway-yaw part of the hull refitted jointly to the default's
+ * records, the 32 recorded Cybersea station-keeping runs (results/all_plots/dyn_pos/) and the recorded steady sway speed (ENV:14: 0.35 m/s) */
+void FN(dpo_dynpos_fit_vessel)(REAL* p)
+{
+    FN(dpo_default_vessel)(p);
+    p[DPO_P_M22] = R(317.3); p[DPO_P_M33] = R(300.0);
+    p[DPO_P_YV] = R(21.4); p[DPO_P_YVV] = R(54.3); p[DPO_P_YR] = R(-4.9);
+    p[DPO_P_NV] = R(11.4); p[DPO_P_NR] = R(57.0); p[DPO_P_NRR] = R(59.6);
+    p[DPO_P_NUV] = R(40.0); p[DPO_P_YUR] = R(25.3);
+}
+
 /* per-variant action bounds ENV:63,339,362,390 */
 static void FN(action_bounds)(const dpo_config* c, REAL bnd[6], int* n)
 {

@@ -32,7 +32,7 @@ G = os.path.join(ROOT, 'tests', 'golden')
 def vessel(preset):
     from oracle import oracle as O
     v = np.zeros(O.NPARAM, np.float64)
-    getattr(O.lib(), 'dpo_thrust_loss_vessel_f64' if preset == 'thrust_loss' else 'dpo_default_vessel_f64')(O._p(v))
+    getattr(O.lib(), {'thrust_loss': 'dpo_thrust_loss_vessel_f64', 'dynpos_fit': 'dpo_dynpos_fit_vessel_f64'}.get(preset, 'dpo_default_vessel_f64'))(O._p(v))
     return v
 
 
@@ -89,7 +89,7 @@ def ratios(w, sel=None):
 
 def main():
     names = ('pseudo-inverse', 'RL + integral')
-    for preset in ('no_loss', 'thrust_loss'):
+    for preset in ('no_loss', 'thrust_loss', 'dynpos_fit'):
         w = wrenches(preset)
         print('preset %s: mean wrench over t = 15 ... 60 s of the commands Cybersea received, in the oracle plant (body frame; Fx, Fy [N], Mz [N m])' % preset)
         print('%-15s %6s  %26s  %26s  %26s  %s' % ('allocator', 'flow', 'thrust in the current', 'hull asks for', 'net (0 = agreement)', 'recorded drift [mm/s, mdeg/s]'))

@@ -28,7 +28,7 @@ def test_the_records_are_station_keeping_runs():
 
 
 def test_net_wrench_of_the_recorded_commands_in_the_oracle_plant_is_bounded_per_flow_angle():
-    for preset, (bx, by, bn) in (('no_loss', (4.0, 5.5, 5.6)), ('thrust_loss', (2.6, 5.8, 5.1))):
+    for preset, (bx, by, bn) in (('no_loss', (4.0, 5.5, 5.6)), ('thrust_loss', (2.6, 5.8, 5.1)), ('dynpos_fit', (4.0, 4.6, 4.3))):
         w = DP.wrenches(preset)
         net = np.abs(w['net'])
         assert net[:, 0].max() < bx and net[:, 1].max() < by and net[:, 2].max() < bn, (preset, net.max(0))

@@ -562,3 +562,25 @@ def test_current_randomisation_on_the_shared_hull_equals_the_per_env_form(loss):
             oc, rc, dc, _ = c.step(act)
             od, rd, dd, _ = d.step(act)
             assert torch.equal(oc, od) and torch.equal(rc, rd) and torch.equal(dc, dd), t
+
+
+@pytest.mark.parametrize('kind', ['dynpos_fit', 'dynpos_fit_thrust_loss'])
+def test_dynpos_fit_preset_through_the_constructor_against_the_oracle(kind):
+    """dpenv_default_vessel_ex(DPENV_VESSEL_DYNPOS_FIT [| THRUST_LOSS]) as the one class of a handle (the default kernels / the shared training form):
+    25 steps of full side thrust from rest against the oracle holding the same vector, re-seeded from the GPU state every step"""
+    import ml4ca_amd
+    torch = torch_()
+    n = 600
+    vec = np.asarray(ml4ca_amd.default_vessel(kind), np.float32)
+    env, orc = H.make_pair('final_cont', n, vessel_params=vec, seed=2, terminate=False, time_limit=False)
+    env.reset(init=H.to_dev(np.zeros((6, n), np.float32)))
+    act = np.tile(np.array([[1.0, 0.4, 0.4, 1.0, 0.0, 1.0, 0.0]], np.float32), (n, 1))        # bow full, stern 40 % at 90 deg: sideways
+    act += 0.02 * np.random.RandomState(1).normal(size=act.shape).astype(np.float32)
+    for t in range(25):
+        g_st, g_ctr = env.get_state()
+        ost, octr = np.ascontiguousarray(g_st.cpu().numpy()), np.ascontiguousarray(g_ctr.cpu().numpy())
+        obs, rew, done, _ = env.step(H.to_dev(act))
+        oo, orw, od = orc.step(ost, octr, act)
+        TOL.assert_close(obs.cpu().numpy(), oo, TOL.OBS_FLOOR, what='obs step %d' % t)
+        TOL.assert_close(rew.cpu().numpy(), orw, TOL.REWARD_FLOOR, what='reward step %d' % t)
+    assert float(obs[:, 4].abs().mean()) > 0.1                                                   # it did move sideways

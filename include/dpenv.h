@@ -213,7 +213,8 @@ int dpenv_set_vessel_class(dpenv_handle h, const int32_t* class_id, dpenv_stream
 enum { DPENV_VESSEL_KEEP_RANDOMISATION = 1 };
 int dpenv_set_vessel_params_ex(dpenv_handle h, const float* params, uint32_t flags, dpenv_stream s);
 int dpenv_set_vessel_params(dpenv_handle h, const float* params, dpenv_stream s);
-/* The parameter vectors in force: DEVICE float[DPENV_NPARAM][n_envs].  Needs per-env blocks in force. */
+/* The parameter vectors in force: DEVICE float[DPENV_NPARAM][n_envs] - the per-env blocks, or, with ONE class and none in force, that class's
+ * vector in every column.  Refused with vessel classes (n_classes > 1) and no per-env blocks. */
 int dpenv_get_vessel_params(dpenv_handle h, float* params_out, dpenv_stream s);
 /* Domain randomisation through the reset path: from this call on EVERY reset of an env - dpenv_reset (also with explicit init),
  * auto-reset inside dpenv_step / dpenv_rollout / dpenv_policy_rollout, reset_at_end - starts the new episode on a freshly drawn hull:

@@ -97,7 +97,9 @@ def main():
                                                  'results/all_plots/current_box_test/plot_pos.py:78)')
     ap.add_argument('--randomise-current', default='', help="'RV,RB_DEG' with --current: every reset (also inside the rollout launch) draws the new episode's current, "
                                                            'V_c = max(0, V + RV u1), beta_c = BETA + RB u2 (dpenv_set_current_randomisation)')
-    ap.add_argument('--preset', default='no_loss', choices=('no_loss', 'thrust_loss', 'dynpos_fit', 'dynpos_fit_thrust_loss'), help='nominal hull (dpenv_default_vessel_ex)')
+    ap.add_argument('--preset', default='thrust_loss', choices=('no_loss', 'thrust_loss', 'dynpos_fit', 'dynpos_fit_thrust_loss'),
+                    help="nominal hull (dpenv_default_vessel_ex); default (round 6): the thrust-loss preset - the steady speeds 'with thrust losses' are the velocity "
+                         'bounds the reference trains with (customEnv.py:17,26), and the shared training form runs it at the cost of the default hull')
     ap.add_argument('--eval', action='store_true', help='after training: run_RL_policy + the box test (IAE, energy) on the nominal hull and on spreads of hulls')
     ap.add_argument('--eval-presets', default='', help="comma-separated presets to run --eval on (default: the training preset), e.g. 'no_loss,thrust_loss': "
                                                       'how an actor trained on one thrust regime fares on the other')

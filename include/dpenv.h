@@ -246,7 +246,8 @@ int dpenv_get_current_mean(dpenv_handle h, float* vc_out, float* beta_out, dpenv
  * words 0 and 1 of Philox4x32-10 keyed by config.seed with counter (global env id, episode counter, tag 3): a function of the env and of
  * its episode like the pose sample and the hull draw - independent of the rank count and of the launch form.  The drawn values become the
  * present current AND the mean the drift (config.current_drift) reverts to.  vc_nominal, beta_nominal: DEVICE float[n_envs], copied; NULL =
- * the means in force (what dpenv_set_current gave).  Until its first reset an env keeps the current it has.  Needs config.current_enabled.
+ * the means in force (what dpenv_set_current gave; a checkpoint restore passes the ORIGINAL nominals explicitly: by then the means are drawn
+ * values).  Until its first reset an env keeps the current it has.  Needs config.current_enabled.
  * The re-draw lives in the kernels that carry re-draws: with ONE class, the shared training form (hull and thrust-loss coefficients - zero for
  * a hull without a loss - as kernel arguments: the default's memory traffic, the default's rows until a reset draws); with per-env blocks in
  * force, the general per-env kernels; vessel classes (n_classes > 1 without per-env blocks) are refused, and so is returning to them with

@@ -584,3 +584,35 @@ def test_dynpos_fit_preset_through_the_constructor_against_the_oracle(kind):
         TOL.assert_close(obs.cpu().numpy(), oo, TOL.OBS_FLOOR, what='obs step %d' % t)
         TOL.assert_close(rew.cpu().numpy(), orw, TOL.REWARD_FLOOR, what='reward step %d' % t)
     assert float(obs[:, 4].abs().mean()) > 0.1                                                   # it did move sideways
+
+
+def test_checkpoint_restore_with_randomised_and_drifting_current_continues_bit_for_bit():
+    """a checkpoint of a run whose current is re-drawn per episode AND drifts: state + counters, present current, drift means, rng counters; restore =
+    fresh handle, set_current(means), set_current(present, present_only), set_current_randomisation(ORIGINAL nominals, ranges), set_rng_counters,
+    set_state - the run continues exactly like the uninterrupted one"""
+    torch = torch_()
+    n, k, m = 1800 + 5, 11, 22
+    rng = np.random.RandomState(6)
+    kw = dict(auto_reset=True, max_ep_len=7, seed=13, env_id_base=999)
+    a, _, cr = _cur_pair(n, drift=True, **kw)
+    a.reset()
+    acts = [H.to_dev(H.random_actions(rng, n, 7, scale=1.0)) for _ in range(k + m)]
+    for t in range(k):
+        a.step(acts[t])
+    st, ctr = (x.clone() for x in a.get_state())
+    cur, mean = [x.clone() for x in a.get_current()], [x.clone() for x in a.get_current_mean()]
+    nctr, dctr = (x.clone() for x in a.get_rng_counters())
+    assert int(ctr[1].min()) >= 1 and not torch.equal(cur[0], mean[0])                       # resets happened, and the present value has drifted off its mean
+    b, _ = H.make_pair('final_cont', n, current=True, current_drift=True, **kw)
+    b.set_current(*mean)
+    b.set_current(*cur, present_only=True)
+    b.set_current_randomisation(cr[0], cr[1], vc_nominal=H.to_dev(cr[2]), beta_nominal=H.to_dev(cr[3]))
+    b.set_rng_counters(nctr, dctr)
+    b.set_state(st, ctr)
+    for t in range(k, k + m):
+        oa, ra, da, _ = a.step(acts[t])
+        ob, rb, db, _ = b.step(acts[t])
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db), t
+    ca, cb = _currents(a), _currents(b)
+    assert np.array_equal(ca[0], cb[0]) and np.array_equal(ca[1], cb[1])
+    assert torch.equal(a.get_state()[0], b.get_state()[0]) and int(a.get_state()[1][1].min()) >= 3

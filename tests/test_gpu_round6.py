@@ -616,3 +616,25 @@ def test_checkpoint_restore_with_randomised_and_drifting_current_continues_bit_f
     ca, cb = _currents(a), _currents(b)
     assert np.array_equal(ca[0], cb[0]) and np.array_equal(ca[1], cb[1])
     assert torch.equal(a.get_state()[0], b.get_state()[0]) and int(a.get_state()[1][1].min()) >= 3
+
+
+@pytest.mark.parametrize('n', [1, 63, 64, 65, 257])
+def test_shared_training_form_on_tiny_and_ragged_batches_in_both_layouts(n):
+    """the shared training form (thrust-loss preset + per-episode current) at batch sizes around a wave, row-major and [dim][n] layouts: the rows of
+    the per-env form of the same hull, bit for bit"""
+    torch = torch_()
+    rng = np.random.RandomState(n)
+    kw = dict(auto_reset=True, max_ep_len=5, seed=3, vessel_params=preset())
+    for layout in ('aos', 'soa'):
+        a, _, _ = _cur_pair(n, drift=True, layout=layout, **kw)
+        b, _, _ = _cur_pair(n, drift=True, layout=layout, **kw)
+        b.set_vessel_params(preset())
+        a.reset(); b.reset()
+        for t in range(12):
+            act = H.random_actions(rng, n, 7, scale=1.0)
+            act_d = H.to_dev(act if layout == 'aos' else np.ascontiguousarray(act.T))
+            oa, ra, da, _ = a.step(act_d)
+            ob, rb, db, _ = b.step(act_d)
+            assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db), (layout, t)
+        ca, cb = _currents(a), _currents(b)
+        assert np.array_equal(ca[0], cb[0]) and np.array_equal(ca[1], cb[1]) and int(a.get_state()[1][1].min()) >= 2

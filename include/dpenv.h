@@ -201,9 +201,10 @@ int dpenv_set_vessel_class(dpenv_handle h, const int32_t* class_id, dpenv_stream
  * its first step.  If ANY env has a thrust-loss coefficient the general per-env kernels apply it (they read 32 B more per env-step; envs
  * without a coefficient get the rows of the plain per-env kernels bit for bit).  Whether any env has one is a word the packing kernel leaves
  * behind the table: the setter does NOT wait for it - it is stream-ordered and may be recorded into a HIP graph.  Outside a capture the word
- * also travels to the host behind an event and the next launch on this handle takes it from there (waiting for that one event if need be);
- * a launch that is itself being recorded, and every launch after a RECORDED setter, runs the general kernels, which read the word on the
- * device.  A refused call (bad flags, a HIP error) leaves the handle's switches - per-env blocks, randomisation, thrust loss - as they were.
+ * travels to the host behind an event and the next launch on this handle takes it from there (waiting for that one event if need be); a
+ * launch that is itself being recorded, and every launch after a RECORDED setter, runs the general kernels with the coefficients applied -
+ * zeros where there are none, which change no row.  A refused call (bad flags, a HIP error) leaves the handle's switches - per-env blocks,
+ * randomisation, thrust loss - as they were.
  * params == NULL: back to the vessel classes / the single class of dpenv_create (the shared-default fast path: parameters in SGPRs).
  * Switching between the paths voids HIP graphs captured before (the table's address is a kernel argument).
  * flags (dpenv_set_vessel_params_ex): DPENV_VESSEL_KEEP_RANDOMISATION - the table is installed while the domain randomisation STAYS in force

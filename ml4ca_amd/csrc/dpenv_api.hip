@@ -34,8 +34,9 @@ struct dpenv_s {
     float4* env_tab;        // per-env parameter blocks + thrust-loss rows ET[DRAW_GROUPS][env_stride] (dpenv_dev.h), always allocated
     int env_stride;
     uint32_t* loss_flag;    // device word BEHIND the table (ET[DRAW_GROUPS][stride] | flag): the packing kernel reports "some env has a thrust-loss
-                            //   coefficient" through it, and the general per-env kernels read it themselves while the host does not know (LOSS_DEVICE)
-    int loss_state;         // LOSS_OFF / LOSS_ON / LOSS_DEVICE -> StepArgs.loss_on (per-env blocks in force only)
+                            //   coefficient" through it; while the host does not know the answer (LOSS_UNKNOWN) the general per-env kernels run with
+                            //   the loss applied: zero coefficients are neutral bit for bit
+    int loss_state;         // LOSS_OFF / LOSS_ON / LOSS_UNKNOWN -> StepArgs.loss_on (per-env blocks in force only)
     bool loss_pending;      // the flag word is on its way to loss_host behind loss_ev: resolved (without blocking a capture) by the next launch
     hipEvent_t loss_ev;
     uint32_t* loss_host;    // pinned host word
@@ -76,7 +77,7 @@ struct dpenv_s {
     std::string err;
 };
 
-enum { LOSS_OFF = 0, LOSS_ON = 1, LOSS_DEVICE = 2 };
+enum { LOSS_OFF = 0, LOSS_ON = 1, LOSS_UNKNOWN = 2 };
 
 static thread_local std::string g_create_err;
 
@@ -579,8 +580,8 @@ extern "C" int dpenv_set_current_randomisation(dpenv_handle h, const float* vc_n
 }
 
 // The packing kernel's flag word is on its way to the host (dpenv_set_vessel_params): take it if it has arrived; wait for it unless the launch
-// that asks is being RECORDED into a graph - a recorded launch (and every launch after a setter that was itself recorded) leaves the
-// question to the kernel, which reads the word where the packing kernel left it (StepArgs.loss_on == 2; thrust_loss_on, dpenv_env_dev.h)
+// that asks is being RECORDED into a graph - a recorded launch (and every launch after a setter that was itself recorded) runs the general
+// per-env kernels with the table's coefficients applied (LOSS_TABLE): where no env has one they are zeros, which leave every row as it is
 static void resolve_loss(dpenv_handle h, hipStream_t s)
 {
     if (!h->loss_pending) return;
@@ -592,7 +593,7 @@ static void resolve_loss(dpenv_handle h, hipStream_t s)
         if (cap != hipStreamCaptureStatusNone) return;
         q = hipEventSynchronize(h->loss_ev);
     }
-    if (q != hipSuccess) { (void)hipGetLastError(); return; }            // the device-side reading stays in force
+    if (q != hipSuccess) { (void)hipGetLastError(); return; }            // unknown stays unknown: the loss stays applied
     h->loss_state = *(volatile uint32_t*)h->loss_host != 0u ? LOSS_ON : LOSS_OFF;
     h->loss_pending = false;
 }
@@ -611,7 +612,7 @@ static void bind_optional(dpenv_handle h, StepArgs& a, hipStream_t s)
     a.env_stride = h->env_stride;
     // the per-episode current re-draw lives in the general per-env kernels and in the shared training form (one class)
     const bool cr = h->cur_rand && h->cfg.current_enabled && (h->per_env || h->n_classes == 1);
-    a.loss_on = h->per_env ? h->loss_state : ((h->shared_loss || cr) ? (int)LOSS_SHARED : (int)LOSS_NONE);
+    a.loss_on = h->per_env ? (h->loss_state == LOSS_OFF ? (int)LOSS_NONE : (int)LOSS_TABLE) : ((h->shared_loss || cr) ? (int)LOSS_SHARED : (int)LOSS_NONE);
     a.rand_tab = (h->per_env && h->randomise) ? h->rand_tab : nullptr;
     a.cur_nom = cr ? h->cur_nom : nullptr;
     a.cur_nom_stride = h->env_stride;
@@ -671,7 +672,7 @@ extern "C" int dpenv_set_vessel_params_ex(dpenv_handle h, const float* params, u
     HIP_TRY(h, dpenv_dev_launch_pack_env_vessels(params, (int64_t)h->cfg.n_envs, 1, h->env_tab, h->loss_flag, h->env_stride, h->cfg.n_envs, (hipStream_t)s));
     // which kernels run from here on depends on that word (the general per-env form applies the loss, the plain one does not carry the code).
     // Outside a capture it also travels to a pinned host word behind an event: the next launch takes the answer from there (resolve_loss);
-    // recorded into a graph the setter leaves it on the device, where the general kernels read it themselves.
+    // recorded into a graph the setter leaves the answer unknown: the general kernels then apply the table's coefficients whatever they are.
     bool pending = false;
     if (cap == hipStreamCaptureStatusNone) {
         HIP_TRY(h, hipMemcpyAsync(h->loss_host, h->loss_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)s));
@@ -681,7 +682,7 @@ extern "C" int dpenv_set_vessel_params_ex(dpenv_handle h, const float* params, u
     h->per_env = true;
     if (!keep) h->randomise = false;
     if (h->randomise && h->rand_loss) { h->loss_state = LOSS_ON; h->loss_pending = false; }     // every drawn hull has a coefficient: nothing to ask
-    else { h->loss_state = LOSS_DEVICE; h->loss_pending = pending; }
+    else { h->loss_state = LOSS_UNKNOWN; h->loss_pending = pending; }
     return DPENV_OK;
 }
 

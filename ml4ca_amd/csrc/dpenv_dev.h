@@ -70,8 +70,8 @@ enum { VES_ARGS = 0,      // one class: kernel arguments (SGPRs)
                           //   the default's memory traffic, not at 160 B per env-step of identical per-env blocks
 // StepArgs.loss_on
 enum { LOSS_NONE = 0,     // no thrust loss anywhere
-       LOSS_TABLE = 1,    // some env of the per-env table has a coefficient (the host knows)
-       LOSS_TABLE_FLAG = 2, // ask the table: the word behind it, written by pack_env_vessels_kernel (thrust_loss_on, dpenv_env_dev.h)
+       LOSS_TABLE = 1,    // the per-env table's coefficients are applied: some env has one - or the host does not know yet (a setter recorded into a
+                          //   graph, an answer still on its way): zero coefficients are neutral bit for bit, so assuming a loss is always right
        LOSS_SHARED = 3 }; // the single class's coefficients in StepArgs.kl (possibly all zero): only kernels instantiated for it are launched with this value
 
 struct StepArgs {

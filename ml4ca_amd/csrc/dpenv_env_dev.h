@@ -385,15 +385,13 @@ struct ThrustLoss {
     float u, v, r;
 };
 
-// StepArgs.loss_on (LOSS_*, dpenv_dev.h) for the kernels that read the per-env TABLE: LOSS_TABLE = the host knows that some env has a coefficient;
-// LOSS_TABLE_FLAG = ask the table: the word behind it, ET[DRAW_GROUPS][stride] | flag, where pack_env_vessels_kernel left the answer - a
-// dpenv_set_vessel_params that was recorded into a graph, or whose answer has not reached the host yet (dpenv_api.hip: resolve_loss), costs no
-// read-back this way.  Launch-uniform either way.
-__device__ __forceinline__ bool thrust_loss_on(const StepArgs& a)
-{
-    if (a.loss_on == LOSS_TABLE_FLAG) return *reinterpret_cast<const uint32_t*>(a.env_tab + (int64_t)DRAW_GROUPS * a.env_stride) != 0u;
-    return a.loss_on == LOSS_TABLE;
-}
+// StepArgs.loss_on (LOSS_*, dpenv_dev.h) for the kernels that read the per-env TABLE: LOSS_TABLE = apply the table's coefficients.  The host sets it
+// when it knows that some env has one AND while it does not know (dpenv_set_vessel_params recorded into a graph, or its answer - a word the
+// packing kernel leaves behind the table - still on its way: dpenv_api.hip resolve_loss): an env without a coefficient gets F - (0 |n|) u_a = F,
+// the rows of the kernels that do not carry the code bit for bit (tested), so assuming a loss costs 32 B per env-step and never a wrong row.
+// A plain kernel argument: the table loads below are issued with the step's opening burst (round 6 tried a device-side flag read here; the loads
+// then sat behind it and the general per-env step kernel lost 3 %, profiles/LAB_NOTES.md).
+__device__ __forceinline__ bool thrust_loss_on(const StepArgs& a) { return a.loss_on == LOSS_TABLE; }
 // `il` argument of env_step_chain / env_step: where the step's thrust-loss coefficients come from.  A compile-time constant in every kernel
 // but the one-wave closed loop (which always passes its env index and decides at run time).
 constexpr int IL_NONE = -1;        // no loss code compiled in: the kernel is what it was before the loss existed

@@ -103,8 +103,8 @@ def test_a_refused_set_vessel_params_leaves_loss_and_redraws_in_force(kind):
 @pytest.mark.parametrize('loss', [0.0, 0.1])
 def test_set_vessel_params_recorded_into_a_graph(loss):
     """The setter no longer reads a word back: it is stream-ordered and can be recorded.  A graph of {set the table, 3 steps} replayed gives the
-    rows of the same calls made eagerly on a second handle - with thrust-loss coefficients in the table (the kernels read the packing
-    kernel's flag word on the device) and without."""
+    rows of the same calls made eagerly on a second handle - with thrust-loss coefficients in the table and without (a recorded setter leaves
+    the question open: the general kernels then apply the coefficients, zeros included, which change no row)."""
     torch = torch_()
     n = 2048 + 5
     rng = np.random.RandomState(11)

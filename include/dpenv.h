@@ -84,9 +84,9 @@ enum {
     DPENV_P_NUV, DPENV_P_YUR, /* speed-proportional cross-flow terms: yaw moment -N_uv u v (adds to the Munk moment -(m22-m11) u v; N_uv < -(m22-m11) would make the hull weathervane-stable), sway force -Y_ur u r */
     /* BUILD-OWNED inflow thrust loss (the linear open-water characteristic, Fossen 2011 eq. 9.7): F = K n|n| - Kl |n| u_a, u_a = the speed through
      * the water of the thruster's position along its axis at the start of the env step, never past zero thrust; [N per percent per m/s], >= 0.
-     * 0 (the default hull) is the reference's law F = K n|n| (SupervisedTau.py:42-83) exactly.  Non-zero coefficients are carried by per-env
-     * blocks only - a single class given to dpenv_create is then installed as such, vessel CLASSES (n_classes > 1) may not have them - and select
-     * the general per-env kernels (what it costs: DESIGN.md section 3). */
+     * 0 (the default hull) is the reference's law F = K n|n| (SupervisedTau.py:42-83) exactly.  Non-zero coefficients are carried by the SINGLE
+     * class of dpenv_create (kernel arguments: the shared training form, the default's cost) or by per-env blocks (the general per-env kernels);
+     * vessel CLASSES (n_classes > 1) may not have them. */
     DPENV_P_KLF_BOW, DPENV_P_KLF_PORT, DPENV_P_KLF_STAR, /* n >= 0 */
     DPENV_P_KLR_BOW, DPENV_P_KLR_PORT, DPENV_P_KLR_STAR, /* n < 0 */
     DPENV_NPARAM = 32,

@@ -129,7 +129,7 @@ def test_envs_without_a_coefficient_get_the_rows_of_the_kernels_without_the_loss
 
 
 def test_the_preset_through_the_constructor_and_its_steady_speeds():
-    """dpenv_default_vessel_ex(DPENV_VESSEL_THRUST_LOSS) as the single class: installed as per-env blocks (every env the same), steps like
+    """dpenv_default_vessel_ex(DPENV_VESSEL_THRUST_LOSS) as the single class (round 6: hull and coefficients as kernel arguments, the shared training form), steps like
     the oracle with that vessel, also on the way to the reference's second set of recorded speeds, +1.4 / -1.1 m/s (customEnv.py:17)."""
     import ml4ca_amd
     torch = torch_()

@@ -6,8 +6,8 @@ Usage: python tools/soak_determinism.py [launches=60] [randomise=0] [preset=no_l
 episode's current, 0.2 +- C m/s from any direction (dpenv_set_current_randomisation: the shared training form with one class, the general per-env
 kernels with randomised hulls); the currents join the digest.  randomise R > 0 (round 5): hulls re-drawn at every reset inside
 the launches (the RND instantiations of the two-wave kernels, the function-call draw of the one-wave kernels); the table of hulls joins the digest.
-preset thrust_loss: the nominal hull carries inflow thrust-loss coefficients (the general per-env kernels apply them; with R = 0 every env runs on the
-preset itself, installed as per-env blocks)"""
+preset thrust_loss: the nominal hull carries inflow thrust-loss coefficients (with R > 0 the general per-env kernels apply them; with R = 0 every env runs on
+the preset itself as the handle's one class: the shared training form)"""
 import os
 import sys
 

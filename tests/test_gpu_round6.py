@@ -638,3 +638,32 @@ def test_shared_training_form_on_tiny_and_ragged_batches_in_both_layouts(n):
             assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db), (layout, t)
         ca, cb = _currents(a), _currents(b)
         assert np.array_equal(ca[0], cb[0]) and np.array_equal(ca[1], cb[1]) and int(a.get_state()[1][1].min()) >= 2
+
+
+@pytest.mark.parametrize('form', ['one_wave', 'two_wave'])
+@pytest.mark.parametrize('mode,ext,act', [('final_cont', True, 'leaky'), ('limited', False, 'leaky'), ('final_cont', True, 'tanh')])
+def test_shared_hull_with_loss_and_redrawn_current_in_every_closed_loop_route(form, mode, ext, act):
+    """one class with thrust-loss coefficients + dpenv_set_current_randomisation through the closed loop's routes: the shared training form of the
+    two-wave kernels (shipped configuration), and the one-wave kernels everything else is sent to (they read the class hull from its table image and
+    re-draw the current behind a run-time switch) - the stored actions replayed through dpenv_step give the same rows, state and currents"""
+    from ml4ca_amd.policy import policy_rollout
+    torch = torch_()
+    n, T = 900 + 7, 24
+    envs = []
+    for _ in range(2):
+        e, _ = H.make_pair(mode, n, ext=ext, auto_reset=True, max_ep_len=7, seed=8, current=True, current_drift=True, vessel_params=preset())
+        e.set_current(torch.full((n,), 0.2, device=e.device), torch.full((n,), 2.0, device=e.device))
+        e.set_current_randomisation(0.1, 1.0)
+        e.reset()
+        envs.append(e)
+    env, env2 = envs
+    make_ac(env.num_states, env.num_actions, (80, 80, 80), seed=2, device=env.device, activation=act).upload(env, precision='f16', launch_form=form if act == 'leaky' else 'auto')
+    out = policy_rollout(env, T, sample=True)
+    for t in range(T):
+        o, r, d, _ = env2.step(out['act'][t].contiguous())
+        nxt = out['obs'][t + 1] if t + 1 < T else out['last_obs']
+        assert torch.equal(r, out['rew'][t]) and torch.equal(d, out['done'][t]) and torch.equal(o, nxt), (mode, t)
+    sa, sb = env.get_state(), env2.get_state()
+    assert torch.equal(sa[0], sb[0]) and torch.equal(sa[1], sb[1]) and int(sa[1][1].min()) >= 2
+    ca, cb = _currents(env), _currents(env2)
+    assert np.array_equal(ca[0], cb[0]) and np.array_equal(ca[1], cb[1])
